@@ -1,0 +1,297 @@
+"""ctypes binding of the CPU ORACLE (oracle/libibf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Product code (readbouncer_amd/, include/) never
+imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libibf_oracle.so")
+
+OK, ERR_NULL_FILTER, ERR_SHORT_READ, ERR_COUNT_KMER, ERR_IO, ERR_PARSE, ERR_BAD_CHUNK = range(7)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ibf_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+_u64p = C.POINTER(C.c_uint64)
+_u8p = C.POINTER(C.c_uint8)
+_u16p = C.POINTER(C.c_uint16)
+_u32p = C.POINTER(C.c_uint32)
+_vpp = C.POINTER(C.c_void_p)
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    L.orc_ibf_new.restype = C.c_void_p
+    L.orc_ibf_new.argtypes = [C.c_uint64] * 4
+    L.orc_ibf_wrap.restype = C.c_void_p
+    L.orc_ibf_wrap.argtypes = [C.c_uint64] * 4 + [C.c_void_p]
+    L.orc_ibf_free.argtypes = [C.c_void_p]
+    L.orc_ibf_words.restype = C.c_void_p
+    L.orc_ibf_words.argtypes = [C.c_void_p]
+    L.orc_ibf_n_words.restype = C.c_uint64
+    L.orc_ibf_n_words.argtypes = [C.c_void_p]
+    L.orc_ibf_info.argtypes = [C.c_void_p] + [_u64p] * 6
+    L.orc_kmer_value.restype = C.c_uint64
+    L.orc_kmer_value.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_block_index.restype = C.c_uint64
+    L.orc_block_index.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+    L.orc_ibf_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+    L.orc_ibf_count.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_ibf_store.restype = C.c_int
+    L.orc_ibf_store.argtypes = [C.c_void_p, C.c_char_p]
+    L.orc_ibf_load.restype = C.c_void_p
+    L.orc_ibf_load.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
+    L.orc_calculate_ci.argtypes = [C.c_double, C.c_uint8, C.c_uint32, C.c_double, _u16p, _u16p]
+    L.orc_normal_cdf_inverse.restype = C.c_double
+    L.orc_normal_cdf_inverse.argtypes = [C.c_double, C.POINTER(C.c_int)]
+    L.orc_threshold.restype = C.c_uint16
+    L.orc_threshold.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double]
+    L.orc_max_matches.restype = C.c_uint64
+    L.orc_max_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint16]
+    L.orc_select_matches.restype = C.c_int
+    L.orc_select_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint16]
+    L.orc_raw_max.restype = C.c_uint16
+    L.orc_raw_max.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.orc_count_matches.restype = C.c_uint64
+    L.orc_count_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double]
+    L.orc_classify_any.restype = C.c_int
+    L.orc_classify_any.argtypes = [_vpp, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
+                                   C.POINTER(C.c_int)]
+    L.orc_classify_best.restype = C.c_int
+    L.orc_classify_best.argtypes = L.orc_classify_any.argtypes
+    L.orc_classify_pair.restype = C.c_int
+    L.orc_classify_pair.argtypes = [_vpp, C.c_size_t, _vpp, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_double, C.c_double, _u64p, _u64p]
+    L.orc_check_unblock.restype = C.c_int
+    L.orc_check_unblock.argtypes = [_vpp, C.c_size_t, _vpp, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_double, C.c_double, _u8p]
+    L.orc_classify_read_chunks.restype = C.c_int
+    L.orc_classify_read_chunks.argtypes = [_vpp, C.c_size_t, _vpp, C.c_size_t, C.c_char_p, C.c_size_t,
+                                           C.c_uint32, C.c_uint32, C.c_double, C.c_double,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _u32p]
+    L.orc_calculate_filter_size_bits.restype = C.c_uint64
+    L.orc_calculate_filter_size_bits.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64]
+    L.orc_cut_out_nnns.restype = C.c_size_t
+    L.orc_cut_out_nnns.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
+    L.orc_add_sequence.restype = C.c_uint64
+    L.orc_add_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64,
+                                   C.c_uint64]
+    L.orc_synth_word.restype = C.c_uint64
+    L.orc_synth_word.argtypes = [C.c_uint64, C.c_uint64]
+    L.orc_ibf_fill_synth.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_batch_raw_max.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int,
+                                    C.c_void_p]
+    L.orc_batch_check_unblock.argtypes = [_vpp, C.c_size_t, _vpp, C.c_size_t, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int,
+                                          C.c_void_p, C.c_void_p]
+    L.orc_dna5_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    L.orc_revcomp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    _lib = L
+    return L
+
+
+def encode(seq):
+    """ASCII (str/bytes) -> numpy uint8 Dna5 ordinals."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = np.empty(len(seq), dtype=np.uint8)
+    lib().orc_dna5_encode(seq, len(seq), out.ctypes.data)
+    return out
+
+
+def revcomp(ord_arr):
+    out = np.empty_like(ord_arr)
+    lib().orc_revcomp(ord_arr.ctypes.data, len(ord_arr), out.ctypes.data)
+    return out
+
+
+def _ptr_array(filters):
+    arr = (C.c_void_p * max(1, len(filters)))()
+    for i, f in enumerate(filters):
+        arr[i] = f.h
+    return C.cast(arr, _vpp)
+
+
+class OracleIBF:
+    """Owning handle around orc_ibf."""
+
+    def __init__(self, n_bins=None, n_hash=3, kmer_size=13, n_bits=None, _handle=None, _keep=None):
+        L = lib()
+        if _handle is not None:
+            self.h = _handle
+        else:
+            self.h = L.orc_ibf_new(n_bins, n_hash, kmer_size, n_bits)
+            if not self.h:
+                raise ValueError("orc_ibf_new failed")
+        self._keep = _keep
+        v = [C.c_uint64() for _ in range(6)]
+        L.orc_ibf_info(self.h, *[C.byref(x) for x in v])
+        (self.n_bins, self.n_hash, self.kmer_size, self.n_bits, self.n_blocks, self.bin_width) = [x.value for x in v]
+
+    @classmethod
+    def wrap(cls, n_bins, n_hash, kmer_size, n_bits, words):
+        """Non-owning view over a numpy uint64 array holding the sdsl payload."""
+        assert words.dtype == np.uint64 and words.flags["C_CONTIGUOUS"]
+        assert len(words) >= (n_bits + 256 + 63) // 64
+        h = lib().orc_ibf_wrap(n_bins, n_hash, kmer_size, n_bits, words.ctypes.data)
+        return cls(_handle=h, _keep=words)
+
+    @classmethod
+    def load(cls, path):
+        st = C.c_int(0)
+        h = lib().orc_ibf_load(os.fsencode(path), C.byref(st))
+        if not h:
+            raise IOError("orc_ibf_load(%s) failed with status %d" % (path, st.value))
+        return cls(_handle=h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orc_ibf_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def words(self):
+        n = lib().orc_ibf_n_words(self.h)
+        p = lib().orc_ibf_words(self.h)
+        return np.ctypeslib.as_array(C.cast(p, _u64p), shape=(n,))
+
+    def store(self, path):
+        st = lib().orc_ibf_store(self.h, os.fsencode(path))
+        if st != OK:
+            raise IOError("orc_ibf_store failed: %d" % st)
+
+    def insert(self, ord_arr, bin_no):
+        lib().orc_ibf_insert(self.h, ord_arr.ctypes.data, len(ord_arr), bin_no)
+
+    def add_sequence(self, ord_arr, fragment_length, first_bin=0, overlap_length=1500):
+        return lib().orc_add_sequence(self.h, ord_arr.ctypes.data, len(ord_arr), fragment_length,
+                                      self.kmer_size, overlap_length, first_bin)
+
+    def fill_synth(self, seed):
+        lib().orc_ibf_fill_synth(self.h, seed)
+
+    def count(self, ord_arr):
+        out = np.zeros(self.n_bins, dtype=np.uint16)
+        lib().orc_ibf_count(self.h, ord_arr.ctypes.data, len(ord_arr), out.ctypes.data)
+        return out
+
+    def raw_max(self, ord_arr):
+        return lib().orc_raw_max(self.h, ord_arr.ctypes.data, len(ord_arr))
+
+    def count_matches(self, ord_arr, r=0.1, conf=0.95):
+        return lib().orc_count_matches(self.h, ord_arr.ctypes.data, len(ord_arr), r, conf)
+
+    def block_index(self, kmer_value, hash_no):
+        return lib().orc_block_index(self.h, kmer_value, hash_no)
+
+
+def kmer_value(ord_arr, k):
+    return lib().orc_kmer_value(ord_arr.ctypes.data, k)
+
+
+def calculate_ci(r, k, readlen, conf):
+    lo, hi = C.c_uint16(), C.c_uint16()
+    lib().orc_calculate_ci(r, k, readlen, conf, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def threshold(readlen, k, r=0.1, conf=0.95):
+    return lib().orc_threshold(readlen, k, r, conf)
+
+
+def max_matches(fwd, rev, thr):
+    return lib().orc_max_matches(fwd.ctypes.data, rev.ctypes.data, len(fwd), thr)
+
+
+def select_matches(fwd, rev, thr):
+    return bool(lib().orc_select_matches(fwd.ctypes.data, rev.ctypes.data, len(fwd), thr))
+
+
+def classify_any(filters, ord_arr, r=0.1, conf=0.95):
+    found = C.c_int(0)
+    st = lib().orc_classify_any(_ptr_array(filters), len(filters), ord_arr.ctypes.data, len(ord_arr), r, conf,
+                                C.byref(found))
+    return st, bool(found.value)
+
+
+def classify_best(filters, ord_arr, r=0.1, conf=0.95):
+    best = C.c_int(-1)
+    st = lib().orc_classify_best(_ptr_array(filters), len(filters), ord_arr.ctypes.data, len(ord_arr), r, conf,
+                                 C.byref(best))
+    return st, best.value
+
+
+def classify_pair(f1, f2, ord_arr, r=0.1, conf=0.95):
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    st = lib().orc_classify_pair(_ptr_array(f1), len(f1), _ptr_array(f2), len(f2), ord_arr.ctypes.data,
+                                 len(ord_arr), r, conf, C.byref(a), C.byref(b))
+    return st, (a.value, b.value)
+
+
+def check_unblock(deplete, target, ord_arr, r=0.1, conf=0.95):
+    d = C.c_uint8(0)
+    st = lib().orc_check_unblock(_ptr_array(deplete), len(deplete), _ptr_array(target), len(target),
+                                 ord_arr.ctypes.data, len(ord_arr), r, conf, C.byref(d))
+    return st, d.value
+
+
+def classify_read_chunks(deplete, target, ascii_seq, chunk_length, max_chunks, r=0.1, conf=0.95):
+    if isinstance(ascii_seq, str):
+        ascii_seq = ascii_seq.encode()
+    ts, cl, bt, cu = C.c_int(0), C.c_int(0), C.c_int(-1), C.c_uint32(0)
+    st = lib().orc_classify_read_chunks(_ptr_array(deplete), len(deplete), _ptr_array(target), len(target),
+                                        ascii_seq, len(ascii_seq), chunk_length, max_chunks, r, conf,
+                                        C.byref(ts), C.byref(cl), C.byref(bt), C.byref(cu))
+    return dict(status=st, too_short=bool(ts.value), classified=bool(cl.value), best_target=bt.value,
+                chunks_used=cu.value)
+
+
+def calculate_filter_size_bits(fragment_length, k, h, max_fp, n_bins):
+    return lib().orc_calculate_filter_size_bits(fragment_length, k, h, max_fp, n_bins)
+
+
+def cut_out_nnns(seq):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = C.create_string_buffer(len(seq) + 1)
+    n = lib().orc_cut_out_nnns(seq, len(seq), out)
+    return out.raw[:n].decode()
+
+
+def synth_word(seed, idx):
+    return lib().orc_synth_word(seed, idx)
+
+
+def batch_raw_max(ibf, ascii_concat, offsets, lens, n_threads=1):
+    """ascii_concat: np.uint8 array; offsets: np.uint64; lens: np.uint32 -> np.uint16 raw maxima."""
+    out = np.zeros(len(lens), dtype=np.uint16)
+    lib().orc_batch_raw_max(ibf.h, ascii_concat.ctypes.data, offsets.ctypes.data, lens.ctypes.data,
+                            len(lens), n_threads, out.ctypes.data)
+    return out
+
+
+def batch_check_unblock(deplete, target, ascii_concat, offsets, lens, r=0.1, conf=0.95, n_threads=1):
+    dec = np.zeros(len(lens), dtype=np.uint8)
+    st = np.zeros(len(lens), dtype=np.uint8)
+    lib().orc_batch_check_unblock(_ptr_array(deplete), len(deplete), _ptr_array(target), len(target),
+                                  ascii_concat.ctypes.data, offsets.ctypes.data, lens.ctypes.data,
+                                  len(lens), r, conf, n_threads, dec.ctypes.data, st.ctypes.data)
+    return dec, st

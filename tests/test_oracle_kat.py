@@ -1,0 +1,237 @@
+"""Pins the CPU oracle against every known-answer value the reference's own tests hold
+for the hot path.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+# src/test/libIBFTests/read.hpp:22 -- six copies of a 59-mer
+READ_354 = "AAAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAGAGAGAGCCCCAAAAGAGAGGAGA" * 6
+# src/test/libIBFTests/read.hpp:113 and :273
+MER_35 = "AAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAG"
+MER_35_RC = "CTCTCCTCTCTCCTCTCTCGGGGGGGGGTTTTTTT"
+
+
+@pytest.fixture(scope="module")
+def test_ibf(refdata):
+    recs = H.read_fasta(os.path.join(refdata, "libIBFTests_test.fasta"))
+    return H.build_filter_like_reference([s for _, s in recs])
+
+
+@pytest.fixture(scope="module")
+def test1_ibf(refdata):
+    recs = H.read_fasta(os.path.join(refdata, "libIBFTests_test1.fasta"))
+    return H.build_filter_like_reference([s for _, s in recs])
+
+
+def test_calculate_ci_kat():
+    # read.hpp:154-164, 300-310: calculateCI(0.1, 13, 35, 0.95) == (5, 30); threshold == -7
+    assert po.calculate_ci(0.1, 13, 35, 0.95) == (5, 30)
+    assert np.int16(np.uint16(po.threshold(35, 13, 0.1, 0.95))) == -7
+    assert po.threshold(35, 13, 0.1, 0.95) == 65529  # as max_matches sees it (uint16_t)
+
+
+def test_z_score():
+    ok = po.C.c_int(0)
+    z = po.lib().orc_normal_cdf_inverse(0.975, po.C.byref(ok))
+    assert ok.value == 1 and abs(z - 1.96) < 1e-3  # read.hpp:352
+    po.lib().orc_normal_cdf_inverse(1.0, po.C.byref(ok))
+    assert ok.value == 0  # IBF.hpp:287-293 throws invalid_argument
+
+
+@pytest.mark.parametrize("L,k,r,expect", [
+    (360, 13, 0.1, 38), (360, 13, 0.08, 61), (360, 15, 0.1, 22), (250, 13, 0.1, 18), (354, 13, 0.1, 36),
+])
+def test_threshold_spot_values(L, k, r, expect):
+    # SURVEY 8a.6 values, re-derived from IBF.hpp:320-338 + IBFClassify.cpp:156-159
+    assert po.threshold(L, k, r, 0.95) == expect
+
+
+def test_threshold_edge_semantics():
+    # L <= ~100 at k=13, r=0.1: negative int16 threshold wraps to >= 0x8000 as uint16_t
+    assert po.threshold(100, 13, 0.1, 0.95) >= 0x8000
+    # len == k: varN < 0 -> sqrt NaN -> (uint16_t)NaN == 0 on x86-64 -> threshold == n == 1
+    assert po.threshold(13, 13, 0.1, 0.95) == 1
+
+
+def test_filter_size_bits_kat():
+    # createfilter.hpp:140-148: frag 100000, k 13, h 3, fp 0.01, 2 bins
+    assert po.calculate_filter_size_bits(100000, 13, 3, 0.01, 2) == 1236269 * 64 == 79121216
+    # B=1024 -> x1088, B=8192 -> x8256
+    assert po.calculate_filter_size_bits(100000, 13, 3, 0.01, 1024) == 1236269 * 1088
+    assert po.calculate_filter_size_bits(100000, 13, 3, 0.01, 8192) == 1236269 * 8256
+
+
+def test_cut_out_nnns_kat(refdata):
+    (_, seq), = H.read_fasta(os.path.join(refdata, "libIBFTests_test.fasta"))
+    assert seq == "AAAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAGAGAGAGCCCCAAAAGAGAGGAGATTTTANNNNNNNNTATATTATA"
+    # createfilter.hpp:135 (note the dropped last base, IBFBuild.cpp:121-125)
+    assert po.cut_out_nnns(seq) == "AAAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAGAGAGAGCCCCAAAAGAGAGGAGATTTTATATATTAT"
+    assert len(po.cut_out_nnns(seq)) == 72
+    assert po.cut_out_nnns("NNNN") == ""
+    assert po.cut_out_nnns("ACGTN") == "ACGT"
+    assert po.cut_out_nnns("ACGT") == "ACG"
+
+
+def test_fragment_loop_kat():
+    # createfilter.hpp:168-173: 72 bp sequence, F=100000 -> one fragment, next bin id 1
+    f = po.OracleIBF(2, 3, 13, 79121216)
+    nxt = f.add_sequence(po.encode("A" * 72), 100000, 0)
+    assert nxt == 1
+    # a 250001 bp sequence at F=100000: fragments [0,1e5) [99988,2e5) [199988,250001) -> 3 bins
+    f2 = po.OracleIBF(4, 3, 13, 64 * 4096)
+    assert f2.add_sequence(np.zeros(250001, dtype=np.uint8), 100000, 0) == 3
+    # len == F exactly: a second, 12-base fragment [99988,100000) still consumes a bin id (no k-mers)
+    assert f2.add_sequence(np.zeros(100000, dtype=np.uint8), 100000, 0) == 2
+
+
+def test_35mer_counts(test_ibf):
+    # read.hpp:144,150: fwd max 23, rev 0;  read.hpp:297,327: mirrored for the reverse complement
+    o = po.encode(MER_35)
+    fwd, rev = test_ibf.count(o), test_ibf.count(po.revcomp(o))
+    assert fwd.max() == 23 and rev.max() == 0
+    assert "".join("ACGTN"[x] for x in po.revcomp(o)) == MER_35_RC
+    o2 = po.encode(MER_35_RC)
+    fwd2, rev2 = test_ibf.count(o2), test_ibf.count(po.revcomp(o2))
+    assert fwd2.max() == 0 and rev2.max() == 23
+    # the test's own loop uses an int16 threshold (-7) => 23; production max_matches sees 65529 => 0
+    assert po.max_matches(fwd2, rev2, 0) == 23
+    assert po.max_matches(fwd2, rev2, po.threshold(35, 13)) == 0
+    assert test_ibf.count_matches(o2) == 0
+
+
+def test_354_read_count_matches(test_ibf, test1_ibf):
+    o = po.encode(READ_354)
+    assert len(o) == 354 and test_ibf.kmer_size == 13  # read.hpp:199-200
+    assert test_ibf.count_matches(o) == 282  # read.hpp:221-229
+    assert test1_ibf.count_matches(o) == 182
+    st, found = po.classify_any([test_ibf, test1_ibf], o)  # read.hpp:201-202
+    assert st == po.OK and found
+    st, best = po.classify_best([test_ibf, test1_ibf], o)  # read.hpp:231
+    assert st == po.OK and best == 0
+    st, pair = po.classify_pair([test_ibf], [test1_ibf], o)  # read.hpp:250-251
+    assert st == po.OK and pair == (282, 182)
+
+
+def test_exceptions(test_ibf):
+    o = po.encode(READ_354)
+    assert po.classify_any([], o)[0] == po.ERR_NULL_FILTER  # read.hpp:188
+    assert po.classify_best([], o)[0] == po.ERR_NULL_FILTER  # read.hpp:208
+    assert po.classify_pair([], [], o)[0] == po.ERR_NULL_FILTER  # read.hpp:241
+    assert po.classify_pair([test_ibf], [], o)[0] == po.ERR_NULL_FILTER
+    short = po.encode("ACGTACGTACGT")  # 12 < k
+    assert po.classify_any([test_ibf], short)[0] == po.ERR_SHORT_READ
+    assert po.classify_best([test_ibf], short)[0] == po.ERR_SHORT_READ
+    # pair overload silently skips filters whose k exceeds the read (IBFClassify.cpp:318,340)
+    assert po.classify_pair([test_ibf], [test_ibf], short) == (po.OK, (0, 0))
+
+
+@pytest.mark.parametrize("chunk_length,max_chunks,expect_found", [
+    (250, 5, 3),  # configReader.cpp:242-243 defaults -> the reference's expectation found == 3
+    (360, 5, 3),  # README-recommended 360 bp prefix with retries
+    (360, 1, 2),  # repo config.toml values: the third read's first 360 bp hold only 24 shared 13-mers (< 38)
+])
+def test_classify_integration_3_of_3(refdata, chunk_length, max_chunks, expect_found):
+    # src/test/classifyTests/classifygtests.hpp:70-79: found == 3, failed == 0, too_short == 0,
+    # readCounter == 3 (the test's config file is an absolute path outside the repo; the expectation is
+    # reproduced by the parser defaults chunk_length 250 / max_chunks 5, for k = 13 and k = 15)
+    ref = H.read_fasta(os.path.join(refdata, "classifyTests_test.fasta"))
+    reads = H.read_fastq(os.path.join(refdata, "classifyTests_test.fastq"))
+    assert [len(s) for _, s in reads] == [1628, 8177, 17298]  # CRLF file; SeqAn strips the \r
+    for k in (15, 13):
+        filt = H.build_filter_like_reference([s for _, s in ref], k=k)
+        for dep, tgt in (([filt], []), ([], [filt]), ([filt], [filt])):
+            found = failed = too_short = 0
+            for _, seq in reads:
+                res = po.classify_read_chunks(dep, tgt, seq, chunk_length, max_chunks)
+                found += res["classified"]
+                failed += res["status"] != po.OK
+                too_short += res["too_short"]
+            if dep and tgt:
+                # same filter on both sides: target and deplete both hit, also at r-0.02 => unclassified
+                assert (found, failed, too_short) == (0, 0, 0)
+            else:
+                assert (found, failed, too_short) == (expect_found, 0, 0)
+
+
+def test_store_load_roundtrip(tmp_path, test1_ibf):
+    p = tmp_path / "t.ibf"
+    test1_ibf.store(str(p))
+    sz = os.path.getsize(p)
+    assert sz == 8 + 8 * ((test1_ibf.n_bits + 256 + 63) // 64)
+    with open(p, "rb") as fh:
+        assert int.from_bytes(fh.read(8), "little") == test1_ibf.n_bits + 256
+    g = po.OracleIBF.load(str(p))
+    assert (g.n_bins, g.n_hash, g.kmer_size, g.n_bits) == (test1_ibf.n_bins, 3, 13, test1_ibf.n_bits)
+    nw = test1_ibf.n_bits // 64
+    assert np.array_equal(g.words()[:nw], test1_ibf.words()[:nw])
+    assert g.count_matches(po.encode(READ_354)) == 182
+    # a FASTA file is not an IBF (configReader.cpp:210-224 relies on retrieve failing)
+    q = tmp_path / "x.fasta"
+    q.write_text(">a\nACGT\n")
+    with pytest.raises(IOError):
+        po.OracleIBF.load(str(q))
+
+
+def test_unaligned_metadata_roundtrip(tmp_path):
+    f = po.OracleIBF(70, 3, 13, 128 * 1000 + 17)  # n_bits not a multiple of 64
+    f.insert(po.encode(H.random_dna(np.random.default_rng(1), 500)), 69)
+    p = tmp_path / "u.ibf"
+    f.store(str(p))
+    g = po.OracleIBF.load(str(p))
+    assert (g.n_bins, g.n_hash, g.kmer_size, g.n_bits) == (70, 3, 13, 128 * 1000 + 17)
+    assert np.array_equal(g.words()[: f.n_bits // 64], f.words()[: f.n_bits // 64])
+
+
+def test_hash_spec_restated():
+    # the recalled SeqAn constants in one place: seed, shift, block mapping, bit layout
+    f = po.OracleIBF(100, 3, 13, 128 * 977)
+    assert (f.bin_width, f.n_blocks) == (2, 977)
+    o = po.encode("ACGTACGTACGTA")
+    v = po.kmer_value(o, 13)
+    assert v == sum(int(x) * 5 ** (12 - i) for i, x in enumerate(o))
+    for i in range(3):
+        pre = (i ^ (13 * 0x90b45d39fb6da1fa)) & (2**64 - 1)
+        x = (pre * v) & (2**64 - 1)
+        x ^= x >> 27
+        assert f.block_index(v, i) == x % 977
+    f.insert(o, 77)
+    w = f.words()
+    for i in range(3):
+        bit = f.block_index(v, i) * 128 + 77
+        assert (int(w[bit // 64]) >> (bit % 64)) & 1
+    assert sum(bin(int(x)).count("1") for x in w) <= 3
+    c = f.count(o)
+    assert c[77] == 1 and c.sum() == 1
+
+
+def test_counts_multiplicity_and_strands():
+    rng = np.random.default_rng(7)
+    ref = H.random_dna(rng, 3000)
+    f = po.OracleIBF(3, 3, 13, 192 * 50021)  # B<64 path: one word per block
+    f.insert(po.encode(ref[:1000]), 0)
+    f.insert(po.encode(ref[1000:2000]), 1)
+    f.insert(po.encode(ref[2000:]), 2)
+    read = ref[1100:1400]
+    o = po.encode(read)
+    c = f.count(o)
+    assert c[1] == 288 and c[0] < 10 and c[2] < 10
+    rc = "".join("ACGTN"[x] for x in po.revcomp(o))
+    assert f.count(po.encode(rc))[1] < 10 and f.count(po.revcomp(po.encode(rc)))[1] == 288
+    assert f.raw_max(po.encode(rc)) == 288
+    # N-containing k-mers are hashed like any other (ordinal 4) and simply do not match
+    readn = read[:150] + "N" + read[151:]
+    assert f.count(po.encode(readn))[1] == 288 - 13
+
+
+def test_synth_fill_density_and_padding():
+    f = po.OracleIBF(100, 3, 13, 128 * 4096)
+    f.fill_synth(42)
+    w = f.words()[: f.n_blocks * f.bin_width].reshape(-1, 2)
+    ones0 = sum(bin(int(x)).count("1") for x in w[:, 0])
+    assert abs(ones0 / (64 * len(w)) - 55 / 256) < 0.01
+    assert all(int(x) >> 36 == 0 for x in w[:, 1])  # bins >= 100 stay clear
+    assert f.words()[f.n_blocks * f.bin_width:].sum() == 0
