@@ -1,0 +1,187 @@
+/*
+ * readbouncer_amd.h -- C ABI of the MI355X-native IBF read-classification engine.
+ *
+ * This is the drop-in boundary for ONE path of ReadBouncer: src/IBF classify
+ * (k-mer extraction -> h-fold hash -> IBF bulk-contains -> per-bin counting ->
+ * error-model threshold -> unblock/keep decision).  The reference exposes that path as
+ * a C++ static library whose types leak SeqAn templates (src/IBF/CMakeLists.txt:5,
+ * src/IBF/IBF.hpp:92-94), so there is no binary FFI to bind; every entry point below
+ * names the reference interface it replaces.  INTEGRATION.md shows the reference-side
+ * shim.  include/readbouncer_amd.hpp is the C++ mirror (interleave::Read, IBF, IBFMeta,
+ * ClassifyConfig, exceptions) over these calls.
+ *
+ * All compute entry points need a gfx950 device and fail with RB_ERR_NO_DEVICE /
+ * RB_ERR_HIP otherwise -- there is no CPU fallback.  Plain pointers and sizes only.
+ */
+#ifndef READBOUNCER_AMD_H_
+#define READBOUNCER_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_API __attribute__((visibility("default")))
+
+/* ---- status codes (the reference throws; src/IBF/IBFExceptions.hpp) ------------------ */
+enum rb_status {
+    RB_OK = 0,
+    RB_ERR_NULL_FILTER = 1,  /* NullFilterException      IBFExceptions.hpp:178 */
+    RB_ERR_SHORT_READ = 2,   /* ShortReadException       IBFExceptions.hpp:96  */
+    RB_ERR_COUNT_KMER = 3,   /* CountKmerException       IBFExceptions.hpp:123 */
+    RB_ERR_MISSING_FILE = 4, /* MissingIBFFileException  IBFExceptions.hpp:317 */
+    RB_ERR_PARSE_IBF = 5,    /* ParseIBFFileException    IBFExceptions.hpp:344 */
+    RB_ERR_BAD_CHUNK = 6,    /* chunk start beyond read end (classify.hpp:264-273, undefined there) */
+    RB_ERR_STORE = 7,        /* StoreFilterException */
+    RB_ERR_INVALID_ARG = 8,
+    RB_ERR_UNSUPPORTED = 9,  /* filter geometry outside what the kernels handle */
+    RB_ERR_NO_DEVICE = 10,   /* no gfx950 GPU visible: the engine has no CPU fallback */
+    RB_ERR_HIP = 11,         /* a HIP runtime call failed, see rb_last_error() */
+    RB_ERR_NOMEM = 12
+};
+
+RB_API const char *rb_status_string(int status);
+/* thread-local text of the last failure on the calling thread */
+RB_API const char *rb_last_error(void);
+RB_API const char *rb_version(void);
+/* number of visible HIP devices, or a negative rb_status */
+RB_API int rb_device_count(void);
+
+/* ---- filter geometry ------------------------------------------------------------------
+ * Mirrors the public members of interleave::TIbf =
+ * seqan::BinningDirectory<InterleavedBloomFilter, BDConfig<Dna5,Normal,Uncompressed>>
+ * that the reference reads (noOfBins: IBFClassify.cpp:27,58; kmerSize: :102,154,192,248;
+ * getNumberOfBins/getKmerSize: IBFBuild.cpp:380-381). */
+typedef struct rb_ibf_info {
+    uint64_t n_bins;     /* noOfBins */
+    uint64_t n_hash;     /* noOfHashFunc */
+    uint64_t kmer_size;  /* kmerSize */
+    uint64_t n_bits;     /* noOfBits, without the 256 metadata bits */
+    uint64_t bin_width;  /* 64-bit words per block = ceil(n_bins/64) */
+    uint64_t n_blocks;   /* n_bits / (64*bin_width) */
+    uint64_t n_words;    /* payload words incl. metadata = (n_bits+256+63)/64 */
+} rb_ibf_info;
+
+/* ---- host-side filter image (.ibf file <-> memory) ------------------------------------ */
+typedef struct rb_ibf rb_ibf;
+
+/* IBF::load_filter -> seqan::retrieve (src/IBF/IBFBuild.cpp:329-396).
+ * RB_ERR_MISSING_FILE if the file cannot be opened, RB_ERR_PARSE_IBF if it is not an IBF. */
+RB_API int rb_ibf_open(const char *path, rb_ibf **out);
+/* TIbf(bins, hash_functions, kmer_size, filter_size_bits) (src/IBF/IBFBuild.cpp:465): zeroed */
+RB_API int rb_ibf_create(uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits, rb_ibf **out);
+/* seqan::store (src/IBF/IBFBuild.cpp:505,307) */
+RB_API int rb_ibf_store(const rb_ibf *f, const char *path);
+RB_API int rb_ibf_get_info(const rb_ibf *f, rb_ibf_info *info);
+/* payload words (n_words of them), owned by the handle */
+RB_API uint64_t *rb_ibf_words(rb_ibf *f);
+RB_API void rb_ibf_close(rb_ibf *f);
+/* ConfigReader::filterException (src/config/configReader.cpp:210-224): 1 = IBF file, 0 = not */
+RB_API int rb_is_ibf_file(const char *path);
+
+/* ---- error model (host, double) -------------------------------------------------------
+ * calculateCI / NormalCDFInverse (src/IBF/IBF.hpp:320-338, 284-308) and the threshold
+ * expression of count_matches (src/IBF/IBFClassify.cpp:154-162), returned as the
+ * uint16_t that max_matches receives (negative int16 thresholds wrap). */
+RB_API int rb_calculate_ci(double error_rate, uint8_t kmer_size, uint32_t readlen, double significance,
+                           uint16_t *low, uint16_t *high);
+RB_API uint16_t rb_threshold(uint64_t readlen, uint64_t kmer_size, double error_rate, double significance);
+
+/* ---- build-side helpers (host) --------------------------------------------------------- */
+/* IBF::calculate_filter_size_bits (src/IBF/IBFBuild.cpp:404-413) */
+RB_API uint64_t rb_calculate_filter_size_bits(uint64_t fragment_length, uint64_t kmer_size,
+                                              uint64_t hash_functions, double max_fp, uint64_t n_bins);
+/* IBF::cutOutNNNs + concatenation (src/IBF/IBFBuild.cpp:81-88,112-132); out holds >= len bytes */
+RB_API size_t rb_cut_out_nnns(const char *seq, size_t len, char *out);
+/* fragment loop of add_sequences_to_filter (src/IBF/IBFBuild.cpp:165-204): fills
+ * starts/ends (capacity cap) and returns the number of fragments of a sequence of length len */
+RB_API size_t rb_fragment_bounds(uint64_t len, uint64_t fragment_length, uint64_t kmer_size,
+                                 uint64_t overlap_length, uint64_t *starts, uint64_t *ends, size_t cap);
+
+/* ---- device-resident filter (the IBF in HBM) -------------------------------------------
+ * Layout in HBM is the reference's own: block-major bit matrix, bin j of block b at bit
+ * b*64*bin_width + j, so a .ibf payload is uploaded verbatim. */
+typedef struct rb_dibf rb_dibf;
+
+RB_API int rb_dibf_create(int device, uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits,
+                          rb_dibf **out);
+RB_API int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out);
+/* load_filter straight into HBM, streamed through pinned staging (no full host copy) */
+RB_API int rb_dibf_open(int device, const char *path, rb_dibf **out);
+RB_API int rb_dibf_download(const rb_dibf *f, rb_ibf **out);
+RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
+RB_API void *rb_dibf_device_words(rb_dibf *f);
+RB_API int rb_dibf_device(const rb_dibf *f);
+RB_API void rb_dibf_free(rb_dibf *f);
+/* synthetic filler for benchmarks: every bin bit ~ Bernoulli(55/256), padding bits clear */
+RB_API int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed);
+/* seqan::insertKmer for a batch of fragments (src/IBF/IBFBuild.cpp:189-190) on the GPU:
+ * fragment i = seq[starts[i], ends[i]) goes to bin bins[i]. seq is host ASCII. */
+RB_API int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_t *starts,
+                          const uint64_t *ends, const uint64_t *bins, size_t n_fragments);
+/* one reference sequence through the reference fragmenter; *next_bin = first_bin + #fragments */
+RB_API int rb_dibf_add_sequence(rb_dibf *f, const char *seq, size_t len, uint64_t fragment_length,
+                                uint64_t overlap_length, uint64_t first_bin, uint64_t *next_bin);
+
+/* ---- classification engine --------------------------------------------------------------
+ * One engine per GPU.  It borrows the filters (like the reference's
+ * std::vector<IBFMeta>& DepletionFilters / TargetFilters, classify.hpp:142,
+ * adaptive_sampling.hpp:214) and owns streams, threshold tables and workspaces. */
+typedef struct rb_engine rb_engine;
+
+RB_API int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete,
+                            rb_dibf *const *target, size_t n_target, rb_engine **out);
+RB_API void rb_engine_destroy(rb_engine *e);
+
+enum rb_mode {
+    /* check_unblock (src/main/adaptive_sampling.hpp:35-113): decision 0 wait / 1 unblock / 2 stop_receiving */
+    RB_MODE_CHECK_UNBLOCK = 0,
+    /* one chunk of classify_reads (src/main/classify.hpp:275-292, 58-111): decision 1 = classified */
+    RB_MODE_CLASSIFY_CHUNK = 1
+};
+
+/* Batch form of Read::classify x3 + the decision, inputs and outputs in HOST memory.
+ *   seqs/offsets/lens : read i is the ASCII bytes seqs[offsets[i] .. offsets[i]+lens[i])
+ *                       ((seqan::Dna5String) conversion is done on the device)
+ *   error_rate        : ClassifyConfig::error_rate, by value (the reference mutates a shared
+ *                       config, adaptive_sampling.hpp:55-59); significance: 0.95 in the reference
+ *   out_maxcount      : [n_reads x (n_deplete+n_target)] raw max k-mer count over bins and both
+ *                       strands per filter, deplete filters first (before thresholding); may be NULL
+ *   out_best_target   : [n_reads] Read::classify(TargetFilters) -> index or -1; may be NULL
+ *   out_decision      : [n_reads] per rb_mode
+ *   out_status        : [n_reads] RB_OK / RB_ERR_SHORT_READ / RB_ERR_NULL_FILTER per read --
+ *                       one bad read never aborts the batch (classify.hpp:306-316)          */
+RB_API int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, const uint32_t *lens,
+                             size_t n_reads, double error_rate, double significance, int mode,
+                             uint16_t *out_maxcount, int32_t *out_best_target, uint8_t *out_decision,
+                             uint8_t *out_status);
+
+/* Same with every buffer already resident in HBM (device pointers) and asynchronous on
+ * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
+ * before returning).  max_len = an upper bound of lens[]. */
+RB_API int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens,
+                                    size_t n_reads, uint32_t max_len, double error_rate, double significance,
+                                    int mode, void *d_maxcount, void *d_best_target, void *d_decision,
+                                    void *d_status, void *stream);
+
+/* bin-sharded operation: restrict the engine to word columns
+ * [rank*ceil(W/world) , ...) of every block; out_maxcount then holds PARTIAL maxima that the
+ * caller combines with an all-reduce(max) before rb_decide_device. world=1 restores the default. */
+RB_API int rb_engine_set_column_shard(rb_engine *e, int rank, int world);
+/* decision stage alone (K2) on device-resident raw maxima */
+RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads,
+                            uint32_t max_len, double error_rate, double significance, int mode,
+                            void *d_best_target, void *d_decision, void *d_status, void *stream);
+
+/* time spent by the count kernels of the most recent rb_classify_batch* call on this engine,
+ * measured with hipEvents on the launch stream (ms); negative if unavailable */
+RB_API double rb_engine_last_kernel_ms(rb_engine *e);
+/* enable/disable per-call kernel event timing (default off; adds two event records per filter) */
+RB_API int rb_engine_set_timing(rb_engine *e, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* READBOUNCER_AMD_H_ */

@@ -1,0 +1,320 @@
+"""ctypes binding of libreadbouncer_amd.so (the C ABI declared in include/readbouncer_amd.h).
+
+This is plumbing for tests and bench.py: every call goes straight to the HIP library.  There is
+no Python or CPU implementation of the hot path here -- if the shared library is missing the
+import fails, and if no GPU is visible every compute call raises RBError(RB_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libreadbouncer_amd.so")
+
+(RB_OK, RB_ERR_NULL_FILTER, RB_ERR_SHORT_READ, RB_ERR_COUNT_KMER, RB_ERR_MISSING_FILE, RB_ERR_PARSE_IBF,
+ RB_ERR_BAD_CHUNK, RB_ERR_STORE, RB_ERR_INVALID_ARG, RB_ERR_UNSUPPORTED, RB_ERR_NO_DEVICE, RB_ERR_HIP,
+ RB_ERR_NOMEM) = range(13)
+RB_MODE_CHECK_UNBLOCK, RB_MODE_CLASSIFY_CHUNK = 0, 1
+
+
+class IbfInfo(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("n_bins", "n_hash", "kmer_size", "n_bits", "bin_width", "n_blocks", "n_words")]
+
+
+class RBError(RuntimeError):
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = lib().rb_last_error().decode(errors="replace")
+        super().__init__("%s: status %d (%s) %s" % (where, status, lib().rb_status_string(status).decode(), msg))
+
+
+# every exported symbol with (restype, argtypes); tests check the .so exports exactly these
+_vp, _u64, _u32, _sz, _dbl, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_size_t, C.c_double, C.c_int
+_pp = C.POINTER(C.c_void_p)
+SIGNATURES = {
+    "rb_status_string": (C.c_char_p, [_int]),
+    "rb_last_error": (C.c_char_p, []),
+    "rb_version": (C.c_char_p, []),
+    "rb_device_count": (_int, []),
+    "rb_ibf_open": (_int, [C.c_char_p, _pp]),
+    "rb_ibf_create": (_int, [_u64, _u64, _u64, _u64, _pp]),
+    "rb_ibf_store": (_int, [_vp, C.c_char_p]),
+    "rb_ibf_get_info": (_int, [_vp, C.POINTER(IbfInfo)]),
+    "rb_ibf_words": (_vp, [_vp]),
+    "rb_ibf_close": (None, [_vp]),
+    "rb_is_ibf_file": (_int, [C.c_char_p]),
+    "rb_calculate_ci": (_int, [_dbl, C.c_uint8, _u32, _dbl, C.POINTER(C.c_uint16), C.POINTER(C.c_uint16)]),
+    "rb_threshold": (C.c_uint16, [_u64, _u64, _dbl, _dbl]),
+    "rb_calculate_filter_size_bits": (_u64, [_u64, _u64, _u64, _dbl, _u64]),
+    "rb_cut_out_nnns": (_sz, [C.c_char_p, _sz, C.c_char_p]),
+    "rb_fragment_bounds": (_sz, [_u64, _u64, _u64, _u64, _vp, _vp, _sz]),
+    "rb_dibf_create": (_int, [_int, _u64, _u64, _u64, _u64, _pp]),
+    "rb_dibf_upload": (_int, [_int, _vp, _pp]),
+    "rb_dibf_open": (_int, [_int, C.c_char_p, _pp]),
+    "rb_dibf_download": (_int, [_vp, _pp]),
+    "rb_dibf_get_info": (_int, [_vp, C.POINTER(IbfInfo)]),
+    "rb_dibf_device_words": (_vp, [_vp]),
+    "rb_dibf_device": (_int, [_vp]),
+    "rb_dibf_free": (None, [_vp]),
+    "rb_dibf_fill_synth": (_int, [_vp, _u64]),
+    "rb_dibf_insert": (_int, [_vp, _vp, _sz, _vp, _vp, _vp, _sz]),
+    "rb_dibf_add_sequence": (_int, [_vp, _vp, _sz, _u64, _u64, _u64, C.POINTER(_u64)]),
+    "rb_engine_create": (_int, [_int, _pp, _sz, _pp, _sz, _pp]),
+    "rb_engine_destroy": (None, [_vp]),
+    "rb_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
+    "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
+    "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_engine_last_kernel_ms": (_dbl, [_vp]),
+    "rb_engine_set_timing": (_int, [_vp, _int]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no fallback implementation" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(st, where):
+    if st != RB_OK:
+        raise RBError(st, where)
+
+
+def _ptr(a):
+    """numpy array / int / None -> void* value"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return int(a)
+
+
+def _info(handle, fn):
+    i = IbfInfo()
+    _check(fn(handle, C.byref(i)), "get_info")
+    return {k: getattr(i, k) for k, _ in IbfInfo._fields_}
+
+
+class HostIBF:
+    """rb_ibf: host image of a .ibf file (IBF::load_filter / TIbf ctor / seqan::store)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.info = _info(self.h, lib().rb_ibf_get_info)
+
+    @classmethod
+    def open(cls, path):
+        h = C.c_void_p()
+        _check(lib().rb_ibf_open(os.fsencode(path), C.byref(h)), "rb_ibf_open")
+        return cls(h)
+
+    @classmethod
+    def create(cls, n_bins, n_hash, kmer_size, n_bits):
+        h = C.c_void_p()
+        _check(lib().rb_ibf_create(n_bins, n_hash, kmer_size, n_bits, C.byref(h)), "rb_ibf_create")
+        return cls(h)
+
+    def words(self):
+        p = lib().rb_ibf_words(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(self.info["n_words"],))
+
+    def store(self, path):
+        _check(lib().rb_ibf_store(self.h, os.fsencode(path)), "rb_ibf_store")
+
+    def close(self):
+        if self.h:
+            lib().rb_ibf_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceIBF:
+    """rb_dibf: an IBF resident in HBM."""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.info = _info(self.h, lib().rb_dibf_get_info)
+
+    @classmethod
+    def create(cls, device, n_bins, n_hash, kmer_size, n_bits):
+        h = C.c_void_p()
+        _check(lib().rb_dibf_create(device, n_bins, n_hash, kmer_size, n_bits, C.byref(h)), "rb_dibf_create")
+        return cls(h)
+
+    @classmethod
+    def upload(cls, device, host):
+        h = C.c_void_p()
+        _check(lib().rb_dibf_upload(device, host.h, C.byref(h)), "rb_dibf_upload")
+        return cls(h)
+
+    @classmethod
+    def open(cls, device, path):
+        h = C.c_void_p()
+        _check(lib().rb_dibf_open(device, os.fsencode(path), C.byref(h)), "rb_dibf_open")
+        return cls(h)
+
+    def download(self):
+        h = C.c_void_p()
+        _check(lib().rb_dibf_download(self.h, C.byref(h)), "rb_dibf_download")
+        return HostIBF(h)
+
+    def device_words(self):
+        return lib().rb_dibf_device_words(self.h)
+
+    def fill_synth(self, seed):
+        _check(lib().rb_dibf_fill_synth(self.h, seed), "rb_dibf_fill_synth")
+
+    def insert(self, seq, starts, ends, bins):
+        if isinstance(seq, str):
+            seq = seq.encode()
+        starts = np.ascontiguousarray(starts, dtype=np.uint64)
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        bins = np.ascontiguousarray(bins, dtype=np.uint64)
+        buf = np.frombuffer(seq, dtype=np.uint8) if not isinstance(seq, np.ndarray) else seq
+        _check(lib().rb_dibf_insert(self.h, _ptr(np.ascontiguousarray(buf)), len(buf), _ptr(starts), _ptr(ends),
+                                    _ptr(bins), len(starts)), "rb_dibf_insert")
+
+    def add_sequence(self, seq, fragment_length, first_bin=0, overlap_length=1500):
+        if isinstance(seq, str):
+            seq = seq.encode()
+        buf = np.ascontiguousarray(np.frombuffer(seq, dtype=np.uint8))
+        nxt = C.c_uint64(0)
+        _check(lib().rb_dibf_add_sequence(self.h, _ptr(buf), len(buf), fragment_length, overlap_length, first_bin,
+                                          C.byref(nxt)), "rb_dibf_add_sequence")
+        return nxt.value
+
+    def free(self):
+        if self.h:
+            lib().rb_dibf_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _handle_array(filters):
+    arr = (C.c_void_p * max(1, len(filters)))()
+    for i, f in enumerate(filters):
+        arr[i] = f.h
+    return C.cast(arr, _pp)
+
+
+class Engine:
+    """rb_engine: per-GPU classifier over borrowed deplete/target filters."""
+
+    def __init__(self, device, deplete, target):
+        self._keep = (list(deplete), list(target))
+        self.nd, self.nt = len(deplete), len(target)
+        h = C.c_void_p()
+        _check(lib().rb_engine_create(device, _handle_array(deplete), len(deplete), _handle_array(target), len(target),
+                                      C.byref(h)), "rb_engine_create")
+        self.h = h
+
+    def classify(self, seqs, offsets, lens, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
+        """host buffers in, host numpy arrays out: (maxcount[n, nf], best_target[n], decision[n], status[n])"""
+        n = len(lens)
+        nf = self.nd + self.nt
+        maxcount = np.zeros((n, nf), dtype=np.uint16)
+        best = np.full(n, -1, dtype=np.int32)
+        decision = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint8)
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        _check(lib().rb_classify_batch(self.h, _ptr(seqs), _ptr(offsets), _ptr(lens), n, error_rate, significance, mode,
+                                       _ptr(maxcount), _ptr(best), _ptr(decision), _ptr(status)), "rb_classify_batch")
+        return maxcount, best, decision, status
+
+    def classify_device(self, d_seqs, d_offsets, d_lens, n_reads, max_len, error_rate=0.1, significance=0.95,
+                        mode=RB_MODE_CHECK_UNBLOCK, d_maxcount=None, d_best=None, d_decision=None, d_status=None,
+                        stream=None):
+        """raw device pointers (ints, e.g. torch.Tensor.data_ptr())"""
+        _check(lib().rb_classify_batch_device(self.h, d_seqs, d_offsets, d_lens, n_reads, max_len, error_rate,
+                                              significance, mode, d_maxcount, d_best, d_decision, d_status, stream),
+               "rb_classify_batch_device")
+
+    def decide_device(self, d_maxcount, d_lens, n_reads, max_len, error_rate=0.1, significance=0.95,
+                      mode=RB_MODE_CHECK_UNBLOCK, d_best=None, d_decision=None, d_status=None, stream=None):
+        _check(lib().rb_decide_device(self.h, d_maxcount, d_lens, n_reads, max_len, error_rate, significance, mode,
+                                      d_best, d_decision, d_status, stream), "rb_decide_device")
+
+    def set_column_shard(self, rank, world):
+        _check(lib().rb_engine_set_column_shard(self.h, rank, world), "rb_engine_set_column_shard")
+
+    def set_timing(self, on):
+        _check(lib().rb_engine_set_timing(self.h, int(on)), "rb_engine_set_timing")
+
+    def last_kernel_ms(self):
+        return lib().rb_engine_last_kernel_ms(self.h)
+
+    def destroy(self):
+        if self.h:
+            lib().rb_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def threshold(readlen, k, error_rate=0.1, significance=0.95):
+    return lib().rb_threshold(readlen, k, error_rate, significance)
+
+
+def calculate_ci(error_rate, k, readlen, significance):
+    lo, hi = C.c_uint16(), C.c_uint16()
+    st = lib().rb_calculate_ci(error_rate, k, readlen, significance, C.byref(lo), C.byref(hi))
+    return st, lo.value, hi.value
+
+
+def calculate_filter_size_bits(fragment_length, k, h, max_fp, n_bins):
+    return lib().rb_calculate_filter_size_bits(fragment_length, k, h, max_fp, n_bins)
+
+
+def cut_out_nnns(seq):
+    if isinstance(seq, str):
+        seq = seq.encode()
+    out = C.create_string_buffer(len(seq) + 1)
+    n = lib().rb_cut_out_nnns(seq, len(seq), out)
+    return out.raw[:n].decode()
+
+
+def fragment_bounds(length, fragment_length, k, overlap=1500):
+    n = lib().rb_fragment_bounds(length, fragment_length, k, overlap, None, None, 0)
+    s = np.zeros(n, dtype=np.uint64)
+    e = np.zeros(n, dtype=np.uint64)
+    lib().rb_fragment_bounds(length, fragment_length, k, overlap, _ptr(s), _ptr(e), n)
+    return s, e
+
+
+def is_ibf_file(path):
+    return bool(lib().rb_is_ibf_file(os.fsencode(path)))
+
+
+def device_count():
+    return lib().rb_device_count()

@@ -1,0 +1,104 @@
+// ibf_spec.h -- the single place holding the layout/hash constants of the IBF as SeqAn's
+// BinningDirectory<InterleavedBloomFilter, BDConfig<Dna5,Normal,Uncompressed>> defines them.
+//
+// The SeqAn fork the reference fetches at configure time (src/seqan/CMakeLists.txt.in:28-30,
+// JensUweUlrich/seqan branch "SeqAn") is not in the reference tree; these constants restate the
+// published binning_directory_interleaved_bloom_filter.h.  If a real .ibf ever contradicts
+// them, this header is the only edit.  Reference call sites that depend on them:
+//   seqan::count      src/IBF/IBFClassify.cpp:97-98,149-150
+//   seqan::insertKmer src/IBF/IBFBuild.cpp:190
+//   seqan::store      src/IBF/IBFBuild.cpp:505      seqan::retrieve  src/IBF/IBFBuild.cpp:343,360
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RB_HD __host__ __device__ __forceinline__
+#else
+#define RB_HD inline
+#endif
+
+namespace rbspec {
+
+constexpr uint64_t kSeed = 0x90b45d39fb6da1faULL;  // seedValue
+constexpr unsigned kShift = 27;                     // shiftValue
+constexpr unsigned kIntSize = 64;                   // intSize: bits per bin-column word
+constexpr unsigned kMetaBits = 256;                 // filterMetadataSize (4 x u64 at bit n_bits)
+constexpr unsigned kMaxHash = 8;                    // engine limit on noOfHashFunc
+constexpr unsigned kMaxKmer = 32;                   // engine limit on kmerSize (u64 base-5 value wraps above 27)
+
+// preCalcValues[i] = i ^ (kmerSize * seedValue)
+RB_HD uint64_t precalc(uint64_t kmer_size, uint64_t i) { return i ^ (kmer_size * kSeed); }
+
+// (seqan::Dna5String) conversion: A/a 0, C/c 1, G/g 2, T/t/U/u 3, everything else N = 4
+RB_HD uint32_t dna5_ord(uint32_t c)
+{
+    c &= 0xDFu;  // fold case: 'a'..'z' -> 'A'..'Z' (non letters land on values that match nothing below)
+    return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
+}
+
+// complement on ordinals (ModComplementDna for Dna5): A<->T, C<->G, N stays N
+RB_HD uint32_t dna5_comp(uint32_t o) { return o < 4u ? 3u - o : 4u; }
+
+// floor(2^64 / d) for d >= 2 (d = 1 handled by callers: everything maps to block 0)
+inline uint64_t fastmod_magic(uint64_t d)
+{
+    // 2^64 / d = (2^64 - 1) / d + (((2^64 - 1) % d + 1 == d) ? 1 : 0)
+    uint64_t q = ~0ULL / d, r = ~0ULL % d;
+    return (r + 1 == d) ? q + 1 : q;
+}
+
+RB_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+// x mod d with d < 2^32, magic = floor(2^64/d).  q_est = floor(x*magic / 2^64) is q or q-1
+// (x*magic/2^64 > x/d - 1), so one conditional subtraction finishes it.
+RB_HD uint32_t fastmod(uint64_t x, uint32_t d, uint64_t magic)
+{
+    uint64_t q = mulhi64(x, magic);
+    uint64_t r = x - q * d;
+    if (r >= d) r -= d;
+    return (uint32_t)r;
+}
+
+// hashToIndex(): idx = preCalc*v; idx ^= idx >> 27; idx %= noOfBlocks  (block NUMBER)
+RB_HD uint32_t block_index(uint64_t kmer_value, uint64_t pre, uint32_t n_blocks, uint64_t magic, uint32_t pow2_mask)
+{
+    uint64_t x = pre * kmer_value;
+    x ^= x >> kShift;
+    if (pow2_mask != 0xFFFFFFFFu) {  // n_blocks is a power of two <= 2^31: mask = n_blocks-1
+        return (uint32_t)x & pow2_mask;
+    }
+    return fastmod(x, n_blocks, magic);
+}
+
+RB_HD uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// synthetic filler: each bit ~ Bernoulli(55/256); 55/256 = .00110111b folded from the last digit
+RB_HD uint64_t synth_word(uint64_t seed, uint64_t word_index)
+{
+    uint64_t r[8];
+    for (int i = 0; i < 8; ++i) r[i] = mix64(seed + (word_index * 8 + (uint64_t)i + 1) * 0x9E3779B97F4A7C15ULL);
+    uint64_t acc = r[7];
+    acc |= r[6];
+    acc |= r[5];
+    acc &= r[4];
+    acc |= r[3];
+    acc |= r[2];
+    acc &= r[1];
+    acc &= r[0];
+    return acc;
+}
+
+}  // namespace rbspec

@@ -1,0 +1,55 @@
+// rb_device.h -- kernel argument structs and launcher declarations (HIP translation units only)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rb_internal.h"
+
+namespace rb {
+
+constexpr unsigned kMaxFilters = 16;
+
+// by-value kernel argument describing one HBM-resident IBF
+struct IbfDev {
+    const uint64_t *words;  // block-major bit matrix, reference layout
+    uint64_t magic;         // floor(2^64 / n_blocks) for the Barrett reduction
+    uint64_t precalc[rbspec::kMaxHash];
+    uint32_t n_blocks;
+    uint32_t pow2_mask;  // n_blocks - 1 when n_blocks is a power of two, else 0xFFFFFFFF
+    uint32_t n_bins;
+    uint32_t bin_width;
+    uint32_t k;
+    uint32_t n_hash;
+};
+
+struct CountLaunch {
+    IbfDev f;
+    const uint8_t *seqs;
+    const uint64_t *offsets;
+    const uint32_t *lens;
+    uint32_t n_reads;
+    uint32_t col_begin, col_end;  // word columns of every block this launch covers
+    uint32_t n_slices;            // column slices of 2^lg * wpl words
+    int lg, wpl, planes;
+    uint16_t *out;
+    uint32_t out_read_stride, out_slice_stride;
+};
+
+struct DecideParams {
+    uint32_t nd, nt;
+    uint32_t k[kMaxFilters];
+    const uint16_t *thr;  // [nf][2][thr_len]: thresholds at r and at r-0.02 by read length
+    uint32_t thr_len;
+};
+
+hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
+hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,
+                                uint32_t nf, uint32_t fidx, hipStream_t st);
+hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, uint32_t n_reads,
+                         int mode, int32_t *best_target, uint8_t *decision, uint8_t *status, hipStream_t st);
+hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,
+                         const uint64_t *ends, const uint64_t *bins, const uint64_t *kmer_prefix,
+                         uint32_t n_fragments, uint64_t total_kmers, hipStream_t st);
+hipError_t launch_fill_synth(uint64_t *words, uint64_t n_words, uint64_t used_words, uint32_t bin_width,
+                             uint64_t last_mask, uint64_t seed, hipStream_t st);
+
+}  // namespace rb

@@ -1,0 +1,556 @@
+// rb_engine.hip -- device-resident filters (rb_dibf) and the per-GPU classification engine.
+// Replaces, behind the C ABI: IBF::load_filter (src/IBF/IBFBuild.cpp:329-396), the three
+// Read::classify overloads (src/IBF/IBF.hpp:211-213), check_unblock
+// (src/main/adaptive_sampling.hpp:35-113) and one chunk of classify_reads
+// (src/main/classify.hpp:262-299), all in batch form.  No CPU fallback: every entry point that
+// computes fails with RB_ERR_NO_DEVICE / RB_ERR_HIP when there is no GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "rb_device.h"
+
+using namespace rb;
+
+#define RB_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            return rb::fail(e__ == hipErrorNoDevice ? RB_ERR_NO_DEVICE : RB_ERR_HIP,              \
+                            std::string(#call) + ": " + hipGetErrorString(e__));                  \
+        }                                                                                         \
+    } while (0)
+
+struct rb_dibf {
+    int device = 0;
+    rb_ibf_info geo{};
+    uint64_t *d_words = nullptr;
+    IbfDev dev{};
+};
+
+// growable device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return RB_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)256);
+        want = want + want / 4;  // slack so that slowly growing batches do not reallocate every call
+        RB_HIP(hipMalloc(&p, want));
+        cap = want;
+        return RB_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct rb_engine {
+    int device = 0;
+    std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
+    uint32_t nd = 0, nt = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    double last_kernel_ms = -1.0;
+    int shard_rank = 0, shard_world = 1;
+    // threshold tables
+    DevBuf d_thr;
+    uint32_t thr_len = 0;
+    double thr_r = -1.0, thr_conf = -1.0;
+    // workspaces
+    DevBuf d_part, d_maxcount;
+    // staging for the host-pointer API
+    DevBuf d_seqs, d_offsets, d_lens, d_best, d_decision, d_status;
+    std::mutex mu;
+};
+
+static int check_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return rb::fail(RB_ERR_NO_DEVICE, std::string("no HIP device: ") + (e == hipSuccess ? "count is 0" : hipGetErrorString(e)));
+    if (device < 0 || device >= n) return rb::fail(RB_ERR_INVALID_ARG, "device index out of range");
+    RB_HIP(hipSetDevice(device));
+    return RB_OK;
+}
+
+static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, IbfDev *d)
+{
+    if (g.n_hash > rbspec::kMaxHash) return rb::fail(RB_ERR_UNSUPPORTED, "more than 8 hash functions");
+    if (g.kmer_size > rbspec::kMaxKmer) return rb::fail(RB_ERR_UNSUPPORTED, "k-mer size above 32");
+    if (g.n_blocks == 0) return rb::fail(RB_ERR_INVALID_ARG, "filter has no blocks (n_bits smaller than one block)");
+    if (g.n_blocks >= (1ULL << 32)) return rb::fail(RB_ERR_UNSUPPORTED, "more than 2^32-1 blocks");
+    if (g.n_bins >= (1ULL << 31)) return rb::fail(RB_ERR_UNSUPPORTED, "too many bins");
+    d->words = d_words;
+    d->n_blocks = (uint32_t)g.n_blocks;
+    const bool pow2 = (g.n_blocks & (g.n_blocks - 1)) == 0;
+    d->pow2_mask = pow2 ? (uint32_t)(g.n_blocks - 1) : 0xFFFFFFFFu;
+    d->magic = g.n_blocks >= 2 ? rbspec::fastmod_magic(g.n_blocks) : 0;
+    for (unsigned i = 0; i < rbspec::kMaxHash; ++i) d->precalc[i] = rbspec::precalc(g.kmer_size, i);
+    d->n_bins = (uint32_t)g.n_bins;
+    d->bin_width = (uint32_t)g.bin_width;
+    d->k = (uint32_t)g.kmer_size;
+    d->n_hash = (uint32_t)g.n_hash;
+    return RB_OK;
+}
+
+static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out)
+{
+    int st = check_device(device);
+    if (st != RB_OK) return st;
+    rb_dibf *f = new (std::nothrow) rb_dibf();
+    if (!f) return rb::fail(RB_ERR_NOMEM, "alloc");
+    f->device = device;
+    f->geo = g;
+    hipError_t e = hipMalloc((void **)&f->d_words, std::max<uint64_t>(g.n_words, 1) * 8);
+    if (e != hipSuccess) {
+        delete f;
+        return rb::fail(RB_ERR_HIP, std::string("hipMalloc of the IBF failed: ") + hipGetErrorString(e));
+    }
+    if (zero) {
+        e = hipMemset(f->d_words, 0, g.n_words * 8);
+        if (e != hipSuccess) { rb_dibf_free(f); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
+    }
+    st = make_dev_desc(g, f->d_words, &f->dev);
+    if (st != RB_OK) { rb_dibf_free(f); return st; }
+    *out = f;
+    return RB_OK;
+}
+
+extern "C" {
+
+int rb_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(int)RB_ERR_NO_DEVICE;
+    return n;
+}
+
+int rb_dibf_create(int device, uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits, rb_dibf **out)
+{
+    if (!out) return rb::fail(RB_ERR_INVALID_ARG, "null out");
+    rb_ibf_info g;
+    if (!geometry_from(n_bins, n_hash, kmer_size, n_bits, &g)) return rb::fail(RB_ERR_INVALID_ARG, "bad IBF geometry");
+    return dibf_alloc(device, g, true, out);
+}
+
+int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out)
+{
+    if (!host || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    rb_dibf *f = nullptr;
+    int st = dibf_alloc(device, host->geo, false, &f);
+    if (st != RB_OK) return st;
+    hipError_t e = hipMemcpy(f->d_words, host->words, host->geo.n_words * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { rb_dibf_free(f); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
+    *out = f;
+    return RB_OK;
+}
+
+int rb_dibf_open(int device, const char *path, rb_dibf **out)
+{
+    if (!out) return rb::fail(RB_ERR_INVALID_ARG, "null out");
+    FILE *fp = nullptr;
+    rb_ibf_info g;
+    int st = open_ibf_stream(path, &fp, &g);
+    if (st != RB_OK) return st;
+    rb_dibf *f = nullptr;
+    st = dibf_alloc(device, g, false, &f);
+    if (st != RB_OK) { std::fclose(fp); return st; }
+    // stream the payload through two pinned staging buffers: file read of chunk i+1 overlaps the
+    // H2D copy of chunk i; the 8 GB GRCh38 filter never needs a host-side image.
+    const size_t chunk_words = (size_t)8 << 20;  // 64 MiB
+    uint64_t *stage[2] = {nullptr, nullptr};
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreate(&s);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipHostMalloc((void **)&stage[i], chunk_words * 8, hipHostMallocDefault);
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    int rc = RB_OK;
+    if (e != hipSuccess) rc = rb::fail(RB_ERR_HIP, std::string("staging setup: ") + hipGetErrorString(e));
+    uint64_t pos = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (rc == RB_OK && pos < g.n_words) {
+        const size_t nw = (size_t)std::min<uint64_t>(chunk_words, g.n_words - pos);
+        if (used[slot]) (void)hipEventSynchronize(done[slot]);
+        if (std::fread(stage[slot], 8, nw, fp) != nw) { rc = rb::fail(RB_ERR_PARSE_IBF, std::string(path) + ": short read"); break; }
+        e = hipMemcpyAsync(f->d_words + pos, stage[slot], nw * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(done[slot], s);
+        if (e != hipSuccess) { rc = rb::fail(RB_ERR_HIP, hipGetErrorString(e)); break; }
+        used[slot] = true;
+        pos += nw;
+        slot ^= 1;
+    }
+    if (s) (void)hipStreamSynchronize(s);
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (stage[i]) (void)hipHostFree(stage[i]);
+    }
+    if (s) (void)hipStreamDestroy(s);
+    std::fclose(fp);
+    if (rc != RB_OK) { rb_dibf_free(f); return rc; }
+    *out = f;
+    return RB_OK;
+}
+
+int rb_dibf_download(const rb_dibf *f, rb_ibf **out)
+{
+    if (!f || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    rb_ibf *h = nullptr;
+    int st = rb_ibf_create(f->geo.n_bins, f->geo.n_hash, f->geo.kmer_size, f->geo.n_bits, &h);
+    if (st != RB_OK) return st;
+    st = check_device(f->device);
+    if (st != RB_OK) { rb_ibf_close(h); return st; }
+    hipError_t e = hipMemcpy(h->words, f->d_words, f->geo.n_words * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rb_ibf_close(h); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
+    *out = h;
+    return RB_OK;
+}
+
+int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info)
+{
+    if (!f || !info) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    *info = f->geo;
+    return RB_OK;
+}
+
+void *rb_dibf_device_words(rb_dibf *f) { return f ? f->d_words : nullptr; }
+int rb_dibf_device(const rb_dibf *f) { return f ? f->device : -1; }
+
+void rb_dibf_free(rb_dibf *f)
+{
+    if (!f) return;
+    if (f->d_words) {
+        (void)hipSetDevice(f->device);
+        (void)hipFree(f->d_words);
+    }
+    delete f;
+}
+
+int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
+{
+    if (!f) return rb::fail(RB_ERR_INVALID_ARG, "null filter");
+    int st = check_device(f->device);
+    if (st != RB_OK) return st;
+    const uint64_t used = f->geo.n_blocks * f->geo.bin_width;
+    const uint64_t rem = f->geo.n_bins & 63;
+    const uint64_t last_mask = rem ? ((1ULL << rem) - 1) : ~0ULL;
+    RB_HIP(launch_fill_synth(f->d_words, f->geo.n_words, used, (uint32_t)f->geo.bin_width, last_mask, seed, nullptr));
+    RB_HIP(hipDeviceSynchronize());
+    return RB_OK;
+}
+
+int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_t *starts, const uint64_t *ends,
+                   const uint64_t *bins, size_t n_fragments)
+{
+    if (!f || (!seq && len) || (n_fragments && (!starts || !ends || !bins))) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (n_fragments == 0) return RB_OK;
+    if (n_fragments >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "too many fragments in one call");
+    int st = check_device(f->device);
+    if (st != RB_OK) return st;
+    const uint64_t k = f->geo.kmer_size;
+    std::vector<uint64_t> prefix(n_fragments + 1, 0);
+    for (size_t i = 0; i < n_fragments; ++i) {
+        if (ends[i] > len || starts[i] > ends[i]) return rb::fail(RB_ERR_INVALID_ARG, "fragment outside the sequence");
+        if (bins[i] >= f->geo.n_bins) return rb::fail(RB_ERR_INVALID_ARG, "bin id outside the filter");
+        const uint64_t flen = ends[i] - starts[i];
+        prefix[i + 1] = prefix[i] + (flen >= k ? flen - k + 1 : 0);
+    }
+    const uint64_t total = prefix[n_fragments];
+    if (total == 0) return RB_OK;
+    if ((total + 255) / 256 >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "too many k-mers in one call");
+    DevBuf d_seq, d_tab;
+    st = d_seq.ensure(len ? len : 1);
+    if (st == RB_OK) st = d_tab.ensure((4 * n_fragments + 1) * 8);
+    if (st != RB_OK) { d_seq.release(); d_tab.release(); return st; }
+    uint64_t *t = (uint64_t *)d_tab.p;
+    hipError_t e = hipMemcpy(d_seq.p, seq, len, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t, starts, n_fragments * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t + n_fragments, ends, n_fragments * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t + 2 * n_fragments, bins, n_fragments * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t + 3 * n_fragments, prefix.data(), (n_fragments + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_insert(f->dev, f->d_words, (const uint8_t *)d_seq.p, t, t + n_fragments, t + 2 * n_fragments,
+                          t + 3 * n_fragments, (uint32_t)n_fragments, total, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    d_seq.release();
+    d_tab.release();
+    if (e != hipSuccess) return rb::fail(RB_ERR_HIP, std::string("insert: ") + hipGetErrorString(e));
+    return RB_OK;
+}
+
+int rb_dibf_add_sequence(rb_dibf *f, const char *seq, size_t len, uint64_t fragment_length, uint64_t overlap_length,
+                         uint64_t first_bin, uint64_t *next_bin)
+{
+    if (!f) return rb::fail(RB_ERR_INVALID_ARG, "null filter");
+    const size_t n = rb_fragment_bounds(len, fragment_length, f->geo.kmer_size, overlap_length, nullptr, nullptr, 0);
+    std::vector<uint64_t> starts(n), ends(n), bins(n);
+    rb_fragment_bounds(len, fragment_length, f->geo.kmer_size, overlap_length, starts.data(), ends.data(), n);
+    for (size_t i = 0; i < n; ++i) bins[i] = first_bin + i;
+    if (next_bin) *next_bin = first_bin + n;
+    return rb_dibf_insert(f, seq, len, starts.data(), ends.data(), bins.data(), n);
+}
+
+// ------------------------------------------------------------------------------------------------
+int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_dibf *const *target, size_t n_target,
+                     rb_engine **out)
+{
+    if (!out) return rb::fail(RB_ERR_INVALID_ARG, "null out");
+    if (n_deplete + n_target == 0) return rb::fail(RB_ERR_NULL_FILTER, "No IBF provided to classify the read!");
+    if (n_deplete + n_target > kMaxFilters) return rb::fail(RB_ERR_UNSUPPORTED, "more than 16 filters");
+    int st = check_device(device);
+    if (st != RB_OK) return st;
+    rb_engine *e = new (std::nothrow) rb_engine();
+    if (!e) return rb::fail(RB_ERR_NOMEM, "alloc");
+    e->device = device;
+    for (size_t i = 0; i < n_deplete + n_target; ++i) {
+        rb_dibf *f = i < n_deplete ? deplete[i] : target[i - n_deplete];
+        if (!f || f->device != device) { delete e; return rb::fail(RB_ERR_INVALID_ARG, "filter is null or lives on another device"); }
+        e->filters.push_back(f);
+    }
+    e->nd = (uint32_t)n_deplete;
+    e->nt = (uint32_t)n_target;
+    hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreate(&e->ev0);
+    if (he == hipSuccess) he = hipEventCreate(&e->ev1);
+    if (he != hipSuccess) { rb_engine_destroy(e); return rb::fail(RB_ERR_HIP, hipGetErrorString(he)); }
+    *out = e;
+    return RB_OK;
+}
+
+void rb_engine_destroy(rb_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (DevBuf *b : {&e->d_thr, &e->d_part, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+                      &e->d_decision, &e->d_status})
+        b->release();
+    delete e;
+}
+
+int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
+{
+    if (!e || world < 1 || rank < 0 || rank >= world) return rb::fail(RB_ERR_INVALID_ARG, "bad shard");
+    e->shard_rank = rank;
+    e->shard_world = world;
+    return RB_OK;
+}
+
+int rb_engine_set_timing(rb_engine *e, int enabled)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    e->timing = enabled != 0;
+    return RB_OK;
+}
+
+double rb_engine_last_kernel_ms(rb_engine *e) { return e ? e->last_kernel_ms : -1.0; }
+
+}  // extern "C"
+
+// thresholds by read length for every filter at r and r-0.02 (host doubles, device table)
+static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st)
+{
+    const uint32_t need = max_len + 1;
+    if (e->thr_len >= need && e->thr_r == r && e->thr_conf == conf) return RB_OK;
+    uint32_t cap = 1024;
+    while (cap < need) cap <<= 1;
+    const size_t nf = e->filters.size();
+    std::vector<uint16_t> tab(nf * 2 * (size_t)cap);
+    const double r2 = r - 0.02;  // "conf.error_rate -= 0.02" (adaptive_sampling.hpp:55, classify.hpp:67)
+    for (size_t fi = 0; fi < nf; ++fi) {
+        const uint64_t k = e->filters[fi]->geo.kmer_size;
+        for (uint32_t len = 0; len < cap; ++len) {
+            tab[(fi * 2 + 0) * cap + len] = threshold_u16(len, k, r, conf);
+            tab[(fi * 2 + 1) * cap + len] = threshold_u16(len, k, r2, conf);
+        }
+    }
+    // the previous table may still be in use by work queued on the stream
+    RB_HIP(hipStreamSynchronize(st));
+    int rc = e->d_thr.ensure(tab.size() * 2);
+    if (rc != RB_OK) return rc;
+    RB_HIP(hipMemcpy(e->d_thr.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
+    e->thr_len = cap;
+    e->thr_r = r;
+    e->thr_conf = conf;
+    return RB_OK;
+}
+
+static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, size_t n_reads, uint32_t max_len,
+                      double r, double conf, int mode, int32_t *d_best, uint8_t *d_decision, uint8_t *d_status,
+                      hipStream_t st)
+{
+    int rc = ensure_thresholds(e, max_len, r, conf, st);
+    if (rc != RB_OK) return rc;
+    DecideParams P{};
+    P.nd = e->nd;
+    P.nt = e->nt;
+    for (size_t i = 0; i < e->filters.size(); ++i) P.k[i] = (uint32_t)e->filters[i]->geo.kmer_size;
+    P.thr = (const uint16_t *)e->d_thr.p;
+    P.thr_len = e->thr_len;
+    RB_HIP(launch_decide(P, d_maxcount, d_lens, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
+    return RB_OK;
+}
+
+extern "C" {
+
+int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens, size_t n_reads,
+                             uint32_t max_len, double error_rate, double significance, int mode, void *d_maxcount,
+                             void *d_best_target, void *d_decision, void *d_status, void *stream)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK) return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
+    if (n_reads >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "batch too large");
+    if (n_reads == 0) return RB_OK;
+    if (!d_seqs || !d_offsets || !d_lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
+    std::lock_guard<std::mutex> lock(e->mu);
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    const size_t nf = e->filters.size();
+
+    uint16_t *maxcount = (uint16_t *)d_maxcount;
+    if (!maxcount) {
+        rc = e->d_maxcount.ensure(n_reads * nf * 2);
+        if (rc != RB_OK) return rc;
+        maxcount = (uint16_t *)e->d_maxcount.p;
+    }
+    if (e->timing) RB_HIP(hipEventRecord(e->ev0, st));
+    for (size_t fi = 0; fi < nf; ++fi) {
+        const rb_dibf *f = e->filters[fi];
+        CountLaunch a{};
+        a.f = f->dev;
+        a.seqs = (const uint8_t *)d_seqs;
+        a.offsets = (const uint64_t *)d_offsets;
+        a.lens = (const uint32_t *)d_lens;
+        a.n_reads = (uint32_t)n_reads;
+        const uint32_t W = (uint32_t)f->geo.bin_width;
+        // bin-sharded operation: contiguous word-column range of every block per rank
+        uint32_t per = (W + e->shard_world - 1) / e->shard_world;
+        if (e->shard_world > 1 && (per & 1)) ++per;  // keep 16-byte alignment of the slices
+        a.col_begin = std::min<uint32_t>(W, per * e->shard_rank);
+        a.col_end = std::min<uint32_t>(W, a.col_begin + per);
+        const uint32_t Weff = a.col_end - a.col_begin;
+        const uint32_t kmers = max_len >= f->geo.kmer_size ? max_len - (uint32_t)f->geo.kmer_size + 1 : 0;
+        a.planes = kmers <= 1023 ? 10 : 16;
+        if (Weff == 0) {
+            // this rank holds no column of this filter: its partial maxima are 0
+            RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, st));
+            continue;
+        }
+        if (Weff > 64 && (W % 2 == 0) && (a.col_begin % 2 == 0)) {
+            a.wpl = 2; a.lg = 6;
+        } else {
+            a.wpl = 1; a.lg = 0;
+            while ((1u << a.lg) < std::min<uint32_t>(Weff, 64)) ++a.lg;
+        }
+        const uint32_t slice_words = (1u << a.lg) * a.wpl;
+        a.n_slices = (Weff + slice_words - 1) / slice_words;
+        if (a.n_slices == 1) {
+            a.out = maxcount + fi;
+            a.out_read_stride = (uint32_t)nf;
+            a.out_slice_stride = 0;
+            RB_HIP(launch_ibf_count_max(a, st));
+        } else {
+            rc = e->d_part.ensure((size_t)a.n_slices * n_reads * 2);
+            if (rc != RB_OK) return rc;
+            a.out = (uint16_t *)e->d_part.p;
+            a.out_read_stride = 1;
+            a.out_slice_stride = (uint32_t)n_reads;
+            RB_HIP(launch_ibf_count_max(a, st));
+            RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, st));
+        }
+    }
+    if (e->timing) RB_HIP(hipEventRecord(e->ev1, st));
+    if (e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
+        rc = run_decide(e, maxcount, (const uint32_t *)d_lens, n_reads, max_len, error_rate, significance, mode,
+                        (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+        if (rc != RB_OK) return rc;
+    }
+    if (e->timing) {
+        RB_HIP(hipEventSynchronize(e->ev1));
+        float ms = 0.f;
+        RB_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->last_kernel_ms = ms;
+    }
+    if (!stream) RB_HIP(hipStreamSynchronize(st));
+    return RB_OK;
+}
+
+int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads, uint32_t max_len,
+                     double error_rate, double significance, int mode, void *d_best_target, void *d_decision,
+                     void *d_status, void *stream)
+{
+    if (!e || !d_maxcount || !d_lens) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (n_reads == 0) return RB_OK;
+    std::lock_guard<std::mutex> lock(e->mu);
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    rc = run_decide(e, (const uint16_t *)d_maxcount, (const uint32_t *)d_lens, n_reads, max_len, error_rate, significance,
+                    mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+    if (rc != RB_OK) return rc;
+    if (!stream) RB_HIP(hipStreamSynchronize(st));
+    return RB_OK;
+}
+
+int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n_reads,
+                      double error_rate, double significance, int mode, uint16_t *out_maxcount, int32_t *out_best_target,
+                      uint8_t *out_decision, uint8_t *out_status)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    if (n_reads == 0) return RB_OK;
+    if (!seqs || !offsets || !lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    uint64_t total = 0;
+    uint32_t max_len = 0;
+    for (size_t i = 0; i < n_reads; ++i) {
+        total = std::max<uint64_t>(total, offsets[i] + lens[i]);
+        max_len = std::max(max_len, lens[i]);
+    }
+    const size_t nf = e->filters.size();
+    hipStream_t st = e->stream;
+    {
+        std::lock_guard<std::mutex> lock(e->mu);
+        if ((rc = e->d_seqs.ensure(total ? total : 1)) != RB_OK) return rc;
+        if ((rc = e->d_offsets.ensure(n_reads * 8)) != RB_OK) return rc;
+        if ((rc = e->d_lens.ensure(n_reads * 4)) != RB_OK) return rc;
+        if ((rc = e->d_maxcount.ensure(n_reads * nf * 2)) != RB_OK) return rc;
+        if ((rc = e->d_best.ensure(n_reads * 4)) != RB_OK) return rc;
+        if ((rc = e->d_decision.ensure(n_reads)) != RB_OK) return rc;
+        if ((rc = e->d_status.ensure(n_reads)) != RB_OK) return rc;
+    }
+    RB_HIP(hipMemcpyAsync(e->d_seqs.p, seqs, total, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(e->d_offsets.p, offsets, n_reads * 8, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(e->d_lens.p, lens, n_reads * 4, hipMemcpyHostToDevice, st));
+    rc = rb_classify_batch_device(e, e->d_seqs.p, e->d_offsets.p, e->d_lens.p, n_reads, max_len, error_rate, significance,
+                                  mode, e->d_maxcount.p, e->d_best.p, e->d_decision.p, e->d_status.p, (void *)st);
+    if (rc != RB_OK) return rc;
+    if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, e->d_maxcount.p, n_reads * nf * 2, hipMemcpyDeviceToHost, st));
+    if (e->shard_world == 1) {
+        if (out_best_target) RB_HIP(hipMemcpyAsync(out_best_target, e->d_best.p, n_reads * 4, hipMemcpyDeviceToHost, st));
+        if (out_decision) RB_HIP(hipMemcpyAsync(out_decision, e->d_decision.p, n_reads, hipMemcpyDeviceToHost, st));
+        if (out_status) RB_HIP(hipMemcpyAsync(out_status, e->d_status.p, n_reads, hipMemcpyDeviceToHost, st));
+    }
+    RB_HIP(hipStreamSynchronize(st));
+    return RB_OK;
+}
+
+}  // extern "C"

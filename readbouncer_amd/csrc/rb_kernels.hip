@@ -1,0 +1,502 @@
+// rb_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the IBF classify path.
+//
+//   K1 ibf_count_max : seqan::count(filter, seq) + seqan::count(filter, TSeqRevComp(seq)) +
+//                      the max over bins/strands of Read::max_matches
+//                      (src/IBF/IBFClassify.cpp:149-150, 48-71); fuses the (Dna5String) conversion
+//                      of src/main/classify.hpp:272.
+//   K2 decide        : threshold + argmax + decision (IBFClassify.cpp:154-162, 262-273, 299-365;
+//                      src/main/adaptive_sampling.hpp:35-113; src/main/classify.hpp:58-111,275-292)
+//   K4 ibf_insert    : seqan::insertKmer (src/IBF/IBFBuild.cpp:190)
+//   fill_synth       : benchmark filler
+//
+// Design (DESIGN.md has the long form).  The path is integer/bitwise and HBM-gather bound: per read
+// and filter 2*(L-k+1)*h random blocks of 8*W bytes.  One 64-lane wave owns one (read, column slice):
+//   * phase A: every lane hashes its own k-mer of a 64-k-mer tile (base-5 value, h multiplicative
+//     hashes, Barrett reduction mod noOfBlocks) -- the block numbers stay in registers;
+//   * phase B: the wave walks the tile; a group of LPB = 2^LG lanes covers one block with one
+//     8-byte (or 16-byte) word column per lane, so every wave-level load instruction is 64/LPB
+//     fully coalesced block gathers; block numbers travel by ds_bpermute / v_readlane;
+//   * per-bin counters are BIT-SLICED: lane-private 64-bit planes, one bit per bin, fed by a
+//     Harley-Seal carry-save tree (7 CSAs per 8 gathered words) -- no atomics, no LDS traffic,
+//     10 or 16 planes (16 planes wrap at 65536 exactly like the reference's uint16_t counters);
+//   * the max over bins is taken on the bit-sliced form with 64-wide ballots, MSB plane first.
+// No MFMA anywhere: there is no multiply-accumulate structure in this path.
+#include <hip/hip_runtime.h>
+
+#include "rb_device.h"
+
+namespace rb {
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t shfl32(uint32_t v, int src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src_lane)
+{
+    uint32_t lo = shfl32((uint32_t)v, src_lane), hi = shfl32((uint32_t)(v >> 32), src_lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t readlane32(uint32_t v, int uniform_lane)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, uniform_lane);
+}
+
+// carry-save adder on bit planes: (h, l) = a + b + c per bit position
+#define RB_CSA(h, l, a, b, c)                \
+    {                                        \
+        const uint64_t u__ = (a) ^ (b);      \
+        const uint64_t c__ = (c);            \
+        (h) = ((a) & (b)) | (u__ & c__);     \
+        (l) = u__ ^ c__;                     \
+    }
+
+template <int NP>
+struct Planes {
+    uint64_t p[NP];  // p[i] holds bit i of 64 per-bin counters
+    __device__ __forceinline__ void clear()
+    {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) p[i] = 0;
+    }
+    // fold 8 one-bit-per-bin words into the counters (Harley-Seal)
+    __device__ __forceinline__ void add8(const uint64_t x[8])
+    {
+        uint64_t twosA, twosB, foursA, foursB, eights;
+        RB_CSA(twosA, p[0], p[0], x[0], x[1]);
+        RB_CSA(twosB, p[0], p[0], x[2], x[3]);
+        RB_CSA(foursA, p[1], p[1], twosA, twosB);
+        RB_CSA(twosA, p[0], p[0], x[4], x[5]);
+        RB_CSA(twosB, p[0], p[0], x[6], x[7]);
+        RB_CSA(foursB, p[1], p[1], twosA, twosB);
+        RB_CSA(eights, p[2], p[2], foursA, foursB);
+        uint64_t carry = eights;
+#pragma unroll
+        for (int i = 3; i < NP; ++i) {
+            const uint64_t t = p[i] & carry;
+            p[i] ^= carry;
+            carry = t;
+        }
+    }
+    // counters += counters held by lane (lane ^ xor_mask)
+    __device__ __forceinline__ void add_from_lane_xor(int lane, int xor_mask)
+    {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const uint64_t o = shfl64(p[i], lane ^ xor_mask);
+            uint64_t h, l;
+            RB_CSA(h, l, p[i], o, carry);
+            p[i] = l;
+            carry = h;
+        }
+    }
+};
+
+// max over all bins held by the wave (WPL plane sets per lane), MSB plane first
+template <int NP, int WPL>
+__device__ __forceinline__ uint32_t planes_max(const Planes<NP> (&pl)[WPL], const uint64_t (&valid)[WPL])
+{
+    uint64_t cand[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) cand[w] = valid[w];
+    uint32_t res = 0;
+#pragma unroll
+    for (int i = NP - 1; i >= 0; --i) {
+        uint64_t t[WPL];
+        bool any = false;
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) {
+            t[w] = cand[w] & pl[w].p[i];
+            any |= (t[w] != 0);
+        }
+        if (__ballot(any) != 0ULL) {  // wave-uniform
+            res |= 1u << i;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) cand[w] = t[w];
+        }
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1.  LG: log2(lanes per block); WPL: 64-bit word columns per lane (1 or 2); NP: counter planes;
+// H: compile-time number of hash functions, 0 = run-time (slow path, hashes in phase B).
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxTiles = 8;                                      // tiles per macro tile when LG < 3
+constexpr int kStageBytes = 64 * kMaxTiles + rbspec::kMaxKmer;    // bases staged per macro tile
+
+template <int LG, int WPL, int NP, int H>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
+    IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
+    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
+    uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
+{
+    constexpr int LPB = 1 << LG;           // lanes that cover one block
+    constexpr int NG = 64 >> LG;           // blocks gathered per wave instruction
+    constexpr int SPT = LPB;               // phase-B steps per 64-k-mer tile
+    constexpr int J = SPT >= 8 ? 1 : 8 / SPT;  // tiles per macro tile (so that steps come in eights)
+    constexpr int STEPS = SPT * J;
+    constexpr int ITEMS = 64 * J;
+    constexpr int HR = H > 0 ? H : 1;
+
+    __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
+    if (read >= n_reads) return;  // wave-uniform; there are no block-level barriers below
+
+    const int g = lane >> LG;
+    const int c = lane & (LPB - 1);
+    const uint32_t W = f.bin_width;
+    const uint32_t col0 = col_begin + blockIdx.y * (uint32_t)(LPB * WPL) + (uint32_t)(c * WPL);
+    uint64_t valid[WPL];
+    bool colok = false;
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) {
+        const uint32_t col = col0 + w;
+        const bool ok = col < col_end;
+        const uint32_t rem = f.n_bins & 63u;
+        valid[w] = !ok ? 0ULL : (col == W - 1 && rem) ? ((1ULL << rem) - 1) : ~0ULL;
+        colok |= ok;
+    }
+    // WPL == 2 loads 16 bytes: the second word must exist (col_end even or lane fully inside)
+    const bool col_full = (col0 + WPL) <= col_end;
+    const uint64_t *lane_base = f.words + col0;
+
+    const uint32_t len = lens[read];
+    const uint32_t k = f.k;
+    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint8_t *seq = seqs + offsets[read];
+    uint8_t *stage = s_stage[wave];
+
+    uint32_t best = 0;
+    for (int strand = 0; strand < 2; ++strand) {
+        Planes<NP> pl[WPL];
+#pragma unroll
+        for (int w = 0; w < WPL; ++w) pl[w].clear();
+
+        for (uint32_t mt = 0; mt < n; mt += ITEMS) {
+            // ---- stage the bases of this macro tile as Dna5 ordinals ((Dna5String) conversion)
+            const uint32_t wlen = min((uint32_t)(ITEMS + k - 1), len - mt);
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i = lane; i < wlen; i += 64) stage[i] = (uint8_t)rbspec::dna5_ord(seq[mt + i]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- phase A: one k-mer per lane and tile
+            uint32_t idx[J][HR];
+            uint64_t kv[J];
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const uint32_t p = mt + j * 64 + lane;
+                uint64_t v = 0;
+                if (p < n) {
+                    const uint8_t *b = stage + (p - mt);
+                    if (strand == 0) {
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
+                    } else {  // k-mer of the reverse complement that covers the same window
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                    }
+                }
+                kv[j] = v;
+                if constexpr (H > 0) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h)
+                        idx[j][h] = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                }
+            }
+
+            // ---- phase B: gather + count, eight steps at a time
+#pragma unroll 1
+            for (int blk = 0; blk < STEPS / 8; ++blk) {
+                {
+                    const int s0 = blk * 8;
+                    const uint32_t first = mt + (uint32_t)((s0 / SPT) * 64 + (s0 % SPT) * NG);
+                    if (first >= n) break;  // wave-uniform
+                }
+                uint64_t x[WPL][8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = blk * 8 + u;
+                    const int j = (SPT >= 8) ? 0 : (u / SPT);  // compile-time either way
+                    const int it = (s % SPT) * NG + g;          // k-mer of this group within tile j
+                    const uint32_t p = mt + (uint32_t)(j * 64 + it);
+                    const bool ok = (p < n) && colok;
+                    uint64_t acc[WPL];
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) acc[w] = ok ? valid[w] : 0ULL;
+                    if constexpr (H > 0) {
+                        uint32_t b[H];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            if constexpr (LG == 0) b[h] = idx[j][h];
+                            else if constexpr (LG == 6) b[h] = readlane32(idx[j][h], it);
+                            else b[h] = shfl32(idx[j][h], it);
+                        }
+                        if (ok) {
+#pragma unroll
+                            for (int h = 0; h < H; ++h) {
+                                const uint64_t *src = lane_base + (uint64_t)b[h] * W;
+                                if constexpr (WPL == 1) {
+                                    acc[0] &= *src;
+                                } else {
+                                    if (col_full) {
+                                        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(src);
+                                        acc[0] &= q.x;
+                                        acc[1] &= q.y;
+                                    } else {
+                                        acc[0] &= *src;
+                                        acc[1] = 0;
+                                    }
+                                }
+                            }
+                        }
+                    } else {
+                        const uint64_t v = (LG == 0) ? kv[j] : shfl64(kv[j], it);
+                        if (ok) {
+                            for (uint32_t h = 0; h < f.n_hash; ++h) {
+                                const uint32_t bi = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                                const uint64_t *src = lane_base + (uint64_t)bi * W;
+#pragma unroll
+                                for (int w = 0; w < WPL; ++w) acc[w] &= (valid[w] ? src[w] : 0ULL);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) x[w][u] = acc[w];
+                }
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) pl[w].add8(x[w]);
+            }
+        }
+
+        // ---- sum the partial counters of the NG groups (butterfly), then max over bins
+        if constexpr (NG > 1) {
+#pragma unroll
+            for (int m = LPB; m < 64; m <<= 1) {
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) pl[w].add_from_lane_xor(lane, m);
+            }
+        }
+        const uint32_t m = planes_max<NP, WPL>(pl, valid);
+        best = m > best ? m : best;
+    }
+    if (lane == 0) out[(size_t)read * out_read_stride + (size_t)blockIdx.y * out_slice_stride] = (uint16_t)best;
+}
+
+// combine the per-slice partial maxima of one filter: part[slice][read] -> maxcount[read*nf + f]
+__global__ void reduce_slices_kernel(const uint16_t *__restrict__ part, uint32_t n_slices, uint32_t n_reads,
+                                     uint16_t *__restrict__ maxcount, uint32_t nf, uint32_t fidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    uint16_t m = 0;
+    for (uint32_t s = 0; s < n_slices; ++s) {
+        const uint16_t v = part[(size_t)s * n_reads + i];
+        m = v > m ? v : m;
+    }
+    maxcount[(size_t)i * nf + fidx] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: one thread per read.
+__global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxcount, const uint32_t *__restrict__ lens,
+                              uint32_t n_reads, int mode, int32_t *__restrict__ out_best_target,
+                              uint8_t *__restrict__ out_decision, uint8_t *__restrict__ out_status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint32_t len = lens[i];
+    const uint32_t nf = P.nd + P.nt;
+    const uint32_t tl = len < P.thr_len ? len : P.thr_len - 1;  // host guarantees len < thr_len
+    // group maxima at r (1) and at r - 0.02 (2), strictly-greater argmax at r (first wins ties)
+    uint32_t D1 = 0, T1 = 0, D2 = 0, T2 = 0;
+    int best_d = -1, best_t = -1;
+    for (uint32_t fi = 0; fi < nf; ++fi) {
+        const uint32_t M = maxcount[(size_t)i * nf + fi];
+        uint32_t c1 = 0, c2 = 0;
+        if (len >= P.k[fi]) {  // pair overload skips filters with k > len; others count 0 there anyway
+            const uint16_t t1 = P.thr[((size_t)fi * 2 + 0) * P.thr_len + tl];
+            const uint16_t t2 = P.thr[((size_t)fi * 2 + 1) * P.thr_len + tl];
+            c1 = (M >= t1) ? M : 0;  // max_matches with the uint16_t threshold
+            c2 = (M >= t2) ? M : 0;
+        }
+        if (fi < P.nd) {
+            if (c1 > D1) { D1 = c1; best_d = (int)fi; }
+            D2 = c2 > D2 ? c2 : D2;
+        } else {
+            if (c1 > T1) { T1 = c1; best_t = (int)(fi - P.nd); }
+            T2 = c2 > T2 ? c2 : T2;
+        }
+    }
+    uint8_t decision = 0, status = RB_OK;
+    const bool short_d = P.nd && len < P.k[0];
+    const bool short_t = P.nt && len < P.k[P.nd];
+    if (mode == RB_MODE_CHECK_UNBLOCK) {
+        if (P.nd && P.nt) {
+            if (D1 > 0) {
+                if (T1 > 0) decision = (D2 > 0 && T2 == 0) ? 1 : 0;
+                else decision = 1;
+            } else {
+                decision = (T1 > 0) ? 2 : 0;
+            }
+        } else if (P.nd) {
+            if (short_d) status = RB_ERR_SHORT_READ;
+            else decision = (best_d > -1) ? 1 : 0;
+        } else if (P.nt) {
+            if (short_t) status = RB_ERR_SHORT_READ;
+            else decision = (best_t < 0) ? 1 : 2;
+        } else {
+            status = RB_ERR_NULL_FILTER;
+        }
+    } else {  // RB_MODE_CLASSIFY_CHUNK
+        if (P.nd && P.nt) {
+            if (T1 > 0) {
+                bool want_target = false;
+                if (D1 > 0) {
+                    if (T2 > 0 && D2 > 0) want_target = false;
+                    else if (T2 > 0) want_target = true;
+                } else {
+                    want_target = true;
+                }
+                if (want_target) {  // r.classify(TargetFilters, Conf) at the restored error rate
+                    if (short_t) status = RB_ERR_SHORT_READ;
+                    else decision = (best_t != -1) ? 1 : 0;
+                }
+            }
+        } else if (P.nd) {
+            if (short_d) status = RB_ERR_SHORT_READ;
+            else decision = (best_d > -1) ? 1 : 0;
+        } else if (P.nt) {
+            if (short_t) status = RB_ERR_SHORT_READ;
+            else decision = (best_t != -1) ? 1 : 0;
+        } else {
+            status = RB_ERR_NULL_FILTER;
+        }
+    }
+    if (out_best_target) out_best_target[i] = (P.nt && !short_t) ? best_t : -1;
+    if (out_decision) out_decision[i] = decision;
+    if (out_status) out_status[i] = status;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: one thread per (fragment, k-mer position); h atomicOr per k-mer.
+__global__ void ibf_insert_kernel(IbfDev f, uint64_t *__restrict__ words, const uint8_t *__restrict__ seq,
+                                  const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
+                                  const uint64_t *__restrict__ bins, const uint64_t *__restrict__ kmer_prefix,
+                                  uint32_t n_fragments, uint64_t total_kmers)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_kmers) return;
+    // fragment lookup: kmer_prefix[i] = number of k-mers in fragments < i (binary search)
+    uint32_t lo = 0, hi = n_fragments;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (kmer_prefix[mid] <= t) lo = mid; else hi = mid;
+    }
+    const uint64_t pos = starts[lo] + (t - kmer_prefix[lo]);
+    if (pos + f.k > ends[lo]) return;
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < f.k; ++i) v = v * 5u + rbspec::dna5_ord(seq[pos + i]);
+    const uint64_t bin = bins[lo];
+    for (uint32_t h = 0; h < f.n_hash; ++h) {
+        const uint64_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+        const uint64_t bit = blk * ((uint64_t)f.bin_width * 64u) + bin;
+        atomicOr(reinterpret_cast<unsigned long long *>(words + (bit >> 6)), 1ULL << (bit & 63));
+    }
+}
+
+__global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t n_words, uint64_t used_words,
+                                  uint32_t bin_width, uint64_t last_mask, uint64_t seed)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
+        uint64_t x = 0;
+        if (w < used_words) {
+            x = rbspec::synth_word(seed, w);
+            if ((w % bin_width) == bin_width - 1) x &= last_mask;
+        }
+        words[w] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+template <int LG, int WPL, int NP, int H>
+static hipError_t launch_count(const CountLaunch &a, hipStream_t st)
+{
+    dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock, a.n_slices);
+    hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.seqs,
+                       a.offsets, a.lens, a.n_reads, a.col_begin, a.col_end, a.out, a.out_read_stride,
+                       a.out_slice_stride);
+    return hipGetLastError();
+}
+
+template <int NP, int H>
+static hipError_t dispatch_geometry(const CountLaunch &a, hipStream_t st)
+{
+    if (a.wpl == 2) return launch_count<6, 2, NP, H>(a, st);
+    switch (a.lg) {
+    case 0: return launch_count<0, 1, NP, H>(a, st);
+    case 1: return launch_count<1, 1, NP, H>(a, st);
+    case 2: return launch_count<2, 1, NP, H>(a, st);
+    case 3: return launch_count<3, 1, NP, H>(a, st);
+    case 4: return launch_count<4, 1, NP, H>(a, st);
+    case 5: return launch_count<5, 1, NP, H>(a, st);
+    default: return launch_count<6, 1, NP, H>(a, st);
+    }
+}
+
+hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
+{
+    if (a.n_reads == 0) return hipSuccess;
+    if (a.f.n_hash == 3) {
+        if (a.planes <= 10) return dispatch_geometry<10, 3>(a, st);
+        return dispatch_geometry<16, 3>(a, st);
+    }
+    return dispatch_geometry<16, 0>(a, st);
+}
+
+hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,
+                                uint32_t nf, uint32_t fidx, hipStream_t st)
+{
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, part, n_slices, n_reads,
+                       maxcount, nf, fidx);
+    return hipGetLastError();
+}
+
+hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, uint32_t n_reads,
+                         int mode, int32_t *best_target, uint8_t *decision, uint8_t *status, hipStream_t st)
+{
+    if (n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(decide_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, P, maxcount, lens, n_reads, mode,
+                       best_target, decision, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,
+                         const uint64_t *ends, const uint64_t *bins, const uint64_t *kmer_prefix,
+                         uint32_t n_fragments, uint64_t total_kmers, hipStream_t st)
+{
+    if (total_kmers == 0) return hipSuccess;
+    const uint64_t blocks = (total_kmers + 255) / 256;
+    hipLaunchKernelGGL(ibf_insert_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, f, words, seq, starts, ends, bins,
+                       kmer_prefix, n_fragments, total_kmers);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_synth(uint64_t *words, uint64_t n_words, uint64_t used_words, uint32_t bin_width,
+                             uint64_t last_mask, uint64_t seed, hipStream_t st)
+{
+    if (n_words == 0) return hipSuccess;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(fill_synth_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, words, n_words, used_words,
+                       bin_width, last_mask, seed);
+    return hipGetLastError();
+}
+
+}  // namespace rb

@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bit-exact (integer/bit work).  Run on the MI355X box with `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pyoracle as po
+from readbouncer_amd import capi
+from tests import helpers as H
+
+READ_354 = "AAAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAGAGAGAGCCCCAAAAGAGAGGAGA" * 6
+
+
+def oracle_view(dibf):
+    host = dibf.download()
+    i = host.info
+    return po.OracleIBF.wrap(i["n_bins"], i["n_hash"], i["kmer_size"], i["n_bits"], host.words()), host
+
+
+def make_reads(rng, ref, n, lo=40, hi=500, err=0.08, n_frac=0.1):
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        kind = i % 4
+        if kind == 0 or len(ref) <= L:
+            r = H.random_dna(rng, L)
+        else:
+            s = int(rng.integers(0, len(ref) - L))
+            r = H.mutate(rng, ref[s:s + L], err if kind != 3 else 0.0)
+        if rng.random() < n_frac and L > 5:
+            p = int(rng.integers(0, L - 1))
+            r = r[:p] + "N" + r[p + 1:]
+        if kind == 2 and rng.random() < 0.5:  # reverse-complement positives
+            r = "".join("ACGTN"[x] for x in po.revcomp(po.encode(r)))
+        reads.append(r)
+    return reads
+
+
+GEOMETRIES = [
+    # (n_bins, n_blocks, k, h)
+    (40, 4099, 13, 3),      # W=1 (B<64), odd block count
+    (64, 4096, 13, 3),      # W=1, power-of-two block count
+    (100, 2053, 13, 3),     # W=2, padding bits in the last word
+    (130, 1021, 15, 3),     # W=3 -> 4 lanes per block, one idle
+    (600, 997, 13, 3),      # W=10 (mock-community target), 16 lanes per block, 6 idle
+    (1024, 1024, 13, 3),    # W=16: config 2 geometry
+    (1030, 509, 13, 3),     # W=17 -> 32 lanes per block
+    (4096, 257, 13, 3),     # W=64: one whole wave per block
+    (8192, 128, 13, 3),     # W=128: config 3 geometry, 16 B per lane
+    (8300, 131, 13, 3),     # W=130: two column slices, 16 B per lane, ragged tail
+    (4200, 211, 13, 3),     # W=66 even
+    (4300, 199, 13, 3),     # W=68
+    (4160 + 1, 173, 13, 3), # W=66 (4161 bins -> 66 words)
+    (5000, 163, 13, 3),     # W=79 odd: 8-byte path with two slices
+    (700, 811, 20, 3),      # k=20 (u64 k-mer values)
+    (300, 1531, 31, 3),     # k=31: base-5 value wraps mod 2^64
+    (500, 1201, 13, 2),     # h=2: generic hash path
+    (500, 1201, 13, 4),     # h=4
+    (64, 1, 13, 3),         # a single block
+]
+
+
+@pytest.mark.parametrize("n_bins,n_blocks,k,h", GEOMETRIES)
+def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
+    rng = np.random.default_rng(n_bins * 7 + n_blocks + k + h)
+    W = (n_bins + 63) // 64
+    n_bits = n_blocks * W * 64 + int(rng.integers(0, 64 * W))  # ragged tail bits that belong to no block
+    d = capi.DeviceIBF.create(0, n_bins, h, k, n_bits)
+    assert d.info["n_blocks"] == n_blocks and d.info["bin_width"] == W
+    d.fill_synth(1234 + n_bins)
+    ref = H.random_dna(rng, 6000)
+    nb = min(n_bins, 12)
+    starts = np.arange(nb, dtype=np.uint64) * 500
+    d.insert(ref, starts, starts + 500, rng.choice(n_bins, size=nb, replace=False).astype(np.uint64))
+    o, _keep = oracle_view(d)
+    reads = make_reads(rng, ref, 96, lo=max(5, k - 3), hi=460)
+    reads += ["", "A" * (k - 1), "A" * k, "N" * 50, "ACGT" * 90, ref[100:100 + k], ref[0:360]]
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [])
+    maxcount, best, decision, status = eng.classify(buf, offs, lens)
+    expect = po.batch_raw_max(o, buf, offs, lens, 4)
+    assert np.array_equal(maxcount[:, 0], expect)
+    assert expect.max() > 100  # the planted reads really hit
+    # deplete-only decision + status against the oracle's check_unblock
+    exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
+    assert np.array_equal(decision, exp_dec)
+    assert np.array_equal(status, exp_st)
+    assert (status == capi.RB_ERR_SHORT_READ).sum() >= 2
+
+
+def test_long_reads_use_wide_counters():
+    # > 1023 k-mers per read -> 16 counter planes (uint16_t semantics of the reference)
+    rng = np.random.default_rng(5)
+    d = capi.DeviceIBF.create(0, 1024, 3, 13, 1024 * 2048)
+    ref = H.random_dna(rng, 30000)
+    d.add_sequence(ref, 1000)
+    o, _k = oracle_view(d)
+    reads = [ref[100:100 + 1500], ref[5000:5000 + 2300], H.random_dna(rng, 1800), ref[900:1100] * 8, ref[:4000]]
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [])
+    maxcount, _, decision, status = eng.classify(buf, offs, lens)
+    assert np.array_equal(maxcount[:, 0], po.batch_raw_max(o, buf, offs, lens, 2))
+    assert maxcount[:, 0].max() > 1023
+    exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens)
+    assert np.array_equal(decision, exp_dec) and np.array_equal(status, exp_st)
+
+
+def test_fill_kernel_matches_oracle_definition():
+    d = capi.DeviceIBF.create(0, 100, 3, 13, 128 * 3001 + 77)
+    d.fill_synth(99)
+    got = d.download().words().copy()
+    o = po.OracleIBF(100, 3, 13, 128 * 3001 + 77)
+    o.fill_synth(99)
+    assert np.array_equal(got, o.words())
+
+
+@pytest.mark.parametrize("n_bins,k,frag", [(70, 13, 1000), (1024, 13, 977), (9, 15, 100000), (200, 20, 333)])
+def test_insert_kernel_builds_identical_filter(n_bins, k, frag):
+    # K4 + the reference fragmenter against the oracle's create_filter restatement: same bits
+    rng = np.random.default_rng(n_bins + k)
+    seqs = [H.random_dna(rng, int(L), with_n=0.001) for L in (frag * 3 + 17, frag, 5 * k, frag * 2 - 1)]
+    bits = capi.calculate_filter_size_bits(frag, k, 3, 0.01, n_bins)
+    assert bits == po.calculate_filter_size_bits(frag, k, 3, 0.01, n_bins)
+    d = capi.DeviceIBF.create(0, n_bins, 3, k, bits)
+    o = po.OracleIBF(n_bins, 3, k, bits)
+    b_gpu = b_cpu = 0
+    for s in seqs:
+        c = capi.cut_out_nnns(s)
+        assert c == po.cut_out_nnns(s)
+        b_gpu = d.add_sequence(c, frag, b_gpu)
+        b_cpu = o.add_sequence(po.encode(c), frag, b_cpu)
+    assert b_gpu == b_cpu <= n_bins
+    host = d.download()
+    nw = o.n_bits // 64
+    assert np.array_equal(host.words()[:nw], o.words()[:nw])
+    assert int(host.words()[:nw].astype(np.uint64).sum()) != 0
+
+
+def test_reference_kat_through_the_gpu(refdata):
+    # 282 / 182 / index 0 / (282,182): src/test/libIBFTests/read.hpp:221-251
+    filt = []
+    for name in ("libIBFTests_test.fasta", "libIBFTests_test1.fasta"):
+        recs = [s for _, s in H.read_fasta(os.path.join(refdata, name)) if len(s) >= 13]
+        cleaned = [capi.cut_out_nnns(s) for s in recs]
+        n_bins = sum(len(c) // 100000 + 1 for c in cleaned)
+        bits = capi.calculate_filter_size_bits(100000, 13, 3, 0.01, n_bins)
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, bits)
+        b = 0
+        for c in cleaned:
+            b = d.add_sequence(c, 100000, b)
+        filt.append(d)
+    buf, offs, lens = H.pack_reads([READ_354, "AAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAG"])
+    # classify(vector<IBFMeta>) over both filters as targets
+    eng = capi.Engine(0, [], filt)
+    maxcount, best, decision, status = eng.classify(buf, offs, lens, mode=capi.RB_MODE_CLASSIFY_CHUNK)
+    assert maxcount[0].tolist() == [282, 182] and best[0] == 0 and decision[0] == 1
+    assert maxcount[1, 0] == 23 and best[1] == -1 and decision[1] == 0  # threshold -7 wraps: no match
+    # pair overload: v1 = {test.ibf}, v2 = {test1.ibf}; both hit -> check_unblock re-tests and waits
+    eng2 = capi.Engine(0, [filt[0]], [filt[1]])
+    mc, _, dec, st = eng2.classify(buf, offs, lens)
+    assert mc[0].tolist() == [282, 182] and dec[0] == 0 and st[0] == 0
+
+
+@pytest.mark.parametrize("nd,nt", [(1, 1), (2, 3), (1, 0), (0, 2), (3, 0)])
+def test_decisions_match_oracle(nd, nt):
+    rng = np.random.default_rng(100 * nd + nt)
+    ref = H.random_dna(rng, 40000)
+    filters, views, keep = [], [], []
+    geos = [(300, 13), (64, 13), (1024, 13), (200, 15), (90, 13)]
+    for i in range(nd + nt):
+        n_bins, k = geos[i % len(geos)]
+        W = (n_bins + 63) // 64
+        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 3001)
+        # overlapping reference windows so that some reads hit deplete AND target filters
+        lo = (i * 6000) % 30000
+        d.add_sequence(ref[lo:lo + 12000], 1000)
+        o, kp = oracle_view(d)
+        filters.append(d); views.append(o); keep.append(kp)
+    dep, tgt = filters[:nd], filters[nd:]
+    odep, otgt = views[:nd], views[nd:]
+    reads = make_reads(rng, ref, 400, lo=10, hi=450, err=0.12) + ["", "ACGTACGTACGT", "ACGTACGTACGTA", "ACGTACGTACGTAC" ]
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, dep, tgt)
+    for r in (0.1, 0.05, 0.15):
+        maxcount, best, decision, status = eng.classify(buf, offs, lens, error_rate=r)
+        exp_dec, exp_st = po.batch_check_unblock(odep, otgt, buf, offs, lens, r=r, n_threads=4)
+        assert np.array_equal(decision, exp_dec), "check_unblock decisions differ at r=%g" % r
+        assert np.array_equal(status, exp_st)
+    assert len(set(exp_dec.tolist())) >= 2
+    # offline chunk semantics (classify.hpp): classified flag, credited target, failed status
+    _, best, classified, status = eng.classify(buf, offs, lens, mode=capi.RB_MODE_CLASSIFY_CHUNK)
+    for i, rd in enumerate(reads):
+        if len(rd) == 0:
+            continue
+        res = po.classify_read_chunks(odep, otgt, rd, len(rd), 1)
+        assert res["status"] == status[i], (i, len(rd))
+        assert res["classified"] == bool(classified[i]), (i, len(rd))
+        if res["classified"] and nt:
+            assert res["best_target"] == best[i]
+
+
+def test_ibf_file_roundtrip_through_hbm(tmp_path):
+    rng = np.random.default_rng(3)
+    ref = H.random_dna(rng, 20000)
+    o = H.build_filter_like_reference([ref], k=13, fragment_length=1500)
+    p = tmp_path / "ref.ibf"
+    o.store(str(p))  # written by the oracle's restatement of seqan::store
+    assert capi.is_ibf_file(str(p))
+    d = capi.DeviceIBF.open(0, str(p))  # load_filter straight into HBM
+    assert (d.info["n_bins"], d.info["n_hash"], d.info["kmer_size"], d.info["n_bits"]) == (o.n_bins, 3, 13, o.n_bits)
+    reads = make_reads(rng, ref, 64)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [])
+    maxcount, _, _, _ = eng.classify(buf, offs, lens)
+    assert np.array_equal(maxcount[:, 0], po.batch_raw_max(o, buf, offs, lens, 2))
+    # and back: product store -> oracle load
+    q = tmp_path / "back.ibf"
+    d.download().store(str(q))
+    with open(p, "rb") as a, open(q, "rb") as b:
+        assert a.read() == b.read()
+
+
+def test_device_pointer_api_and_column_shards():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(8)
+    d = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * 512)
+    d.fill_synth(3)
+    ref = H.random_dna(rng, 8000)
+    d.add_sequence(ref, 100)
+    o, _k = oracle_view(d)
+    reads = make_reads(rng, ref, 300, lo=100, hi=400)
+    buf, offs, lens = H.pack_reads(reads)
+    dev = torch.device("cuda:0")
+    t_seq = torch.from_numpy(buf).to(dev)
+    t_off = torch.from_numpy(offs.view(np.int64)).to(dev)
+    t_len = torch.from_numpy(lens.view(np.int32)).to(dev)
+    n = len(reads)
+    t_max = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+    t_dec = torch.zeros(n, dtype=torch.uint8, device=dev)
+    t_st = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng = capi.Engine(0, [d], [])
+    stream = torch.cuda.current_stream().cuda_stream
+    eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, int(lens.max()),
+                        d_maxcount=t_max.data_ptr(), d_decision=t_dec.data_ptr(), d_status=t_st.data_ptr(),
+                        stream=stream)
+    torch.cuda.synchronize()
+    expect = po.batch_raw_max(o, buf, offs, lens, 4)
+    assert np.array_equal(t_max.cpu().numpy().view(np.uint16)[:, 0], expect)
+    exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
+    assert np.array_equal(t_dec.cpu().numpy(), exp_dec)
+    # bin-sharded layout: per-rank partial maxima, element-wise max == unsharded result
+    for world in (2, 3, 8):
+        acc = np.zeros(n, dtype=np.uint16)
+        for rank in range(world):
+            eng.set_column_shard(rank, world)
+            t_part = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+            eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, int(lens.max()),
+                                d_maxcount=t_part.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            acc = np.maximum(acc, t_part.cpu().numpy().view(np.uint16)[:, 0])
+        assert np.array_equal(acc, expect)
+        t_all = torch.from_numpy(acc.view(np.int16).reshape(n, 1)).to(dev)
+        t_dec2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        eng.decide_device(t_all.data_ptr(), t_len.data_ptr(), n, int(lens.max()), d_decision=t_dec2.data_ptr(),
+                          stream=stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(t_dec2.cpu().numpy(), exp_dec)
+    eng.set_column_shard(0, 1)
+
+
+def test_empty_batch_and_null_filters():
+    d = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 100)
+    eng = capi.Engine(0, [d], [])
+    mc, best, dec, st = eng.classify(np.zeros(1, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    assert mc.shape == (0, 1)
+    with pytest.raises(capi.RBError) as ei:
+        capi.Engine(0, [], [])
+    assert ei.value.status == capi.RB_ERR_NULL_FILTER
