@@ -175,11 +175,12 @@ RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_
                             uint32_t max_len, double error_rate, double significance, int mode,
                             void *d_best_target, void *d_decision, void *d_status, void *stream);
 
-/* time spent by the count kernels of the most recent rb_classify_batch* call on this engine,
- * measured with hipEvents on the launch stream (ms); negative if unavailable */
-RB_API double rb_engine_last_kernel_ms(rb_engine *e);
-/* enable/disable per-call kernel event timing (default off; adds two event records per filter) */
+/* Kernel timing for the roofline figure: when enabled every rb_classify_batch* call brackets its
+ * count kernels (K1, all filters) with a hipEvent pair recorded on the launch stream, without
+ * synchronising.  rb_engine_kernel_time waits for the recorded pairs, returns their summed elapsed
+ * time and the number of calls, and resets the accumulation. */
 RB_API int rb_engine_set_timing(rb_engine *e, int enabled);
+RB_API int rb_engine_kernel_time(rb_engine *e, double *total_ms, uint64_t *n_calls);
 
 #ifdef __cplusplus
 }

@@ -67,8 +67,8 @@ SIGNATURES = {
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
-    "rb_engine_last_kernel_ms": (_dbl, [_vp]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
+    "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
 }
 
 _lib = None
@@ -267,8 +267,11 @@ class Engine:
     def set_timing(self, on):
         _check(lib().rb_engine_set_timing(self.h, int(on)), "rb_engine_set_timing")
 
-    def last_kernel_ms(self):
-        return lib().rb_engine_last_kernel_ms(self.h)
+    def kernel_time(self):
+        """(total_ms, n_calls) of the count kernels since the last query; waits for them"""
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _check(lib().rb_engine_kernel_time(self.h, C.byref(ms), C.byref(n)), "rb_engine_kernel_time")
+        return ms.value, n.value
 
     def destroy(self):
         if self.h:

@@ -61,9 +61,11 @@ struct rb_engine {
     std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
     uint32_t nd = 0, nt = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // hipEvent pairs around the count kernels of each call, on the launch stream; resolved lazily
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_ring;
+    size_t ev_used = 0;
     bool timing = false;
-    double last_kernel_ms = -1.0;
+    std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
     // threshold tables
     DevBuf d_thr;
@@ -325,8 +327,6 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     e->nd = (uint32_t)n_deplete;
     e->nt = (uint32_t)n_target;
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (he == hipSuccess) he = hipEventCreate(&e->ev0);
-    if (he == hipSuccess) he = hipEventCreate(&e->ev1);
     if (he != hipSuccess) { rb_engine_destroy(e); return rb::fail(RB_ERR_HIP, hipGetErrorString(he)); }
     *out = e;
     return RB_OK;
@@ -337,8 +337,7 @@ void rb_engine_destroy(rb_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (auto &p : e->ev_ring) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf *b : {&e->d_thr, &e->d_part, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
@@ -356,11 +355,30 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
 int rb_engine_set_timing(rb_engine *e, int enabled)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
     e->timing = enabled != 0;
+    e->ev_used = 0;
     return RB_OK;
 }
 
-double rb_engine_last_kernel_ms(rb_engine *e) { return e ? e->last_kernel_ms : -1.0; }
+int rb_engine_kernel_time(rb_engine *e, double *total_ms, uint64_t *n_calls)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    double sum = 0.0;
+    for (size_t i = 0; i < e->ev_used; ++i) {
+        RB_HIP(hipEventSynchronize(e->ev_ring[i].second));
+        float ms = 0.f;
+        RB_HIP(hipEventElapsedTime(&ms, e->ev_ring[i].first, e->ev_ring[i].second));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (n_calls) *n_calls = e->ev_used;
+    e->ev_used = 0;
+    return RB_OK;
+}
 
 }  // extern "C"
 
@@ -431,7 +449,17 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         if (rc != RB_OK) return rc;
         maxcount = (uint16_t *)e->d_maxcount.p;
     }
-    if (e->timing) RB_HIP(hipEventRecord(e->ev0, st));
+    std::pair<hipEvent_t, hipEvent_t> *evp = nullptr;
+    if (e->timing) {
+        if (e->ev_used == e->ev_ring.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            RB_HIP(hipEventCreate(&a));
+            RB_HIP(hipEventCreate(&b));
+            e->ev_ring.emplace_back(a, b);
+        }
+        evp = &e->ev_ring[e->ev_used++];
+        RB_HIP(hipEventRecord(evp->first, st));
+    }
     for (size_t fi = 0; fi < nf; ++fi) {
         const rb_dibf *f = e->filters[fi];
         CountLaunch a{};
@@ -477,17 +505,11 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
             RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, st));
         }
     }
-    if (e->timing) RB_HIP(hipEventRecord(e->ev1, st));
+    if (evp) RB_HIP(hipEventRecord(evp->second, st));
     if (e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
         rc = run_decide(e, maxcount, (const uint32_t *)d_lens, n_reads, max_len, error_rate, significance, mode,
                         (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
         if (rc != RB_OK) return rc;
-    }
-    if (e->timing) {
-        RB_HIP(hipEventSynchronize(e->ev1));
-        float ms = 0.f;
-        RB_HIP(hipEventElapsedTime(&ms, e->ev0, e->ev1));
-        e->last_kernel_ms = ms;
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     return RB_OK;
@@ -527,6 +549,7 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
     }
     const size_t nf = e->filters.size();
     hipStream_t st = e->stream;
+    std::lock_guard<std::mutex> host_lock(e->host_mu);  // the staging buffers below are per engine
     {
         std::lock_guard<std::mutex> lock(e->mu);
         if ((rc = e->d_seqs.ensure(total ? total : 1)) != RB_OK) return rc;
