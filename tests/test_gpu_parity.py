@@ -111,7 +111,8 @@ def test_long_reads_use_wide_counters():
 def test_fill_kernel_matches_oracle_definition():
     d = capi.DeviceIBF.create(0, 100, 3, 13, 128 * 3001 + 77)
     d.fill_synth(99)
-    got = d.download().words().copy()
+    host = d.download()  # keep the image alive while its words are viewed
+    got = host.words().copy()
     o = po.OracleIBF(100, 3, 13, 128 * 3001 + 77)
     o.fill_synth(99)
     assert np.array_equal(got, o.words())
