@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the IBF classify hot path on MI355X (BASELINE.json metric).
+
+A step = one pass of the hot path (K1 count/max for every filter + K2 decision) over one batch of
+synthetic 360 bp read prefixes that is already resident in HBM, against IBF(s) resident in HBM.
+N=1 workload = BASELINE.json configs[1] ("c2"); other configs via --workload.  With N>1 (torchrun)
+every rank holds a replica of the IBF and its own shard of reads (weak scaling, no data-path
+collective); time = max over ranks, value = all reads / that time.
+
+Prints ONE JSON line with the driver contract fields plus "roofline" and "cpu_baseline".
+The CPU oracle is used here only as the checker / cpu_baseline leg, never in the timed path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", help="c2 (default, BASELINE configs[1]), c3, c3np2, c1, c4")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's batch)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--check-reads", type=int, default=2048, help="reads checked against the oracle (rank 0)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    from readbouncer_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev_index = local_rank if world > 1 else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+
+    # ---------------------------------------------------------------- workload (untimed set-up)
+    t_setup = time.time()
+    if args.workload == "c4":
+        wd, wt = synth.WORKLOADS["c3"], synth.WORKLOADS["zymo"]
+        dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
+        tgt, ref_t = synth.build_device_filter(dev_index, wt, fill_seed=6, plant_seed=60)
+        deplete, target = [dep], [tgt]
+        ref = np.concatenate([ref_d, ref_t])
+        wname = "config4: deplete=GRCh38-scale IBF (8192 bins, 8 GiB) + target=Zymo-mock-like IBF (600 bins), check_unblock"
+        n_reads = args.reads or 2_000_000
+        read_len = 360
+    else:
+        w = synth.WORKLOADS[args.workload]
+        seeds = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60)}[args.workload]
+        dep, ref = synth.build_device_filter(dev_index, w, fill_seed=seeds[0], plant_seed=seeds[1])
+        deplete, target = [dep], []
+        wname = w["name"]
+        n_reads = args.reads or w["reads"]
+        read_len = w["read_len"]
+    filters = deplete + target
+    geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in filters]
+    bytes_per_read = synth.algorithmic_bytes_per_read(read_len, geo)
+
+    # reads are generated on the device (plumbing) and stay resident in HBM
+    t_seq, t_off, t_len = synth.make_reads_device(1000 + rank, n_reads, read_len, ref, dev)
+    lens = np.full(n_reads, read_len, dtype=np.uint32)
+    offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(read_len)
+    t_max = torch.zeros((n_reads, len(filters)), dtype=torch.int16, device=dev)
+    t_best = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    eng = capi.Engine(dev_index, deplete, target)
+    stream = torch.cuda.current_stream().cuda_stream
+    max_len = int(lens.max())
+
+    def step():
+        eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
+                            capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), t_best.data_ptr(), t_dec.data_ptr(),
+                            t_st.data_ptr(), stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    setup_s = time.time() - t_setup
+    # ---------------------------------------------------------------- warm-up + timed region
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    eng.set_timing(True)  # hipEvent pairs around the count kernels, on the launch stream, no sync
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, n_calls = eng.kernel_time()
+    eng.set_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_reads = n_reads * world * args.steps
+    value = total_reads / elapsed
+
+    result = None
+    if rank == 0:
+        avg_kernel_s = (kernel_ms / max(1, n_calls)) / 1e3
+        achieved = bytes_per_read * n_reads / avg_kernel_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        decisions = t_dec.cpu().numpy()
+        result = {
+            "metric": "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)",
+            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wname, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
+                       "filters": [{"n_bins": g[0], "k": g[1], "h": g[2], "bytes": f.info["n_words"] * 8}
+                                   for g, f in zip(geo, filters)],
+                       "parallelism": "read-sharded x%d, IBF replicated" % world,
+                       "decisions": np.bincount(decisions, minlength=3).tolist()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "ibf_count_max_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_read": bytes_per_read,
+                         "algorithmic_bytes_per_launch": bytes_per_read * n_reads},
+            "setup_s": setup_s,
+        }
+
+    # ---------------------------------------------------------------- parity check + CPU baseline (rank 0, N=1)
+    buf = None
+    if rank == 0:
+        cap = min(n_reads, 1 << 21)  # host copy of the head of the batch: CPU baseline, parity, latency legs
+        buf = t_seq[: cap * read_len].cpu().numpy()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        keep = []
+        views = []
+        for f in filters:
+            h = f.download()
+            keep.append(h)
+            views.append(po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"],
+                                           h.words()))
+        od, ot = views[:len(deplete)], views[len(deplete):]
+        cores = os.cpu_count() or 1
+        cap = len(buf) // read_len
+        pilot = min(cap, 64 * min(cores, 64))
+        tp = time.perf_counter()
+        po.batch_check_unblock(od, ot, buf, offs[:pilot], lens[:pilot], n_threads=cores)
+        pilot_s = time.perf_counter() - tp
+        sample = int(min(cap, max(pilot, pilot * args.cpu_seconds / max(pilot_s, 1e-6))))
+        tp = time.perf_counter()
+        cpu_dec, cpu_st = po.batch_check_unblock(od, ot, buf, offs[:sample], lens[:sample], n_threads=cores)
+        cpu_s = time.perf_counter() - tp
+        t1 = time.perf_counter()
+        n1 = min(sample, max(16, int(sample / cores / 4)))
+        po.batch_check_unblock(od, ot, buf, offs[:n1], lens[:n1], n_threads=1)
+        one_s = time.perf_counter() - t1
+        gpu_dec = decisions[:sample]
+        mism = int((gpu_dec != cpu_dec).sum())
+        result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
+                                  "sample": "first %d reads of the same batch, oracle check_unblock, read-parallel "
+                                            "pthreads; single-thread rate %.1f reads/s on %d reads"
+                                            % (sample, n1 / one_s, n1),
+                                  "single_thread_reads_per_s": n1 / one_s}
+        result["parity"] = {"checked_reads": sample, "decision_mismatches": mism}
+        if mism:
+            result["parity"]["error"] = "GPU decisions differ from the oracle"
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    # ---------------------------------------------------------------- per-read classify latency (small batches)
+    if rank == 0 and not args.no_latency:
+        lat = {}
+        for mb in (64, 256, 1024):
+            m = min(mb, len(buf) // read_len)
+            sub = np.ascontiguousarray(buf[: m * read_len])
+            so, sl = offs[:m].copy(), lens[:m].copy()
+            for _ in range(5):
+                eng.classify(sub, so, sl)
+            ts = []
+            for _ in range(200):
+                a = time.perf_counter()
+                eng.classify(sub, so, sl)  # host buffers in, decisions back on the host
+                ts.append((time.perf_counter() - a) * 1e3)
+            ts = np.sort(np.array(ts))
+            lat[str(mb)] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99) - 1]),
+                            "reads_per_s": m / (float(ts[len(ts) // 2]) / 1e3)}
+        result["latency"] = {"what": "host-to-host rb_classify_batch wall time per micro-batch (H2D + kernels + D2H)",
+                             "by_batch": lat}
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+        if result.get("parity", {}).get("decision_mismatches"):
+            sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()
