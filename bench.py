@@ -90,7 +90,9 @@ def main():
     t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     eng = capi.Engine(dev_index, deplete, target)
-    stream = torch.cuda.current_stream().cuda_stream
+    # a dedicated non-null stream: steps are queued asynchronously; torch.cuda.synchronize() covers it
+    side = torch.cuda.Stream(device=dev)
+    stream = side.cuda_stream
     max_len = int(lens.max())
 
     def step():

@@ -243,7 +243,10 @@ def test_device_pointer_api_and_column_shards():
     t_dec = torch.zeros(n, dtype=torch.uint8, device=dev)
     t_st = torch.zeros(n, dtype=torch.uint8, device=dev)
     eng = capi.Engine(0, [d], [])
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.synchronize()  # inputs/outputs were produced on torch's default stream
+    side = torch.cuda.Stream()  # a real (non-null) stream: the call is then fully asynchronous
+    stream = side.cuda_stream
+    assert stream != 0
     eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, int(lens.max()),
                         d_maxcount=t_max.data_ptr(), d_decision=t_dec.data_ptr(), d_status=t_st.data_ptr(),
                         stream=stream)
@@ -258,6 +261,7 @@ def test_device_pointer_api_and_column_shards():
         for rank in range(world):
             eng.set_column_shard(rank, world)
             t_part = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
             eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, int(lens.max()),
                                 d_maxcount=t_part.data_ptr(), stream=stream)
             torch.cuda.synchronize()
@@ -265,6 +269,7 @@ def test_device_pointer_api_and_column_shards():
         assert np.array_equal(acc, expect)
         t_all = torch.from_numpy(acc.view(np.int16).reshape(n, 1)).to(dev)
         t_dec2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         eng.decide_device(t_all.data_ptr(), t_len.data_ptr(), n, int(lens.max()), d_decision=t_dec2.data_ptr(),
                           stream=stream)
         torch.cuda.synchronize()
