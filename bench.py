@@ -134,7 +134,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                per_read = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_read")
+                traffic = per_read * n_reads if per_read else None  # PMC passes of profiles/collect_pmc.sh
             except Exception:
                 traffic = None
         decisions = t_dec.cpu().numpy()
