@@ -268,9 +268,12 @@ int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_t *star
     std::vector<uint64_t> prefix(n_fragments + 1, 0);
     for (size_t i = 0; i < n_fragments; ++i) {
         if (ends[i] > len || starts[i] > ends[i]) return rb::fail(RB_ERR_INVALID_ARG, "fragment outside the sequence");
-        if (bins[i] >= f->geo.n_bins) return rb::fail(RB_ERR_INVALID_ARG, "bin id outside the filter");
         const uint64_t flen = ends[i] - starts[i];
-        prefix[i + 1] = prefix[i] + (flen >= k ? flen - k + 1 : 0);
+        const uint64_t nk = flen >= k ? flen - k + 1 : 0;
+        // a tail fragment shorter than k carries no k-mer; the reference hands it a bin id past the
+        // predicted bin count (IBFBuild.cpp:171-190 vs :90) and insertKmer then touches nothing
+        if (nk && bins[i] >= f->geo.n_bins) return rb::fail(RB_ERR_INVALID_ARG, "bin id outside the filter");
+        prefix[i + 1] = prefix[i] + nk;
     }
     const uint64_t total = prefix[n_fragments];
     if (total == 0) return RB_OK;

@@ -124,7 +124,7 @@ def test_config1_build_and_classify(tmp_path, refdata):
     assert ibf.exists()
     # byte-identical to the oracle's restatement of create_filter + store
     o = H.build_filter_like_reference([genome], k=13, fragment_length=100000)
-    assert o.n_bins == 64
+    assert o.n_bins == 63 and o.bin_width == 1  # 6 299 999 bases after cutOutNNNs' dropped base: 62 + 1 bins
     op = tmp_path / "oracle.ibf"
     o.store(str(op))
     assert open(ibf, "rb").read() == open(op, "rb").read()
