@@ -76,19 +76,21 @@ _lib = None
 
 def _preload_hip_runtime():
     """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME as
-    /opt/rocm's, different file); if our library pulled in the system copy and torch later loaded its
-    own, two runtimes would fight over the device.  So when torch is installed its runtime is loaded
-    first and libreadbouncer_amd.so binds to it by SONAME.  Without torch the system runtime is used."""
+    /opt/rocm's, different file).  If our library pulled in the system copy and torch loaded its own
+    later, two runtimes would fight over the device; and loading torch's libraries after a runtime has
+    already been initialised can make their code-object registration take minutes.  So when torch is
+    installed it is imported BEFORE libreadbouncer_amd.so is loaded: its libraries register lazily and
+    our library binds to the already loaded runtime by SONAME.  Without torch the system runtime is
+    used.  torch stays plumbing: nothing else of it is touched here."""
     import importlib.util
-    try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
+    import sys
+    if "torch" in sys.modules:
         return
-    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(cand):
-        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    try:
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+    except Exception:
+        pass
 
 
 def lib():
