@@ -175,6 +175,11 @@ RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_
                             uint32_t max_len, double error_rate, double significance, int mode,
                             void *d_best_target, void *d_decision, void *d_status, void *stream);
 
+/* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
+ * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
+ * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */
+RB_API int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads);
+
 /* Kernel timing for the roofline figure: when enabled every rb_classify_batch* call brackets its
  * count kernels (K1, all filters) with a hipEvent pair recorded on the launch stream, without
  * synchronising.  rb_engine_kernel_time waits for the recorded pairs, returns their summed elapsed

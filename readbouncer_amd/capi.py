@@ -67,6 +67,7 @@ SIGNATURES = {
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
 }
@@ -283,6 +284,9 @@ class Engine:
 
     def set_column_shard(self, rank, world):
         _check(lib().rb_engine_set_column_shard(self.h, rank, world), "rb_engine_set_column_shard")
+
+    def set_split_threshold(self, max_reads):
+        _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")
 
     def set_timing(self, on):
         _check(lib().rb_engine_set_timing(self.h, int(on)), "rb_engine_set_timing")

@@ -30,6 +30,7 @@ struct CountLaunch {
     uint32_t col_begin, col_end;  // word columns of every block this launch covers
     uint32_t n_slices;            // column slices of 2^lg * wpl words
     int lg, wpl, planes;
+    int split_waves;              // >= 2: latency form, one workgroup of split_waves waves per read
     uint16_t *out;
     uint32_t out_read_stride, out_slice_stride;
 };
@@ -42,6 +43,7 @@ struct DecideParams {
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
+int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
 hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,
                                 uint32_t nf, uint32_t fidx, hipStream_t st);
 hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, uint32_t n_reads,

@@ -67,6 +67,7 @@ struct rb_engine {
     bool timing = false;
     std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
+    uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     // threshold tables
     DevBuf d_thr;
     uint32_t thr_len = 0;
@@ -355,6 +356,14 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
     return RB_OK;
 }
 
+int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->split_threshold = max_reads;
+    return RB_OK;
+}
+
 int rb_engine_set_timing(rb_engine *e, int enabled)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -493,6 +502,10 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         }
         const uint32_t slice_words = (1u << a.lg) * a.wpl;
         a.n_slices = (Weff + slice_words - 1) / slice_words;
+        // micro-batches cannot fill 256 CUs with one wave per read: spread each read over a workgroup
+        a.split_waves = 0;
+        if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
+            a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
         if (a.n_slices == 1) {
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;

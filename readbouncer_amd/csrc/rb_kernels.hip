@@ -126,164 +126,259 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kMaxTiles = 8;                                      // tiles per macro tile when LG < 3
 constexpr int kStageBytes = 64 * kMaxTiles + rbspec::kMaxKmer;    // bases staged per macro tile
 
+template <int LG>
+struct TileShape {
+    static constexpr int LPB = 1 << LG;                 // lanes that cover one block
+    static constexpr int NG = 64 >> LG;                 // blocks gathered per wave instruction
+    static constexpr int SPT = LPB;                     // phase-B steps per 64-k-mer tile
+    static constexpr int J = SPT >= 8 ? 1 : 8 / SPT;    // tiles per macro tile (so that steps come in eights)
+    static constexpr int STEPS = SPT * J;
+    static constexpr int ITEMS = 64 * J;                // k-mers per macro tile
+};
+
+// per-lane view of the column slice a wave works on
+template <int WPL>
+struct LaneCols {
+    uint64_t valid[WPL];        // bins of this lane's word(s) that exist (padding and foreign columns masked)
+    const uint64_t *lane_base;  // f.words + first word column of this lane
+    bool colok;                 // lane owns at least one existing column
+    bool col_full;              // WPL == 2: both words exist, a 16-byte load is allowed
+};
+
+template <int LG, int WPL>
+__device__ __forceinline__ LaneCols<WPL> make_lane_cols(const IbfDev &f, int lane, uint32_t col_begin, uint32_t col_end,
+                                                        uint32_t slice)
+{
+    constexpr int LPB = 1 << LG;
+    const int c = lane & (LPB - 1);
+    const uint32_t W = f.bin_width;
+    const uint32_t col0 = col_begin + slice * (uint32_t)(LPB * WPL) + (uint32_t)(c * WPL);
+    LaneCols<WPL> lc;
+    lc.colok = false;
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) {
+        const uint32_t col = col0 + w;
+        const bool ok = col < col_end;
+        const uint32_t rem = f.n_bins & 63u;
+        lc.valid[w] = !ok ? 0ULL : (col == W - 1 && rem) ? ((1ULL << rem) - 1) : ~0ULL;
+        lc.colok |= ok;
+    }
+    lc.col_full = (col0 + WPL) <= col_end;
+    lc.lane_base = f.words + col0;
+    return lc;
+}
+
+// Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
+// mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves).
+template <int LG, int WPL, int NP, int H>
+__device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
+                                             const uint8_t *__restrict__ seq, uint32_t len, uint32_t n, int strand,
+                                             uint32_t mt_first, uint32_t mt_step, uint8_t *stage, int lane)
+{
+    using T = TileShape<LG>;
+    constexpr int NG = T::NG, SPT = T::SPT, J = T::J, STEPS = T::STEPS, ITEMS = T::ITEMS;
+    constexpr int HR = H > 0 ? H : 1;
+    const int g = lane >> LG;
+    const uint32_t W = f.bin_width;
+    const uint32_t k = f.k;
+
+    for (uint32_t mt = mt_first; mt < n; mt += mt_step) {
+        // ---- stage the bases of this macro tile as Dna5 ordinals ((Dna5String) conversion)
+        const uint32_t wlen = min((uint32_t)(ITEMS + k - 1), len - mt);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < wlen; i += 64) stage[i] = (uint8_t)rbspec::dna5_ord(seq[mt + i]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- phase A: one k-mer per lane and tile
+        uint32_t idx[J][HR];
+        uint64_t kv[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const uint32_t p = mt + j * 64 + lane;
+            uint64_t v = 0;
+            if (p < n) {
+                const uint8_t *b = stage + (p - mt);
+                if (strand == 0) {
+                    for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
+                } else {  // k-mer of the reverse complement that covers the same window
+                    for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                }
+            }
+            kv[j] = v;
+            if constexpr (H > 0) {
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    idx[j][h] = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+            }
+        }
+
+        // ---- phase B: gather + count, eight steps at a time
+#pragma unroll 1
+        for (int blk = 0; blk < STEPS / 8; ++blk) {
+            {
+                const int s0 = blk * 8;
+                const uint32_t first = mt + (uint32_t)((s0 / SPT) * 64 + (s0 % SPT) * NG);
+                if (first >= n) break;  // wave-uniform
+            }
+            uint64_t x[WPL][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = blk * 8 + u;
+                const int j = (SPT >= 8) ? 0 : (u / SPT);  // compile-time either way
+                const int it = (s % SPT) * NG + g;          // k-mer of this group within tile j
+                const uint32_t p = mt + (uint32_t)(j * 64 + it);
+                const bool ok = (p < n) && lc.colok;
+                uint64_t acc[WPL];
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) acc[w] = ok ? lc.valid[w] : 0ULL;
+                if constexpr (H > 0) {
+                    uint32_t b[H];
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        if constexpr (LG == 0) b[h] = idx[j][h];
+                        else if constexpr (LG == 6) b[h] = readlane32(idx[j][h], it);
+                        else b[h] = shfl32(idx[j][h], it);
+                    }
+                    if (ok) {
+#pragma unroll
+                        for (int h = 0; h < H; ++h) {
+                            const uint64_t *src = lc.lane_base + (uint64_t)b[h] * W;
+                            if constexpr (WPL == 1) {
+                                acc[0] &= *src;
+                            } else {
+                                if (lc.col_full) {
+                                    const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(src);
+                                    acc[0] &= q.x;
+                                    acc[1] &= q.y;
+                                } else {
+                                    acc[0] &= *src;
+                                    acc[1] = 0;
+                                }
+                            }
+                        }
+                    }
+                } else {
+                    const uint64_t v = (LG == 0) ? kv[j] : shfl64(kv[j], it);
+                    if (ok) {
+                        for (uint32_t h = 0; h < f.n_hash; ++h) {
+                            const uint32_t bi = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                            const uint64_t *src = lc.lane_base + (uint64_t)bi * W;
+#pragma unroll
+                            for (int w = 0; w < WPL; ++w) acc[w] &= (lc.valid[w] ? src[w] : 0ULL);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) x[w][u] = acc[w];
+            }
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) pl[w].add8(x[w]);
+        }
+    }
+
+    // ---- sum the partial counters of the NG groups (butterfly): every group then holds the total
+    if constexpr (NG > 1) {
+#pragma unroll
+        for (int m = T::LPB; m < 64; m <<= 1) {
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) pl[w].add_from_lane_xor(lane, m);
+        }
+    }
+}
+
+// throughput form: one wave per (read, column slice), both strands in sequence
 template <int LG, int WPL, int NP, int H>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
     IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
     const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
 {
-    constexpr int LPB = 1 << LG;           // lanes that cover one block
-    constexpr int NG = 64 >> LG;           // blocks gathered per wave instruction
-    constexpr int SPT = LPB;               // phase-B steps per 64-k-mer tile
-    constexpr int J = SPT >= 8 ? 1 : 8 / SPT;  // tiles per macro tile (so that steps come in eights)
-    constexpr int STEPS = SPT * J;
-    constexpr int ITEMS = 64 * J;
-    constexpr int HR = H > 0 ? H : 1;
-
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
-
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
     if (read >= n_reads) return;  // wave-uniform; there are no block-level barriers below
 
-    const int g = lane >> LG;
-    const int c = lane & (LPB - 1);
-    const uint32_t W = f.bin_width;
-    const uint32_t col0 = col_begin + blockIdx.y * (uint32_t)(LPB * WPL) + (uint32_t)(c * WPL);
-    uint64_t valid[WPL];
-    bool colok = false;
-#pragma unroll
-    for (int w = 0; w < WPL; ++w) {
-        const uint32_t col = col0 + w;
-        const bool ok = col < col_end;
-        const uint32_t rem = f.n_bins & 63u;
-        valid[w] = !ok ? 0ULL : (col == W - 1 && rem) ? ((1ULL << rem) - 1) : ~0ULL;
-        colok |= ok;
-    }
-    // WPL == 2 loads 16 bytes: the second word must exist (col_end even or lane fully inside)
-    const bool col_full = (col0 + WPL) <= col_end;
-    const uint64_t *lane_base = f.words + col0;
-
+    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, blockIdx.y);
     const uint32_t len = lens[read];
-    const uint32_t k = f.k;
-    const uint32_t n = len >= k ? len - k + 1 : 0;
+    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     const uint8_t *seq = seqs + offsets[read];
-    uint8_t *stage = s_stage[wave];
 
     uint32_t best = 0;
     for (int strand = 0; strand < 2; ++strand) {
         Planes<NP> pl[WPL];
 #pragma unroll
         for (int w = 0; w < WPL; ++w) pl[w].clear();
-
-        for (uint32_t mt = 0; mt < n; mt += ITEMS) {
-            // ---- stage the bases of this macro tile as Dna5 ordinals ((Dna5String) conversion)
-            const uint32_t wlen = min((uint32_t)(ITEMS + k - 1), len - mt);
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i = lane; i < wlen; i += 64) stage[i] = (uint8_t)rbspec::dna5_ord(seq[mt + i]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-
-            // ---- phase A: one k-mer per lane and tile
-            uint32_t idx[J][HR];
-            uint64_t kv[J];
-#pragma unroll
-            for (int j = 0; j < J; ++j) {
-                const uint32_t p = mt + j * 64 + lane;
-                uint64_t v = 0;
-                if (p < n) {
-                    const uint8_t *b = stage + (p - mt);
-                    if (strand == 0) {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
-                    } else {  // k-mer of the reverse complement that covers the same window
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
-                    }
-                }
-                kv[j] = v;
-                if constexpr (H > 0) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h)
-                        idx[j][h] = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
-                }
-            }
-
-            // ---- phase B: gather + count, eight steps at a time
-#pragma unroll 1
-            for (int blk = 0; blk < STEPS / 8; ++blk) {
-                {
-                    const int s0 = blk * 8;
-                    const uint32_t first = mt + (uint32_t)((s0 / SPT) * 64 + (s0 % SPT) * NG);
-                    if (first >= n) break;  // wave-uniform
-                }
-                uint64_t x[WPL][8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int s = blk * 8 + u;
-                    const int j = (SPT >= 8) ? 0 : (u / SPT);  // compile-time either way
-                    const int it = (s % SPT) * NG + g;          // k-mer of this group within tile j
-                    const uint32_t p = mt + (uint32_t)(j * 64 + it);
-                    const bool ok = (p < n) && colok;
-                    uint64_t acc[WPL];
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) acc[w] = ok ? valid[w] : 0ULL;
-                    if constexpr (H > 0) {
-                        uint32_t b[H];
-#pragma unroll
-                        for (int h = 0; h < H; ++h) {
-                            if constexpr (LG == 0) b[h] = idx[j][h];
-                            else if constexpr (LG == 6) b[h] = readlane32(idx[j][h], it);
-                            else b[h] = shfl32(idx[j][h], it);
-                        }
-                        if (ok) {
-#pragma unroll
-                            for (int h = 0; h < H; ++h) {
-                                const uint64_t *src = lane_base + (uint64_t)b[h] * W;
-                                if constexpr (WPL == 1) {
-                                    acc[0] &= *src;
-                                } else {
-                                    if (col_full) {
-                                        const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(src);
-                                        acc[0] &= q.x;
-                                        acc[1] &= q.y;
-                                    } else {
-                                        acc[0] &= *src;
-                                        acc[1] = 0;
-                                    }
-                                }
-                            }
-                        }
-                    } else {
-                        const uint64_t v = (LG == 0) ? kv[j] : shfl64(kv[j], it);
-                        if (ok) {
-                            for (uint32_t h = 0; h < f.n_hash; ++h) {
-                                const uint32_t bi = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
-                                const uint64_t *src = lane_base + (uint64_t)bi * W;
-#pragma unroll
-                                for (int w = 0; w < WPL; ++w) acc[w] &= (valid[w] ? src[w] : 0ULL);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int w = 0; w < WPL; ++w) x[w][u] = acc[w];
-                }
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) pl[w].add8(x[w]);
-            }
-        }
-
-        // ---- sum the partial counters of the NG groups (butterfly), then max over bins
-        if constexpr (NG > 1) {
-#pragma unroll
-            for (int m = LPB; m < 64; m <<= 1) {
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) pl[w].add_from_lane_xor(lane, m);
-            }
-        }
-        const uint32_t m = planes_max<NP, WPL>(pl, valid);
+        count_strand<LG, WPL, NP, H>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, s_stage[wave], lane);
+        const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
         best = m > best ? m : best;
     }
     if (lane == 0) out[(size_t)read * out_read_stride + (size_t)blockIdx.y * out_slice_stride] = (uint16_t)best;
+}
+
+// latency form for micro-batches: one workgroup per (read, column slice); wave w takes strand w&1 and every
+// (blockDim/128)-th macro tile starting at w>>1.  Partial counters meet in LDS (bit-sliced adds), then max.
+template <int LG, int WPL, int NP, int H>
+__global__ __launch_bounds__((WPL == 2 && NP > 10) ? 512 : 1024) void ibf_count_max_split_kernel(
+    IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
+    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
+    uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int per_strand = n_waves >> 1;
+    const int strand = wave & 1, slot = wave >> 1;
+    const uint32_t read = blockIdx.x;
+
+    uint64_t *s_planes = reinterpret_cast<uint64_t *>(s_dyn);  // [wave][WPL][NP][64]
+    uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);
+    uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
+
+    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, blockIdx.y);
+    const uint32_t len = lens[read];
+    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
+    const uint8_t *seq = seqs + offsets[read];
+    constexpr uint32_t ITEMS = TileShape<LG>::ITEMS;
+
+    Planes<NP> pl[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) pl[w].clear();
+    count_strand<LG, WPL, NP, H>(pl, f, lc, seq, len, n, strand, (uint32_t)slot * ITEMS, (uint32_t)per_strand * ITEMS, stage, lane);
+
+    if (slot != 0) {
+#pragma unroll
+        for (int w = 0; w < WPL; ++w)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) s_planes[(((size_t)wave * WPL + w) * NP + i) * 64 + lane] = pl[w].p[i];
+    }
+    __syncthreads();
+    if (slot == 0) {
+        for (int o = 1; o < per_strand; ++o) {
+            const int ow = (o << 1) | strand;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                uint64_t carry = 0;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const uint64_t other = s_planes[(((size_t)ow * WPL + w) * NP + i) * 64 + lane];
+                    uint64_t h, l;
+                    RB_CSA(h, l, pl[w].p[i], other, carry);
+                    pl[w].p[i] = l;
+                    carry = h;
+                }
+            }
+        }
+        const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
+        if (lane == 0) s_max[strand] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t a = s_max[0], b = s_max[1];
+        out[(size_t)read * out_read_stride + (size_t)blockIdx.y * out_slice_stride] = (uint16_t)(a > b ? a : b);
+    }
 }
 
 // combine the per-slice partial maxima of one filter: part[slice][read] -> maxcount[read*nf + f]
@@ -427,11 +522,44 @@ __global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t n_words
 template <int LG, int WPL, int NP, int H>
 static hipError_t launch_count(const CountLaunch &a, hipStream_t st)
 {
+    if (a.split_waves >= 2) {
+        // latency form: one workgroup per read; dynamic LDS = plane exchange + maxima + per-wave staging
+        const int nw = a.split_waves;
+        const size_t lds = (size_t)nw * WPL * NP * 64 * 8 + 16 + (size_t)nw * kStageBytes;
+        auto kern = ibf_count_max_split_kernel<LG, WPL, NP, H>;
+        static bool attr_done = false;  // per instantiation
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        dim3 grid(a.n_reads, a.n_slices);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.seqs, a.offsets, a.lens, a.n_reads, a.col_begin,
+                           a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
+        return hipGetLastError();
+    }
     dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock, a.n_slices);
     hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.seqs,
                        a.offsets, a.lens, a.n_reads, a.col_begin, a.col_end, a.out, a.out_read_stride,
                        a.out_slice_stride);
     return hipGetLastError();
+}
+
+// number of waves the split form may use per read for this geometry (0 = split form not applicable)
+int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
+{
+    const int np = planes <= 10 ? 10 : 16;
+    const size_t per_wave = (size_t)wpl * np * 64 * 8 + kStageBytes;
+    int by_lds = (int)((160 * 1024 - 16) / per_wave);
+    int items = 64 * (lg >= 3 ? 1 : (8 >> lg));
+    int tiles = (int)((max_kmers + items - 1) / items);
+    int nw = 2 * (tiles < 1 ? 1 : tiles);
+    if (nw > by_lds) nw = by_lds;
+    if (nw > 16) nw = 16;
+    if (wpl == 2 && np > 10 && nw > 8) nw = 8;  // that instantiation is built for 512 threads
+    nw &= ~1;
+    return nw >= 4 ? nw : 0;
 }
 
 template <int NP, int H>

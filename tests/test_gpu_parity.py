@@ -80,10 +80,14 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     reads += ["", "A" * (k - 1), "A" * k, "N" * 50, "ACGT" * 90, ref[100:100 + k], ref[0:360]]
     buf, offs, lens = H.pack_reads(reads)
     eng = capi.Engine(0, [d], [])
-    maxcount, best, decision, status = eng.classify(buf, offs, lens)
+    maxcount, best, decision, status = eng.classify(buf, offs, lens)  # micro-batch: latency form of K1
     expect = po.batch_raw_max(o, buf, offs, lens, 4)
     assert np.array_equal(maxcount[:, 0], expect)
     assert expect.max() > 100  # the planted reads really hit
+    eng.set_split_threshold(0)  # same batch through the throughput form (one wave per read)
+    mc2, _, dec2, st2 = eng.classify(buf, offs, lens)
+    assert np.array_equal(mc2[:, 0], expect) and np.array_equal(dec2, decision) and np.array_equal(st2, status)
+    eng.set_split_threshold(2048)
     # deplete-only decision + status against the oracle's check_unblock
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
     assert np.array_equal(decision, exp_dec)
@@ -91,12 +95,13 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     assert (status == capi.RB_ERR_SHORT_READ).sum() >= 2
 
 
-def test_long_reads_use_wide_counters():
+@pytest.mark.parametrize("n_bins,n_blocks", [(1024, 2048), (8192, 300), (40, 5003)])
+def test_long_reads_use_wide_counters(n_bins, n_blocks):
     # > 1023 k-mers per read -> 16 counter planes (uint16_t semantics of the reference)
     rng = np.random.default_rng(5)
-    d = capi.DeviceIBF.create(0, 1024, 3, 13, 1024 * 2048)
+    d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * n_blocks)
     ref = H.random_dna(rng, 30000)
-    d.add_sequence(ref, 1000)
+    d.add_sequence(ref, 1000 if n_bins >= 1024 else 30000 // n_bins + 1)
     o, _k = oracle_view(d)
     reads = [ref[100:100 + 1500], ref[5000:5000 + 2300], H.random_dna(rng, 1800), ref[900:1100] * 8, ref[:4000]]
     buf, offs, lens = H.pack_reads(reads)
@@ -104,6 +109,9 @@ def test_long_reads_use_wide_counters():
     maxcount, _, decision, status = eng.classify(buf, offs, lens)
     assert np.array_equal(maxcount[:, 0], po.batch_raw_max(o, buf, offs, lens, 2))
     assert maxcount[:, 0].max() > 1023
+    eng.set_split_threshold(0)
+    assert np.array_equal(eng.classify(buf, offs, lens)[0], maxcount)
+    eng.set_split_threshold(2048)
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens)
     assert np.array_equal(decision, exp_dec) and np.array_equal(status, exp_st)
 
