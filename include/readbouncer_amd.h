@@ -175,6 +175,26 @@ RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_
                             uint32_t max_len, double error_rate, double significance, int mode,
                             void *d_best_target, void *d_decision, void *d_status, void *stream);
 
+/* ---- live micro-batch shim ----------------------------------------------------------------
+ * Batch form of classify_live_reads (src/main/adaptive_sampling.hpp:214-356), the step between the reference's
+ * classification_queue and action_queue: keeps the once_seen map, concatenates undecided chunks of a read,
+ * applies the 1500 bp cut-off (:315) and maps decisions to actions like Data::sendActions
+ * (src/minknow/Data.cpp:169-187).  Read ids are opaque byte strings. */
+typedef struct rb_live rb_live;
+RB_API int rb_live_create(rb_engine *e, double error_rate, double significance, uint32_t max_undecided_len,
+                          rb_live **out);
+RB_API void rb_live_destroy(rb_live *lv);
+/* out_action[i]: 0 = none yet (read kept in once_seen), 1 = unblock_read, 2 = stop_receiving_data;
+ * out_status[i] != RB_OK = the reference's caught-exception case (no action, state untouched);
+ * out_classified_len[i] = length of the (possibly concatenated) sequence the decision was taken on. */
+RB_API int rb_live_process(rb_live *lv, const char *ids, const uint64_t *id_offsets, const uint32_t *id_lens,
+                           const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n,
+                           uint8_t *out_action, uint8_t *out_status, uint32_t *out_classified_len);
+/* reads currently waiting for more data (size of once_seen) */
+RB_API size_t rb_live_pending(rb_live *lv);
+/* drop a read that ended on the sequencer before a decision was reached */
+RB_API int rb_live_forget(rb_live *lv, const char *id, uint32_t id_len);
+
 /* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
  * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
  * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */

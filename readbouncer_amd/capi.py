@@ -67,6 +67,11 @@ SIGNATURES = {
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_live_create": (_int, [_vp, _dbl, _dbl, _u32, _pp]),
+    "rb_live_destroy": (None, [_vp]),
+    "rb_live_process": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
+    "rb_live_pending": (_sz, [_vp]),
+    "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -300,6 +305,57 @@ class Engine:
     def destroy(self):
         if self.h:
             lib().rb_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Live:
+    """rb_live: micro-batch form of classify_live_reads (once_seen bookkeeping + actions)."""
+
+    def __init__(self, engine, error_rate=0.1, significance=0.95, max_undecided_len=1500):
+        self._engine = engine
+        h = C.c_void_p()
+        _check(lib().rb_live_create(engine.h, error_rate, significance, max_undecided_len, C.byref(h)), "rb_live_create")
+        self.h = h
+
+    def process(self, ids, seqs):
+        """ids, seqs: lists of bytes/str -> (action[n] uint8, status[n] uint8, classified_len[n] uint32)"""
+        n = len(ids)
+        ids = [i.encode() if isinstance(i, str) else i for i in ids]
+        seqs = [s.encode() if isinstance(s, str) else s for s in seqs]
+
+        def pack(items):
+            lens = np.array([len(x) for x in items], dtype=np.uint32)
+            offs = np.zeros(n, dtype=np.uint64)
+            if n:
+                offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+            buf = np.frombuffer(b"".join(items) or b"N", dtype=np.uint8).copy()
+            return buf, offs, lens
+        ib, io, il = pack(ids)
+        sb, so, sl = pack(seqs)
+        action = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint8)
+        clen = np.zeros(n, dtype=np.uint32)
+        _check(lib().rb_live_process(self.h, _ptr(ib), _ptr(io), _ptr(il), _ptr(sb), _ptr(so), _ptr(sl), n, _ptr(action),
+                                     _ptr(status), _ptr(clen)), "rb_live_process")
+        return action, status, clen
+
+    def pending(self):
+        return lib().rb_live_pending(self.h)
+
+    def forget(self, read_id):
+        if isinstance(read_id, str):
+            read_id = read_id.encode()
+        _check(lib().rb_live_forget(self.h, read_id, len(read_id)), "rb_live_forget")
+
+    def destroy(self):
+        if self.h:
+            lib().rb_live_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,184 @@
+// rb_live.cpp -- micro-batch form of classify_live_reads (src/main/adaptive_sampling.hpp:214-356): the step
+// between the reference's classification_queue and action_queue.  Host logic only (the once_seen map, the
+// concatenation of undecided chunks, the 1500 bp cut-off, decision -> action); all classification goes through
+// rb_classify_batch, i.e. the GPU.  Per read and in arrival order the outcome equals the reference's loop:
+//   decision = check_unblock(new chunk)                                            (:237)
+//   1 -> unblock, forget the read (:241-264);  2 -> stop_receiving, forget it (:265-275)
+//   0 -> if seen before: classify stored + new chunk (:284-288); 1/2 as above; still 0: longer than
+//        1500 bp -> stop_receiving ("we assume read to be on target", :315-325) else store the
+//        concatenation (:329); if not seen before: store the chunk, no action (:336)
+//   exception (short read ...) -> logged, no action, state untouched (:340-349)
+// The action codes follow Data::sendActions (src/minknow/Data.cpp:169-187): unblock=true -> unblock_read,
+// unblock=false -> stop_receiving_data.
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "rb_internal.h"
+
+struct rb_live {
+    rb_engine *engine = nullptr;
+    double error_rate = 0.1, significance = 0.95;
+    uint32_t max_undecided_len = 1500;
+    std::unordered_map<std::string, std::pair<std::string, uint8_t>> once_seen;  // id -> (sequence so far, iterstep)
+    std::mutex mu;
+};
+
+namespace {
+
+struct Item {
+    size_t index;        // position in the caller's batch
+    std::string id;
+    const char *seq;
+    uint32_t len;
+};
+
+int classify_strings(rb_live *lv, const std::vector<const char *> &ptrs, const std::vector<uint32_t> &lens,
+                     std::vector<uint8_t> &decision, std::vector<uint8_t> &status)
+{
+    const size_t n = ptrs.size();
+    decision.assign(n, 0);
+    status.assign(n, 0);
+    if (n == 0) return RB_OK;
+    std::string flat;
+    size_t total = 0;
+    for (uint32_t l : lens) total += l;
+    flat.reserve(total + 1);
+    std::vector<uint64_t> offs(n);
+    for (size_t i = 0; i < n; ++i) {
+        offs[i] = flat.size();
+        flat.append(ptrs[i], lens[i]);
+    }
+    if (flat.empty()) flat.push_back('N');
+    return rb_classify_batch(lv->engine, flat.data(), offs.data(), lens.data(), n, lv->error_rate, lv->significance,
+                             RB_MODE_CHECK_UNBLOCK, nullptr, nullptr, decision.data(), status.data());
+}
+
+}  // namespace
+
+extern "C" {
+
+int rb_live_create(rb_engine *e, double error_rate, double significance, uint32_t max_undecided_len, rb_live **out)
+{
+    if (!e || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    rb_live *lv = new (std::nothrow) rb_live();
+    if (!lv) return rb::fail(RB_ERR_NOMEM, "alloc");
+    lv->engine = e;
+    lv->error_rate = error_rate;
+    lv->significance = significance;
+    lv->max_undecided_len = max_undecided_len;
+    *out = lv;
+    return RB_OK;
+}
+
+void rb_live_destroy(rb_live *lv) { delete lv; }
+
+size_t rb_live_pending(rb_live *lv)
+{
+    if (!lv) return 0;
+    std::lock_guard<std::mutex> lock(lv->mu);
+    return lv->once_seen.size();
+}
+
+int rb_live_forget(rb_live *lv, const char *id, uint32_t id_len)
+{
+    if (!lv || !id) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(lv->mu);
+    lv->once_seen.erase(std::string(id, id_len));
+    return RB_OK;
+}
+
+int rb_live_process(rb_live *lv, const char *ids, const uint64_t *id_offsets, const uint32_t *id_lens, const char *seqs,
+                    const uint64_t *offsets, const uint32_t *lens, size_t n, uint8_t *out_action, uint8_t *out_status,
+                    uint32_t *out_classified_len)
+{
+    if (!lv) return rb::fail(RB_ERR_INVALID_ARG, "null live handle");
+    if (n == 0) return RB_OK;
+    if (!ids || !id_offsets || !id_lens || !seqs || !offsets || !lens || !out_action)
+        return rb::fail(RB_ERR_INVALID_ARG, "null buffer");
+    std::lock_guard<std::mutex> lock(lv->mu);
+    std::vector<Item> todo(n);
+    for (size_t i = 0; i < n; ++i) {
+        todo[i] = Item{i, std::string(ids + id_offsets[i], id_lens[i]), seqs + offsets[i], lens[i]};
+        out_action[i] = 0;
+        if (out_status) out_status[i] = RB_OK;
+        if (out_classified_len) out_classified_len[i] = lens[i];
+    }
+    // A read id may occur more than once in a micro-batch (two chunks of one read).  The reference handles them
+    // one after the other through once_seen; rounds keep that order: each round takes the first pending chunk of every id.
+    while (!todo.empty()) {
+        std::vector<Item> round, later;
+        {
+            std::unordered_map<std::string, int> taken;
+            for (Item &it : todo) {
+                if (taken.emplace(it.id, 1).second) round.push_back(std::move(it));
+                else later.push_back(std::move(it));
+            }
+        }
+        // pass 1: the new chunk on its own
+        std::vector<const char *> ptrs;
+        std::vector<uint32_t> ls;
+        for (const Item &it : round) { ptrs.push_back(it.seq); ls.push_back(it.len); }
+        std::vector<uint8_t> dec, st;
+        int rc = classify_strings(lv, ptrs, ls, dec, st);
+        if (rc != RB_OK) return rc;
+        // pass 2: undecided chunks of reads seen before, concatenated with what is stored
+        std::vector<size_t> again;
+        std::vector<std::string> concat;
+        for (size_t j = 0; j < round.size(); ++j) {
+            const Item &it = round[j];
+            if (st[j] != RB_OK) {  // exception path: nothing is pushed, nothing is stored
+                if (out_status) out_status[it.index] = st[j];
+                continue;
+            }
+            if (dec[j] == 1) {
+                lv->once_seen.erase(it.id);
+                out_action[it.index] = 1;
+            } else if (dec[j] == 2) {
+                lv->once_seen.erase(it.id);
+                out_action[it.index] = 2;
+            } else {
+                auto f = lv->once_seen.find(it.id);
+                if (f != lv->once_seen.end()) {
+                    again.push_back(j);
+                    concat.push_back(f->second.first + std::string(it.seq, it.len));
+                } else {
+                    lv->once_seen[it.id] = std::make_pair(std::string(it.seq, it.len), (uint8_t)1);
+                }
+            }
+        }
+        if (!again.empty()) {
+            ptrs.clear();
+            ls.clear();
+            for (const std::string &s : concat) { ptrs.push_back(s.data()); ls.push_back((uint32_t)s.size()); }
+            std::vector<uint8_t> dec2, st2;
+            rc = classify_strings(lv, ptrs, ls, dec2, st2);
+            if (rc != RB_OK) return rc;
+            for (size_t a = 0; a < again.size(); ++a) {
+                const Item &it = round[again[a]];
+                if (out_classified_len) out_classified_len[it.index] = (uint32_t)concat[a].size();
+                if (st2[a] != RB_OK) {
+                    if (out_status) out_status[it.index] = st2[a];
+                    continue;
+                }
+                if (dec2[a] == 1 || dec2[a] == 2) {
+                    lv->once_seen.erase(it.id);
+                    out_action[it.index] = dec2[a];
+                } else if (concat[a].size() > lv->max_undecided_len) {
+                    lv->once_seen.erase(it.id);
+                    out_action[it.index] = 2;  // unblock = false -> stop_receiving_data
+                } else {
+                    auto f = lv->once_seen.find(it.id);
+                    const uint8_t step = f != lv->once_seen.end() ? (uint8_t)(f->second.second + 1) : (uint8_t)1;
+                    lv->once_seen[it.id] = std::make_pair(std::move(concat[a]), step);
+                }
+            }
+        }
+        todo.swap(later);
+    }
+    return RB_OK;
+}
+
+}  // extern "C"
