@@ -48,7 +48,7 @@ def test_live_shim_matches_sequential_reference(nd, nt):
     bug = H.random_dna(rng, 30000)
     filters, views, keep = [], [], []
     for src, n_bins in ((host, 300), (bug, 64)):
-        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * 4001)
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * 120011)  # roomy: few false positives
         d.add_sequence(src, 1000)
         h = d.download()
         keep.append(h)
