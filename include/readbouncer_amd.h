@@ -200,6 +200,10 @@ RB_API int rb_live_forget(rb_live *lv, const char *id, uint32_t id_len);
  * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */
 RB_API int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads);
 
+/* Filters larger than table_bytes are gathered with non-temporal loads (default 512 MiB = 2x the Infinity
+ * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
+RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
+
 /* Kernel timing for the roofline figure: when enabled every rb_classify_batch* call brackets its
  * count kernels (K1, all filters) with a hipEvent pair recorded on the launch stream, without
  * synchronising.  rb_engine_kernel_time waits for the recorded pairs, returns their summed elapsed

@@ -30,6 +30,7 @@ struct CountLaunch {
     uint32_t col_begin, col_end;  // word columns of every block this launch covers
     uint32_t n_slices;            // column slices of 2^lg * wpl words
     int lg, wpl, planes;
+    int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
     int split_waves;              // >= 2: latency form, one workgroup of split_waves waves per read
     uint16_t *out;
     uint32_t out_read_stride, out_slice_stride;

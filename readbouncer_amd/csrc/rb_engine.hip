@@ -67,6 +67,7 @@ struct rb_engine {
     bool timing = false;
     std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
+    uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     // threshold tables
     DevBuf d_thr;
@@ -364,6 +365,14 @@ int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads)
     return RB_OK;
 }
 
+int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->nt_threshold_bytes = table_bytes;
+    return RB_OK;
+}
+
 int rb_engine_set_timing(rb_engine *e, int enabled)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -489,6 +498,7 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         const uint32_t Weff = a.col_end - a.col_begin;
         const uint32_t kmers = max_len >= f->geo.kmer_size ? max_len - (uint32_t)f->geo.kmer_size + 1 : 0;
         a.planes = kmers <= 1023 ? 10 : 16;
+        a.nt = f->geo.n_words * 8 > e->nt_threshold_bytes;
         if (Weff == 0) {
             // this rank holds no column of this filter: its partial maxima are 0
             RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, st));

@@ -87,7 +87,11 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     eng.set_split_threshold(0)  # same batch through the throughput form (one wave per read)
     mc2, _, dec2, st2 = eng.classify(buf, offs, lens)
     assert np.array_equal(mc2[:, 0], expect) and np.array_equal(dec2, decision) and np.array_equal(st2, status)
+    eng.set_nt_threshold(0)  # non-temporal gathers, both forms
+    assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], expect)
     eng.set_split_threshold(2048)
+    assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], expect)
+    eng.set_nt_threshold(512 << 20)
     # deplete-only decision + status against the oracle's check_unblock
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
     assert np.array_equal(decision, exp_dec)
