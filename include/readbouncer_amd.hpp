@@ -278,12 +278,29 @@ struct BatchResult
     std::vector<uint8_t> status;
 };
 
-inline BatchResult classify_batch(const std::vector<IBFMeta>& DepletionFilters, const std::vector<IBFMeta>& TargetFilters,
-                                  const ClassifyConfig& conf, const std::vector<std::string>& seqs, int mode)
+// flat form: read i = seqs[offsets[i] .. offsets[i]+lens[i])
+inline BatchResult classify_batch_flat(const std::vector<IBFMeta>& DepletionFilters, const std::vector<IBFMeta>& TargetFilters,
+                                       const ClassifyConfig& conf, const char* seqs, const uint64_t* offsets,
+                                       const uint32_t* lens, size_t n, int mode)
 {
     if (DepletionFilters.empty() && TargetFilters.empty()) throw NullFilterException("No IBF provided to classify the read!");
     rb_engine* e = detail::engine_for(DepletionFilters, TargetFilters);
-    const size_t n = seqs.size(), nf = DepletionFilters.size() + TargetFilters.size();
+    const size_t nf = DepletionFilters.size() + TargetFilters.size();
+    BatchResult r;
+    r.maxcount.resize(n * nf);
+    r.best_target.resize(n);
+    r.decision.resize(n);
+    r.status.resize(n);
+    throw_status(rb_classify_batch(e, seqs, offsets, lens, n, conf.error_rate, conf.significance, mode, r.maxcount.data(),
+                                   r.best_target.data(), r.decision.data(), r.status.data()),
+                 "classify_batch");
+    return r;
+}
+
+inline BatchResult classify_batch(const std::vector<IBFMeta>& DepletionFilters, const std::vector<IBFMeta>& TargetFilters,
+                                  const ClassifyConfig& conf, const std::vector<std::string>& seqs, int mode)
+{
+    const size_t n = seqs.size();
     std::string flat;
     std::vector<uint64_t> offs(n);
     std::vector<uint32_t> lens(n);
@@ -296,15 +313,7 @@ inline BatchResult classify_batch(const std::vector<IBFMeta>& DepletionFilters, 
         flat += seqs[i];
     }
     if (flat.empty()) flat.push_back('N');
-    BatchResult r;
-    r.maxcount.resize(n * nf);
-    r.best_target.resize(n);
-    r.decision.resize(n);
-    r.status.resize(n);
-    throw_status(rb_classify_batch(e, flat.data(), offs.data(), lens.data(), n, conf.error_rate, conf.significance, mode,
-                                   r.maxcount.data(), r.best_target.data(), r.decision.data(), r.status.data()),
-                 "classify_batch");
-    return r;
+    return classify_batch_flat(DepletionFilters, TargetFilters, conf, flat.data(), offs.data(), lens.data(), n, mode);
 }
 
 // ---- Read (src/IBF/IBF.hpp:169-226) -------------------------------------------------------------

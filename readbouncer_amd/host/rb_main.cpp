@@ -5,6 +5,11 @@
 // unclassified go on to chunk i+1 -- per read this is the reference's loop (classify.hpp:262-299).
 // usage = "target" (live MinKNOW sampling) and "test" (connection test) are out of scope.
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -87,14 +92,21 @@ static std::vector<interleave::IBFMeta> getIBF(ConfigReader config, bool deplete
     return out;
 }
 
-struct PendingRead
+struct ReadState
 {
-    std::string id, seq;
     bool classified = false, failed = false;
     int best = -1;
 };
 
-// classify_reads, src/main/classify.hpp:142-380
+// one parsed batch travelling from the reader thread to the classifying thread
+struct ParsedBatch
+{
+    seqio::Batch batch;
+    uint64_t n_records = 0;
+};
+
+// classify_reads, src/main/classify.hpp:142-380.  A reader thread parses batch i+1 from the memory-mapped read
+// file while the GPU works on batch i.
 static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta> DepletionFilters,
                            std::vector<interleave::IBFMeta> TargetFilters, size_t batch_reads)
 {
@@ -112,22 +124,28 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         uint16_t failed = 0;
         double classify_seconds = 0.0;
         uint64_t classify_reads_n = 0;
+        const auto wall0 = std::chrono::steady_clock::now();
 
         std::vector<std::ofstream> targetFastas{};
-        for (interleave::IBFMeta& f : TargetFilters) {
+        std::vector<std::vector<char>> outbufs(TargetFilters.size() + 1, std::vector<char>(1 << 20));
+        for (size_t i = 0; i < TargetFilters.size(); ++i) {
             std::filesystem::path outfile(config.output_dir);
-            outfile /= f.name + ".fasta";
-            targetFastas.emplace_back(outfile, std::ios::out);
+            outfile /= TargetFilters[i].name + ".fasta";
+            targetFastas.emplace_back();
+            targetFastas.back().rdbuf()->pubsetbuf(outbufs[i].data(), (std::streamsize)outbufs[i].size());
+            targetFastas.back().open(outfile, std::ios::out);
         }
         std::filesystem::path outfile(config.output_dir);
         outfile /= "unclassified.fasta";
-        std::ofstream UnclassifiedOut(outfile, std::ios::out);
+        std::ofstream UnclassifiedOut;
+        UnclassifiedOut.rdbuf()->pubsetbuf(outbufs.back().data(), (std::streamsize)outbufs.back().size());
+        UnclassifiedOut.open(outfile, std::ios::out);
         if (!UnclassifiedOut.is_open()) {
             std::cerr << "ERROR: Unable to open the file: " << outfile.string() << std::endl;
             return;
         }
-        seqio::Reader seqFileIn(read_file.string());
-        if (!seqFileIn.is_open()) {
+        seqio::MappedFile mapped(read_file.string());
+        if (!mapped.is_open()) {
             std::cerr << "ERROR: Unable to open the file: " << read_file.string() << std::endl;
             return;
         }
@@ -135,47 +153,84 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
 
         const uint32_t chunk_length = (uint32_t)config.IBF_Parsed.chunk_length;
         const uint32_t max_chunks = (uint8_t)config.IBF_Parsed.max_chunks;  // "uint8_t i" in the reference
-        bool eof = false;
-        while (!eof) {
-            std::vector<PendingRead> batch;
-            while (batch.size() < batch_reads) {
-                PendingRead r;
-                try {
-                    if (!seqFileIn.read_record(r.id, r.seq)) { eof = true; break; }
-                    readCounter++;
-                } catch (const std::exception& e) {
-                    std::cerr << "ERROR: " << e.what() << " [@" << r.id << "]" << std::endl;
-                    eof = true;
-                    break;
+
+        // ---- reader thread: two batches in flight
+        std::mutex mu;
+        std::condition_variable cv_full, cv_free;
+        std::deque<std::unique_ptr<ParsedBatch>> ready;
+        bool reader_done = false;
+        std::thread reader([&] {
+            seqio::Parser parser(mapped.data(), mapped.size());
+            for (;;) {
+                std::unique_ptr<ParsedBatch> pb(new ParsedBatch());
+                parser.next_batch(pb->batch, batch_reads);
+                const bool last = pb->batch.eof;
+                {
+                    std::unique_lock<std::mutex> lock(mu);
+                    cv_free.wait(lock, [&] { return ready.size() < 2; });
+                    ready.push_back(std::move(pb));
                 }
-                if (r.seq.size() < chunk_length) { too_short++; continue; }  // classify.hpp:247-250
-                batch.push_back(std::move(r));
+                cv_full.notify_one();
+                if (last) break;
             }
-            if (batch.empty()) continue;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                reader_done = true;
+            }
+            cv_full.notify_one();
+        });
+
+        std::vector<char> flat;
+        std::vector<uint64_t> offs;
+        std::vector<uint32_t> lens;
+        for (;;) {
+            std::unique_ptr<ParsedBatch> pb;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_full.wait(lock, [&] { return !ready.empty() || reader_done; });
+                if (ready.empty()) break;
+                pb = std::move(ready.front());
+                ready.pop_front();
+            }
+            cv_free.notify_one();
+            const std::vector<seqio::Record>& recs = pb->batch.records;
+            readCounter += recs.size();
+            if (!pb->batch.error.empty()) std::cerr << "ERROR: " << pb->batch.error << std::endl;
+            std::vector<ReadState> state(recs.size());
+            std::vector<size_t> active;
+            for (size_t i = 0; i < recs.size(); ++i) {
+                if (recs[i].seq_len < chunk_length) too_short++;  // classify.hpp:247-250
+                else active.push_back(i);
+            }
+            const size_t n_candidates = active.size();
             const auto t0 = std::chrono::steady_clock::now();
-            std::vector<size_t> active(batch.size());
-            for (size_t i = 0; i < batch.size(); ++i) active[i] = i;
             for (uint32_t c = 0; c < max_chunks && !active.empty(); ++c) {
-                std::vector<std::string> frags;
+                flat.clear();
+                offs.clear();
+                lens.clear();
                 std::vector<size_t> idx;
                 for (size_t i : active) {
-                    PendingRead& r = batch[i];
+                    const seqio::Record& r = recs[i];
                     uint64_t fragend = (uint64_t)(c + 1) * chunk_length, fragstart = (uint64_t)c * chunk_length;
-                    if (fragend > r.seq.size()) fragend = r.seq.size();
-                    if (fragstart > fragend) { r.failed = true; continue; }  // undefined infix in the reference
-                    frags.push_back(r.seq.substr(fragstart, fragend - fragstart));
+                    if (fragend > r.seq_len) fragend = r.seq_len;
+                    if (fragstart > fragend) { state[i].failed = true; continue; }  // undefined infix in the reference
+                    offs.push_back(flat.size());
+                    lens.push_back((uint32_t)(fragend - fragstart));
+                    flat.insert(flat.end(), r.seq + fragstart, r.seq + fragend);
                     idx.push_back(i);
                 }
                 std::vector<size_t> next;
-                if (!frags.empty()) {
-                    interleave::BatchResult res =
-                        interleave::classify_batch(DepletionFilters, TargetFilters, Conf, frags, RB_MODE_CLASSIFY_CHUNK);
+                if (!idx.empty()) {
+                    if (flat.empty()) flat.push_back('N');
+                    interleave::BatchResult res = interleave::classify_batch_flat(
+                        DepletionFilters, TargetFilters, Conf, flat.data(), offs.data(), lens.data(), idx.size(),
+                        RB_MODE_CLASSIFY_CHUNK);
                     for (size_t j = 0; j < idx.size(); ++j) {
-                        PendingRead& r = batch[idx[j]];
-                        if (res.status[j] != RB_OK) { r.failed = true; continue; }  // exception -> failed++ (:306-316)
+                        ReadState& st = state[idx[j]];
+                        if (res.status[j] != RB_OK) { st.failed = true; continue; }  // exception -> failed++ (:306-316)
                         if (res.decision[j]) {
-                            r.classified = true;
-                            r.best = target ? res.best_target[j] : -1;
+                            st.classified = true;
+                            st.best = target ? res.best_target[j] : -1;
                         } else {
                             next.push_back(idx[j]);
                         }
@@ -184,22 +239,26 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                 active.swap(next);
             }
             classify_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            classify_reads_n += batch.size();
-            for (PendingRead& r : batch) {  // outputs in read order
-                if (r.failed) { failed++; continue; }
-                if (r.classified) {
+            classify_reads_n += n_candidates;
+            for (size_t i = 0; i < recs.size(); ++i) {  // outputs in read order
+                const seqio::Record& r = recs[i];
+                if (r.seq_len < chunk_length) continue;
+                if (state[i].failed) { failed++; continue; }
+                if (state[i].classified) {
                     found++;
-                    if (target && r.best >= 0) {
-                        TargetFilters[r.best].classified += 1;
-                        seqio::write_fasta(targetFastas[r.best], r.id, r.seq);
+                    if (target && state[i].best >= 0) {
+                        TargetFilters[state[i].best].classified += 1;
+                        seqio::write_fasta(targetFastas[state[i].best], r.id, r.id_len, r.seq, r.seq_len);
                     }
                 } else {
-                    seqio::write_fasta(UnclassifiedOut, r.id, r.seq);
+                    seqio::write_fasta(UnclassifiedOut, r.id, r.id_len, r.seq, r.seq_len);
                 }
             }
         }
+        reader.join();
         for (auto& f : targetFastas) f.close();
         UnclassifiedOut.close();
+        const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
         const double avg = classify_reads_n ? classify_seconds / (double)classify_reads_n : 0.0;
         std::cout << "------------------------------- Final Results -------------------------------" << std::endl;
         std::cout << "Number of classified reads                         :   " << found << std::endl;
@@ -211,6 +270,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         std::cout << "-----------------------------------------------------------------------------------" << std::endl;
         std::cout << "RESULT found=" << found << " failed=" << failed << " too_short=" << too_short
                   << " readCounter=" << readCounter << std::endl;
+        std::cout << "THROUGHPUT reads_per_s=" << (wall > 0 ? (double)readCounter / wall : 0.0) << " wall_s=" << wall
+                  << " classify_s=" << classify_seconds << std::endl;
         ClassificationResults_.found = found;
         ClassificationResults_.failed = failed;
         ClassificationResults_.too_short = too_short;
@@ -252,6 +313,28 @@ int main(int argc, char const* argv[])
         if ((!std::strcmp(argv[i], "--config") || !std::strcmp(argv[i], "-c")) && i + 1 < argc) config_path = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-config")) dump_only = true;
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) batch_reads = (size_t)std::stoull(argv[++i]);
+        else if (!std::strcmp(argv[i], "--parse-stats") && i + 1 < argc) {
+            // ingest self-check (no GPU): records, bases and an FNV-1a digest over "id\tseq\n" of every record
+            seqio::MappedFile mf(argv[++i]);
+            if (!mf.is_open()) { std::cerr << "ERROR: Unable to open the file: " << argv[i] << std::endl; return 1; }
+            seqio::Parser parser(mf.data(), mf.size());
+            seqio::Batch b;
+            uint64_t n = 0, bases = 0, h = 1469598103934665603ull;
+            auto mix = [&](const char* d, size_t len) { for (size_t k = 0; k < len; ++k) { h ^= (unsigned char)d[k]; h *= 1099511628211ull; } };
+            const auto t0 = std::chrono::steady_clock::now();
+            do {
+                parser.next_batch(b, batch_reads);
+                for (const seqio::Record& r : b.records) {
+                    ++n; bases += r.seq_len;
+                    mix(r.id, r.id_len); mix("\t", 1); mix(r.seq, r.seq_len); mix("\n", 1);
+                }
+                if (!b.error.empty()) { std::cerr << "ERROR: " << b.error << std::endl; return 1; }
+            } while (!b.eof);
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cout << "records=" << n << " bases=" << bases << " fnv=" << h << " seconds=" << secs
+                      << " MB_per_s=" << (secs > 0 ? mf.size() / 1e6 / secs : 0.0) << std::endl;
+            return 0;
+        }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
             std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N]" << std::endl;
             return 0;

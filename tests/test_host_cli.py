@@ -96,6 +96,36 @@ def test_defaults_and_errors(tmp_path):
     assert p.returncode == 1
 
 
+def _fnv(recs):
+    h = 1469598103934665603
+    for rid, seq in recs:
+        for ch in (rid + "\t" + seq + "\n").encode():
+            h = ((h ^ ch) * 1099511628211) & (2**64 - 1)
+    return h
+
+
+def test_ingest_parser_matches_python_reader(tmp_path, refdata):
+    cases = [(os.path.join(refdata, "classifyTests_test.fastq"), H.read_fastq),   # CRLF FASTQ
+             (os.path.join(refdata, "libIBFTests_test1.fasta"), H.read_fasta),    # multi-line FASTA, blank line
+             (os.path.join(refdata, "testQueries.fasta"), H.read_fasta)]
+    weird = tmp_path / "w.fasta"
+    weird.write_bytes(b"\n\n>a desc\r\nACGT\r\nAC\r\n\r\nGT\n>b\n>c\nNNNN\n>d\nAC")  # empty record, no final newline
+    cases.append((str(weird), H.read_fasta))
+    mixed = tmp_path / "m.fq"
+    mixed.write_bytes(b"@r1 x\nACGTN\n+\n!!!!!\n@r2\nAC\n+r2\n@@\n")  # quality line starting with '@'
+    cases.append((str(mixed), H.read_fastq))
+    for path, reader in cases:
+        recs = reader(path)
+        out = run_cli("--parse-stats", path).stdout.split()
+        kv = dict(x.split("=") for x in out)
+        assert int(kv["records"]) == len(recs), path
+        assert int(kv["bases"]) == sum(len(s) for _, s in recs), path
+        assert int(kv["fnv"]) == _fnv(recs), path
+    bad = tmp_path / "bad.fq"
+    bad.write_bytes(b"@r1\nACGT\nIIII\n")
+    assert run_cli("--parse-stats", str(bad), check=False).returncode == 1
+
+
 def synth_genome(seed, n, plant=None, at=0):
     rng = np.random.default_rng(seed)
     g = H.random_dna(rng, n)
