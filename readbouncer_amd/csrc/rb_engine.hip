@@ -56,6 +56,30 @@ struct DevBuf {
     }
 };
 
+// growable pinned host buffer (staging of micro-batches)
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return RB_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = std::max(bytes, (size_t)65536);
+        want = want + want / 2;
+        RB_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return RB_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
 struct rb_engine {
     int device = 0;
     std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
@@ -77,6 +101,7 @@ struct rb_engine {
     DevBuf d_part, d_maxcount;
     // staging for the host-pointer API
     DevBuf d_seqs, d_offsets, d_lens, d_best, d_decision, d_status;
+    PinnedBuf h_in, h_out;
     std::mutex mu;
 };
 
@@ -346,6 +371,8 @@ void rb_engine_destroy(rb_engine *e)
     for (DevBuf *b : {&e->d_thr, &e->d_part, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
+    e->h_in.release();
+    e->h_out.release();
     delete e;
 }
 
@@ -567,36 +594,88 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
     if (!seqs || !offsets || !lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
     int rc = check_device(e->device);
     if (rc != RB_OK) return rc;
-    uint64_t total = 0;
+    uint64_t hi = 0, lo = ~0ULL, sum_len = 0;
     uint32_t max_len = 0;
     for (size_t i = 0; i < n_reads; ++i) {
-        total = std::max<uint64_t>(total, offsets[i] + lens[i]);
+        hi = std::max<uint64_t>(hi, offsets[i] + lens[i]);
+        lo = std::min<uint64_t>(lo, offsets[i]);
+        sum_len += lens[i];
         max_len = std::max(max_len, lens[i]);
     }
     const size_t nf = e->filters.size();
+    const size_t n = n_reads;
     hipStream_t st = e->stream;
     std::lock_guard<std::mutex> host_lock(e->host_mu);  // the staging buffers below are per engine
+    const bool sharded = e->shard_world != 1;
+
+    if (sum_len + 16 * n <= ((uint64_t)8 << 20)) {
+        // ---- micro-batch path: one pinned staging block each way -> one H2D and one D2H copy.
+        // in : u64 offsets[n] | u32 lens[n] | compacted read bytes      out: i32 best[n] | u16 maxcount[n*nf] | u8 decision[n] | u8 status[n]
+        const size_t in_bytes = 12 * n + (size_t)sum_len + 1;
+        const size_t out_bytes = 4 * n + 2 * nf * n + 2 * n;
+        {
+            std::lock_guard<std::mutex> lock(e->mu);
+            if ((rc = e->h_in.ensure(in_bytes)) != RB_OK) return rc;
+            if ((rc = e->h_out.ensure(out_bytes)) != RB_OK) return rc;
+            if ((rc = e->d_seqs.ensure(in_bytes)) != RB_OK) return rc;
+            if ((rc = e->d_maxcount.ensure(out_bytes)) != RB_OK) return rc;
+        }
+        uint64_t *ho = (uint64_t *)e->h_in.p;
+        uint32_t *hl = (uint32_t *)(ho + n);
+        char *hs = (char *)(hl + n);
+        uint64_t pos = 0;
+        for (size_t i = 0; i < n; ++i) {
+            ho[i] = pos;
+            hl[i] = lens[i];
+            std::memcpy(hs + pos, seqs + offsets[i], lens[i]);
+            pos += lens[i];
+        }
+        char *din = (char *)e->d_seqs.p;
+        char *dout = (char *)e->d_maxcount.p;
+        RB_HIP(hipMemcpyAsync(din, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+        int32_t *d_best = (int32_t *)dout;
+        uint16_t *d_max = (uint16_t *)(dout + 4 * n);
+        uint8_t *d_dec = (uint8_t *)(dout + 4 * n + 2 * nf * n);
+        uint8_t *d_st = d_dec + n;
+        rc = rb_classify_batch_device(e, din + 12 * n, din, din + 8 * n, n, max_len, error_rate, significance, mode, d_max,
+                                      d_best, d_dec, d_st, (void *)st);
+        if (rc != RB_OK) return rc;
+        RB_HIP(hipMemcpyAsync(e->h_out.p, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        RB_HIP(hipStreamSynchronize(st));
+        const char *hout = (const char *)e->h_out.p;
+        if (out_maxcount) std::memcpy(out_maxcount, hout + 4 * n, 2 * nf * n);
+        if (!sharded) {
+            if (out_best_target) std::memcpy(out_best_target, hout, 4 * n);
+            if (out_decision) std::memcpy(out_decision, hout + 4 * n + 2 * nf * n, n);
+            if (out_status) std::memcpy(out_status, hout + 4 * n + 2 * nf * n + n, n);
+        }
+        return RB_OK;
+    }
+
+    // ---- large batches: copy the spanned byte range as it is (offsets stay valid relative to a shifted base)
+    const uint64_t span = hi - lo;
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        if ((rc = e->d_seqs.ensure(total ? total : 1)) != RB_OK) return rc;
-        if ((rc = e->d_offsets.ensure(n_reads * 8)) != RB_OK) return rc;
-        if ((rc = e->d_lens.ensure(n_reads * 4)) != RB_OK) return rc;
-        if ((rc = e->d_maxcount.ensure(n_reads * nf * 2)) != RB_OK) return rc;
-        if ((rc = e->d_best.ensure(n_reads * 4)) != RB_OK) return rc;
-        if ((rc = e->d_decision.ensure(n_reads)) != RB_OK) return rc;
-        if ((rc = e->d_status.ensure(n_reads)) != RB_OK) return rc;
+        if ((rc = e->d_seqs.ensure(span ? span : 1)) != RB_OK) return rc;
+        if ((rc = e->d_offsets.ensure(n * 8)) != RB_OK) return rc;
+        if ((rc = e->d_lens.ensure(n * 4)) != RB_OK) return rc;
+        if ((rc = e->d_maxcount.ensure(n * nf * 2)) != RB_OK) return rc;
+        if ((rc = e->d_best.ensure(n * 4)) != RB_OK) return rc;
+        if ((rc = e->d_decision.ensure(n)) != RB_OK) return rc;
+        if ((rc = e->d_status.ensure(n)) != RB_OK) return rc;
     }
-    RB_HIP(hipMemcpyAsync(e->d_seqs.p, seqs, total, hipMemcpyHostToDevice, st));
-    RB_HIP(hipMemcpyAsync(e->d_offsets.p, offsets, n_reads * 8, hipMemcpyHostToDevice, st));
-    RB_HIP(hipMemcpyAsync(e->d_lens.p, lens, n_reads * 4, hipMemcpyHostToDevice, st));
-    rc = rb_classify_batch_device(e, e->d_seqs.p, e->d_offsets.p, e->d_lens.p, n_reads, max_len, error_rate, significance,
-                                  mode, e->d_maxcount.p, e->d_best.p, e->d_decision.p, e->d_status.p, (void *)st);
+    RB_HIP(hipMemcpyAsync(e->d_seqs.p, seqs + lo, span, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(e->d_offsets.p, offsets, n * 8, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(e->d_lens.p, lens, n * 4, hipMemcpyHostToDevice, st));
+    const char *d_base = (const char *)e->d_seqs.p - lo;  // device address of the caller's seqs[0]
+    rc = rb_classify_batch_device(e, d_base, e->d_offsets.p, e->d_lens.p, n, max_len, error_rate, significance, mode,
+                                  e->d_maxcount.p, e->d_best.p, e->d_decision.p, e->d_status.p, (void *)st);
     if (rc != RB_OK) return rc;
-    if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, e->d_maxcount.p, n_reads * nf * 2, hipMemcpyDeviceToHost, st));
-    if (e->shard_world == 1) {
-        if (out_best_target) RB_HIP(hipMemcpyAsync(out_best_target, e->d_best.p, n_reads * 4, hipMemcpyDeviceToHost, st));
-        if (out_decision) RB_HIP(hipMemcpyAsync(out_decision, e->d_decision.p, n_reads, hipMemcpyDeviceToHost, st));
-        if (out_status) RB_HIP(hipMemcpyAsync(out_status, e->d_status.p, n_reads, hipMemcpyDeviceToHost, st));
+    if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, e->d_maxcount.p, n * nf * 2, hipMemcpyDeviceToHost, st));
+    if (!sharded) {
+        if (out_best_target) RB_HIP(hipMemcpyAsync(out_best_target, e->d_best.p, n * 4, hipMemcpyDeviceToHost, st));
+        if (out_decision) RB_HIP(hipMemcpyAsync(out_decision, e->d_decision.p, n, hipMemcpyDeviceToHost, st));
+        if (out_status) RB_HIP(hipMemcpyAsync(out_status, e->d_status.p, n, hipMemcpyDeviceToHost, st));
     }
     RB_HIP(hipStreamSynchronize(st));
     return RB_OK;

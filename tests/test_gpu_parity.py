@@ -297,3 +297,51 @@ def test_empty_batch_and_null_filters():
     with pytest.raises(capi.RBError) as ei:
         capi.Engine(0, [], [])
     assert ei.value.status == capi.RB_ERR_NULL_FILTER
+
+
+def test_host_api_micro_and_large_paths():
+    """rb_classify_batch: the pinned micro-batch path (compaction of arbitrary, even overlapping, offsets) and the
+    large-batch path (spanned range copied as is, base shifted by the lowest offset)."""
+    rng = np.random.default_rng(21)
+    d = capi.DeviceIBF.create(0, 60, 3, 13, 64 * 300007)
+    ref = H.random_dna(rng, 50000)
+    d.add_sequence(ref, 1000)
+    o, _k = oracle_view(d)
+    eng = capi.Engine(0, [d], [])
+    pool = np.frombuffer((H.random_dna(rng, 1000) + ref + H.random_dna(rng, 50000)).encode(), dtype=np.uint8).copy()
+    # micro: shuffled, overlapping windows, first byte used is far from 0
+    n = 500
+    offs = rng.integers(900, len(pool) - 400, size=n).astype(np.uint64)
+    lens = rng.integers(0, 400, size=n).astype(np.uint32)
+    mc, _, dec, st = eng.classify(pool, offs, lens)
+    assert np.array_equal(mc[:, 0], po.batch_raw_max(o, pool, offs, lens, 4))
+    edec, est = po.batch_check_unblock([o], [], pool, offs, lens, n_threads=4)
+    assert np.array_equal(dec, edec) and np.array_equal(st, est)
+    # large: > 8 MB of read bytes
+    n = 32000
+    offs = rng.integers(1000, len(pool) - 300, size=n).astype(np.uint64)
+    lens = np.full(n, 300, dtype=np.uint32)
+    mc, _, dec, st = eng.classify(pool, offs, lens)
+    assert np.array_equal(mc[:, 0], po.batch_raw_max(o, pool, offs, lens, 8))
+    edec, est = po.batch_check_unblock([o], [], pool, offs, lens, n_threads=8)
+    assert np.array_equal(dec, edec) and np.array_equal(st, est)
+    assert 0 < dec.sum() < n
+
+
+def test_more_ranks_than_columns():
+    # bin-sharded layout with a one-word filter on two ranks: the second rank owns no column -> zero partials
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(4)
+    d = capi.DeviceIBF.create(0, 50, 3, 13, 64 * 50021)
+    ref = H.random_dna(rng, 5000)
+    d.add_sequence(ref, 100)
+    o, _k = oracle_view(d)
+    reads = make_reads(rng, ref, 64, lo=100, hi=300)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [])
+    expect = po.batch_raw_max(o, buf, offs, lens, 2)
+    eng.set_column_shard(0, 2)
+    p0 = eng.classify(buf, offs, lens)[0][:, 0]
+    eng.set_column_shard(1, 2)
+    p1 = eng.classify(buf, offs, lens)[0][:, 0]
+    assert np.array_equal(p0, expect) and not p1.any()
