@@ -345,3 +345,23 @@ def test_more_ranks_than_columns():
     eng.set_column_shard(1, 2)
     p1 = eng.classify(buf, offs, lens)[0][:, 0]
     assert np.array_equal(p0, expect) and not p1.any()
+
+
+def test_uint16_wraparound_semantics():
+    """Reads with more than 65535 k-mers: the reference's uint16_t counters and its uint16_t readlen both wrap
+    (IBFClassify.cpp:149-159); the 16-plane bit-sliced counters and the threshold table wrap identically."""
+    rng = np.random.default_rng(31)
+    d = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 1000003)
+    unit = H.random_dna(rng, 997)
+    d.add_sequence(unit * 3, 100000)
+    o, _k = oracle_view(d)
+    reads = [unit * 70, unit * 66 + "ACGT", H.random_dna(rng, 66000), (unit * 67)[:65535 + 12], (unit * 67)[:65536 + 12]]
+    buf, offs, lens = H.pack_reads(reads)
+    assert lens.max() > 65535
+    eng = capi.Engine(0, [d], [])
+    for thr in (2048, 0):
+        eng.set_split_threshold(thr)
+        mc, _, dec, st = eng.classify(buf, offs, lens)
+        assert np.array_equal(mc[:, 0], po.batch_raw_max(o, buf, offs, lens, 4))
+        edec, est = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
+        assert np.array_equal(dec, edec) and np.array_equal(st, est)
