@@ -175,6 +175,22 @@ RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_
                             uint32_t max_len, double error_rate, double significance, int mode,
                             void *d_best_target, void *d_decision, void *d_status, void *stream);
 
+/* ---- single-process multi-GPU pool -----------------------------------------------------------
+ * One engine + one host thread per entry of devices[] (an entry may repeat), every filter replicated into each
+ * device's HBM from its host image, batches cut into contiguous slices of ceil(n/parts) reads, no collective
+ * (SURVEY 8e).  Batches with fewer than min_split reads per device are not split: they go to one device,
+ * round-robin.  Outputs as rb_classify_batch. */
+typedef struct rb_pool rb_pool;
+RB_API int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *deplete, size_t n_deplete,
+                          const rb_ibf *const *target, size_t n_target, rb_pool **out);
+RB_API void rb_pool_destroy(rb_pool *p);
+RB_API size_t rb_pool_size(const rb_pool *p);
+RB_API int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device);
+RB_API int rb_pool_classify_batch(rb_pool *p, const char *seqs, const uint64_t *offsets, const uint32_t *lens,
+                                  size_t n_reads, double error_rate, double significance, int mode,
+                                  uint16_t *out_maxcount, int32_t *out_best_target, uint8_t *out_decision,
+                                  uint8_t *out_status);
+
 /* ---- live micro-batch shim ----------------------------------------------------------------
  * Batch form of classify_live_reads (src/main/adaptive_sampling.hpp:214-356), the step between the reference's
  * classification_queue and action_queue: keeps the once_seen map, concatenates undecided chunks of a read,

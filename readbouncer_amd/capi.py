@@ -67,6 +67,11 @@ SIGNATURES = {
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_pool_create": (_int, [C.POINTER(_int), _sz, _pp, _sz, _pp, _sz, _pp]),
+    "rb_pool_destroy": (None, [_vp]),
+    "rb_pool_size": (_sz, [_vp]),
+    "rb_pool_set_min_split": (_int, [_vp, _sz]),
+    "rb_pool_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_live_create": (_int, [_vp, _dbl, _dbl, _u32, _pp]),
     "rb_live_destroy": (None, [_vp]),
     "rb_live_process": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
@@ -309,6 +314,51 @@ class Engine:
     def destroy(self):
         if self.h:
             lib().rb_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Pool:
+    """rb_pool: one engine per device entry, filters replicated from host images, read-sharded batches."""
+
+    def __init__(self, devices, deplete_images, target_images):
+        self.nd, self.nt = len(deplete_images), len(target_images)
+        self._keep = (list(deplete_images), list(target_images))
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _check(lib().rb_pool_create(devs, len(devices), _handle_array(deplete_images), self.nd,
+                                    _handle_array(target_images), self.nt, C.byref(h)), "rb_pool_create")
+        self.h = h
+
+    def size(self):
+        return lib().rb_pool_size(self.h)
+
+    def set_min_split(self, reads_per_device):
+        _check(lib().rb_pool_set_min_split(self.h, reads_per_device), "rb_pool_set_min_split")
+
+    def classify(self, seqs, offsets, lens, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
+        n = len(lens)
+        nf = self.nd + self.nt
+        maxcount = np.zeros((n, nf), dtype=np.uint16)
+        best = np.full(n, -1, dtype=np.int32)
+        decision = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint8)
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        _check(lib().rb_pool_classify_batch(self.h, _ptr(seqs), _ptr(offsets), _ptr(lens), n, error_rate, significance,
+                                            mode, _ptr(maxcount), _ptr(best), _ptr(decision), _ptr(status)),
+               "rb_pool_classify_batch")
+        return maxcount, best, decision, status
+
+    def destroy(self):
+        if self.h:
+            lib().rb_pool_destroy(self.h)
             self.h = None
 
     def __del__(self):

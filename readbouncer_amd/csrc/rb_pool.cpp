@@ -1,0 +1,173 @@
+// rb_pool.cpp -- single-process multi-GPU form of the classifier: one engine and one host thread per
+// device, every filter replicated in each device's HBM, batches cut into contiguous read slices, no collective.
+// The reference's scaling model is N classify threads popping one queue (src/main/adaptive_sampling.hpp:745-751);
+// here the N workers are GPUs.  Micro-batches are not split (latency): they go to one device, round-robin.
+#include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "rb_internal.h"
+
+namespace {
+
+struct Worker {
+    int device = 0;
+    std::vector<rb_dibf *> filters;  // owned replicas, deplete first
+    rb_engine *engine = nullptr;
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> task;
+    bool has_task = false, done = false, stop = false;
+    int result = RB_OK;
+    std::string error;
+
+    void loop()
+    {
+        for (;;) {
+            std::function<int()> t;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return has_task || stop; });
+                if (stop) return;
+                t = task;
+            }
+            const int rc = t();
+            const std::string err = rc == RB_OK ? std::string() : std::string(rb_last_error());
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                result = rc;
+                error = err;
+                has_task = false;
+                done = true;
+            }
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int()> t)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            task = std::move(t);
+            has_task = true;
+            done = false;
+        }
+        cv.notify_all();
+    }
+    int wait()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return done; });
+        return result;
+    }
+};
+
+}  // namespace
+
+struct rb_pool {
+    std::vector<Worker *> workers;
+    size_t nd = 0, nt = 0;
+    size_t next = 0;              // round-robin cursor for unsplit micro-batches
+    size_t min_split_reads = 4096;  // per-device slice below which splitting does not pay
+    std::mutex mu;
+};
+
+extern "C" {
+
+void rb_pool_destroy(rb_pool *p)
+{
+    if (!p) return;
+    for (Worker *w : p->workers) {
+        if (w->thread.joinable()) {
+            {
+                std::lock_guard<std::mutex> lock(w->mu);
+                w->stop = true;
+            }
+            w->cv.notify_all();
+            w->thread.join();
+        }
+        if (w->engine) rb_engine_destroy(w->engine);
+        for (rb_dibf *f : w->filters) rb_dibf_free(f);
+        delete w;
+    }
+    delete p;
+}
+
+int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *deplete, size_t n_deplete,
+                   const rb_ibf *const *target, size_t n_target, rb_pool **out)
+{
+    if (!out || !devices || n_devices == 0) return rb::fail(RB_ERR_INVALID_ARG, "no devices");
+    if (n_deplete + n_target == 0) return rb::fail(RB_ERR_NULL_FILTER, "No IBF provided to classify the read!");
+    rb_pool *p = new (std::nothrow) rb_pool();
+    if (!p) return rb::fail(RB_ERR_NOMEM, "alloc");
+    p->nd = n_deplete;
+    p->nt = n_target;
+    for (size_t d = 0; d < n_devices; ++d) {
+        Worker *w = new (std::nothrow) Worker();
+        if (!w) { rb_pool_destroy(p); return rb::fail(RB_ERR_NOMEM, "alloc"); }
+        p->workers.push_back(w);
+        w->device = devices[d];
+        for (size_t i = 0; i < n_deplete + n_target; ++i) {
+            const rb_ibf *img = i < n_deplete ? deplete[i] : target[i - n_deplete];
+            rb_dibf *f = nullptr;
+            const int rc = img ? rb_dibf_upload(w->device, img, &f) : rb::fail(RB_ERR_INVALID_ARG, "null filter image");
+            if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+            w->filters.push_back(f);
+        }
+        const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target,
+                                        &w->engine);
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+        w->thread = std::thread([w] { w->loop(); });
+    }
+    *out = p;
+    return RB_OK;
+}
+
+size_t rb_pool_size(const rb_pool *p) { return p ? p->workers.size() : 0; }
+
+int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device)
+{
+    if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    p->min_split_reads = reads_per_device ? reads_per_device : 1;
+    return RB_OK;
+}
+
+int rb_pool_classify_batch(rb_pool *p, const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n_reads,
+                           double error_rate, double significance, int mode, uint16_t *out_maxcount,
+                           int32_t *out_best_target, uint8_t *out_decision, uint8_t *out_status)
+{
+    if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    if (n_reads == 0) return RB_OK;
+    std::lock_guard<std::mutex> lock(p->mu);
+    const size_t nf = p->nd + p->nt;
+    size_t parts = std::min(p->workers.size(), std::max<size_t>(1, n_reads / p->min_split_reads));
+    const size_t per = (n_reads + parts - 1) / parts;  // contiguous slices of ceil(n/parts) reads
+    std::vector<Worker *> used;
+    for (size_t k = 0; k < parts; ++k) {
+        const size_t b = std::min(n_reads, k * per), e = std::min(n_reads, b + per);
+        if (b == e) continue;
+        Worker *w = p->workers[(p->next + k) % p->workers.size()];
+        used.push_back(w);
+        w->submit([=] {
+            return rb_classify_batch(w->engine, seqs, offsets + b, lens + b, e - b, error_rate, significance, mode,
+                                     out_maxcount ? out_maxcount + b * nf : nullptr,
+                                     out_best_target ? out_best_target + b : nullptr,
+                                     out_decision ? out_decision + b : nullptr, out_status ? out_status + b : nullptr);
+        });
+    }
+    p->next = (p->next + (parts == 1 ? 1 : 0)) % p->workers.size();
+    int rc = RB_OK;
+    std::string err;
+    for (Worker *w : used) {
+        const int r = w->wait();
+        if (r != RB_OK && rc == RB_OK) { rc = r; err = w->error; }
+    }
+    if (rc != RB_OK) return rb::fail(rc, err);
+    return RB_OK;
+}
+
+}  // extern "C"

@@ -365,3 +365,30 @@ def test_uint16_wraparound_semantics():
         assert np.array_equal(mc[:, 0], po.batch_raw_max(o, buf, offs, lens, 4))
         edec, est = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
         assert np.array_equal(dec, edec) and np.array_equal(st, est)
+
+
+def test_pool_shards_reads_across_engines():
+    """rb_pool: single-process multi-GPU form.  On a one-GPU box the device list repeats device 0, which still
+    exercises replication, contiguous slicing, the worker threads and the merge of outputs."""
+    rng = np.random.default_rng(77)
+    ref = H.random_dna(rng, 40000)
+    images, views = [], []
+    for n_bins, lo in ((300, 0), (64, 20000)):
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * 100003)
+        d.add_sequence(ref[lo:lo + 20000], 1000)
+        h = d.download()
+        images.append(h)
+        views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+    reads = make_reads(rng, ref, 3001, lo=5, hi=420)
+    buf, offs, lens = H.pack_reads(reads)
+    exp_dec, exp_st = po.batch_check_unblock(views[:1], views[1:], buf, offs, lens, n_threads=8)
+    exp_max = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    for devices in ([0], [0, 0], [0, 0, 0], [0] * 8):
+        pool = capi.Pool(devices, images[:1], images[1:])
+        assert pool.size() == len(devices)
+        for min_split in (1, 500, 4096):
+            pool.set_min_split(min_split)
+            mc, best, dec, st = pool.classify(buf, offs, lens)
+            assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)
+        pool.destroy()
+    assert len(set(exp_dec.tolist())) == 3
