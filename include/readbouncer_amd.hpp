@@ -316,6 +316,50 @@ inline BatchResult classify_batch(const std::vector<IBFMeta>& DepletionFilters, 
     return classify_batch_flat(DepletionFilters, TargetFilters, conf, flat.data(), offs.data(), lens.data(), n, mode);
 }
 
+// ---- several GPUs in one process: filters replicated, batches read-sharded (rb_pool) --------------
+class MultiDeviceClassifier
+{
+    rb_pool* pool_ = nullptr;
+    size_t nf_ = 0;
+public:
+    MultiDeviceClassifier(const std::vector<int>& devices, const std::vector<IBFMeta>& DepletionFilters,
+                          const std::vector<IBFMeta>& TargetFilters)
+    {
+        if (DepletionFilters.empty() && TargetFilters.empty()) throw NullFilterException("No IBF provided to classify the read!");
+        std::vector<rb_ibf*> images;
+        auto cleanup = [&] { for (rb_ibf* i : images) rb_ibf_close(i); };
+        for (const std::vector<IBFMeta>* set : {&DepletionFilters, &TargetFilters})
+            for (const IBFMeta& m : *set) {
+                rb_ibf* img = nullptr;
+                const int st = rb_dibf_download(m.filter.handle(), &img);
+                if (st != RB_OK) { cleanup(); throw_status(st, "download"); }
+                images.push_back(img);
+            }
+        nf_ = images.size();
+        const int st = rb_pool_create(devices.data(), devices.size(), images.data(), DepletionFilters.size(),
+                                      images.data() + DepletionFilters.size(), TargetFilters.size(), &pool_);
+        cleanup();  // the pool holds its own replicas in HBM
+        throw_status(st, "rb_pool_create");
+    }
+    ~MultiDeviceClassifier() { rb_pool_destroy(pool_); }
+    MultiDeviceClassifier(const MultiDeviceClassifier&) = delete;
+    MultiDeviceClassifier& operator=(const MultiDeviceClassifier&) = delete;
+
+    BatchResult classify_flat(const ClassifyConfig& conf, const char* seqs, const uint64_t* offsets, const uint32_t* lens,
+                              size_t n, int mode)
+    {
+        BatchResult r;
+        r.maxcount.resize(n * nf_);
+        r.best_target.resize(n);
+        r.decision.resize(n);
+        r.status.resize(n);
+        throw_status(rb_pool_classify_batch(pool_, seqs, offsets, lens, n, conf.error_rate, conf.significance, mode,
+                                            r.maxcount.data(), r.best_target.data(), r.decision.data(), r.status.data()),
+                     "rb_pool_classify_batch");
+        return r;
+    }
+};
+
 // ---- Read (src/IBF/IBF.hpp:169-226) -------------------------------------------------------------
 class Read
 {

@@ -108,9 +108,13 @@ struct ParsedBatch
 // classify_reads, src/main/classify.hpp:142-380.  A reader thread parses batch i+1 from the memory-mapped read
 // file while the GPU works on batch i.
 static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta> DepletionFilters,
-                           std::vector<interleave::IBFMeta> TargetFilters, size_t batch_reads)
+                           std::vector<interleave::IBFMeta> TargetFilters, size_t batch_reads,
+                           const std::vector<int>& devices)
 {
     interleave::ClassifyConfig Conf{};
+    std::unique_ptr<interleave::MultiDeviceClassifier> multi;
+    if (devices.size() > 1 && (!DepletionFilters.empty() || !TargetFilters.empty()))
+        multi.reset(new interleave::MultiDeviceClassifier(devices, DepletionFilters, TargetFilters));
     const bool deplete = DepletionFilters.size() >= 1, target = TargetFilters.size() >= 1;
     if (!deplete && !target) {
         std::cerr << "[Error] No depletion or target filters have been provided for classification! " << '\n';
@@ -222,9 +226,10 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                 std::vector<size_t> next;
                 if (!idx.empty()) {
                     if (flat.empty()) flat.push_back('N');
-                    interleave::BatchResult res = interleave::classify_batch_flat(
-                        DepletionFilters, TargetFilters, Conf, flat.data(), offs.data(), lens.data(), idx.size(),
-                        RB_MODE_CLASSIFY_CHUNK);
+                    interleave::BatchResult res =
+                        multi ? multi->classify_flat(Conf, flat.data(), offs.data(), lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK)
+                              : interleave::classify_batch_flat(DepletionFilters, TargetFilters, Conf, flat.data(), offs.data(),
+                                                                lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK);
                     for (size_t j = 0; j < idx.size(); ++j) {
                         ReadState& st = state[idx[j]];
                         if (res.status[j] != RB_OK) { st.failed = true; continue; }  // exception -> failed++ (:306-316)
@@ -280,7 +285,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
     }
 }
 
-static int run_program(ConfigReader& config, size_t batch_reads)
+static int run_program(ConfigReader& config, size_t batch_reads, const std::vector<int>& devices)
 {
     config.parse();
     if (config.usage == "build") {  // main.cpp:286-344
@@ -297,7 +302,7 @@ static int run_program(ConfigReader& config, size_t batch_reads)
     if (config.usage == "classify") {  // main.cpp:346-376
         std::vector<interleave::IBFMeta> DepletionFilters = getIBF(config, true, false);
         std::vector<interleave::IBFMeta> TargetFilters = getIBF(config, false, true);
-        classify_reads(config, DepletionFilters, TargetFilters, batch_reads);
+        classify_reads(config, DepletionFilters, TargetFilters, batch_reads, devices);
         return 0;
     }
     std::cerr << "usage \"" << config.usage << "\" is outside this engine's scope (supported: build, classify)" << std::endl;
@@ -309,7 +314,22 @@ int main(int argc, char const* argv[])
     std::string config_path;
     bool dump_only = false;
     size_t batch_reads = 65536;
+    std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {  // e.g. --devices 0,1,2,3,4,5,6,7
+            devices.clear();
+            std::string list = argv[++i];
+            size_t pos = 0;
+            while (pos <= list.size()) {
+                const size_t comma = list.find(',', pos);
+                const std::string tok = list.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+                if (!tok.empty()) devices.push_back(std::stoi(tok));
+                if (comma == std::string::npos) break;
+                pos = comma + 1;
+            }
+            if (devices.empty()) devices.push_back(0);
+            continue;
+        }
         if ((!std::strcmp(argv[i], "--config") || !std::strcmp(argv[i], "-c")) && i + 1 < argc) config_path = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-config")) dump_only = true;
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) batch_reads = (size_t)std::stoull(argv[++i]);
@@ -336,7 +356,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N]" << std::endl;
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--devices 0,1,...] [--parse-stats file]" << std::endl;
             return 0;
         }
     }
@@ -352,7 +372,7 @@ int main(int argc, char const* argv[])
             std::cout << config.dump();
             return 0;
         }
-        return run_program(config, batch_reads);
+        return run_program(config, batch_reads, devices);
     } catch (const ConfigReaderException& e) {
         std::cerr << "Error in reading TOML configuration file!" << std::endl << e.what() << std::endl;
         return 1;

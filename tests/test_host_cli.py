@@ -170,7 +170,9 @@ def test_config1_build_and_classify(tmp_path, refdata):
     for (chunk, maxc) in ((360, 1), (360, 5), (250, 5)):
         write_config(cfg, "classify", out, kmer_size=13, deplete_files=[ibf], read_files=[rf], chunk_length=chunk,
                      max_chunks=maxc)
-        stdout = run_cli("--config", str(cfg)).stdout
+        # the third variant goes through the multi-device pool (device 0 listed twice on a one-GPU box)
+        extra = ["--devices", "0,0", "--batch-reads", "3"] if maxc == 5 and chunk == 250 else []
+        stdout = run_cli("--config", str(cfg), *extra).stdout
         exp = dict(found=0, failed=0, too_short=0)
         unclassified = []
         for n, s in reads:
