@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--check-reads", type=int, default=2048, help="reads checked against the oracle (rank 0)")
+    ap.add_argument("--no-overlap", action="store_true", help="serialise the count kernels of different filters")
     ap.add_argument("--rate", type=float, default=150000.0, help="c5: total chunk arrival rate (chunks/s) over all GPUs")
     ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
     return ap.parse_args()
@@ -50,6 +51,8 @@ def replay(args, torch, capi, synth, world, rank, dev_index, dev, dist):
     dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
     tgt, ref_t = synth.build_device_filter(dev_index, wt, fill_seed=6, plant_seed=60)
     eng = capi.Engine(dev_index, [dep], [tgt])
+    if args.no_overlap:
+        eng.set_overlap(False)
     rate = args.rate / world
     n = int(rate * args.replay_seconds)
     read_len = 360
@@ -175,6 +178,8 @@ def main():
     t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     eng = capi.Engine(dev_index, deplete, target)
+    if args.no_overlap:
+        eng.set_overlap(False)
     # a dedicated non-null stream: steps are queued asynchronously; torch.cuda.synchronize() covers it
     side = torch.cuda.Stream(device=dev)
     stream = side.cuda_stream

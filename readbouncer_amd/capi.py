@@ -78,6 +78,7 @@ SIGNATURES = {
     "rb_live_pending": (_sz, [_vp]),
     "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
+    "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -298,6 +299,9 @@ class Engine:
 
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")
+
+    def set_overlap(self, on):
+        _check(lib().rb_engine_set_overlap(self.h, int(on)), "rb_engine_set_overlap")
 
     def set_nt_threshold(self, table_bytes):
         _check(lib().rb_engine_set_nt_threshold(self.h, table_bytes), "rb_engine_set_nt_threshold")

@@ -98,7 +98,13 @@ struct rb_engine {
     uint32_t thr_len = 0;
     double thr_r = -1.0, thr_conf = -1.0;
     // workspaces
-    DevBuf d_part, d_maxcount;
+    DevBuf d_maxcount;
+    std::vector<DevBuf> d_parts;  // per filter: partial maxima of the column slices
+    // filters run concurrently: filter 0 on the caller's stream, the others on auxiliary streams (fork/join by events)
+    std::vector<hipStream_t> aux;
+    hipEvent_t fork_ev = nullptr;
+    std::vector<hipEvent_t> join_ev;
+    bool overlap = true;
     // staging for the host-pointer API
     DevBuf d_seqs, d_offsets, d_lens, d_best, d_decision, d_status;
     PinnedBuf h_in, h_out;
@@ -357,6 +363,17 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     e->nd = (uint32_t)n_deplete;
     e->nt = (uint32_t)n_target;
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    e->d_parts.resize(e->filters.size());
+    const size_t n_aux = std::min<size_t>(3, e->filters.size() - 1);
+    for (size_t i = 0; i < n_aux && he == hipSuccess; ++i) {
+        hipStream_t s = nullptr;
+        he = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (he == hipSuccess) e->aux.push_back(s);
+        hipEvent_t ev = nullptr;
+        if (he == hipSuccess) he = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (he == hipSuccess) e->join_ev.push_back(ev);
+    }
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming);
     if (he != hipSuccess) { rb_engine_destroy(e); return rb::fail(RB_ERR_HIP, hipGetErrorString(he)); }
     *out = e;
     return RB_OK;
@@ -368,7 +385,11 @@ void rb_engine_destroy(rb_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     for (auto &p : e->ev_ring) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-    for (DevBuf *b : {&e->d_thr, &e->d_part, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+    for (hipStream_t s : e->aux) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (hipEvent_t ev : e->join_ev) (void)hipEventDestroy(ev);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    for (DevBuf &b : e->d_parts) b.release();
+    for (DevBuf *b : {&e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
     e->h_in.release();
@@ -389,6 +410,14 @@ int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads)
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
     std::lock_guard<std::mutex> lock(e->mu);
     e->split_threshold = max_reads;
+    return RB_OK;
+}
+
+int rb_engine_set_overlap(rb_engine *e, int enabled)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->overlap = enabled != 0;
     return RB_OK;
 }
 
@@ -508,8 +537,14 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         evp = &e->ev_ring[e->ev_used++];
         RB_HIP(hipEventRecord(evp->first, st));
     }
+    const bool fan_out = e->overlap && nf > 1 && !e->aux.empty();
+    if (fan_out) {
+        RB_HIP(hipEventRecord(e->fork_ev, st));
+        for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) RB_HIP(hipStreamWaitEvent(e->aux[k], e->fork_ev, 0));
+    }
     for (size_t fi = 0; fi < nf; ++fi) {
         const rb_dibf *f = e->filters[fi];
+        hipStream_t fs = (fan_out && fi > 0) ? e->aux[(fi - 1) % e->aux.size()] : st;
         CountLaunch a{};
         a.f = f->dev;
         a.seqs = (const uint8_t *)d_seqs;
@@ -528,7 +563,7 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         a.nt = f->geo.n_words * 8 > e->nt_threshold_bytes;
         if (Weff == 0) {
             // this rank holds no column of this filter: its partial maxima are 0
-            RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, st));
+            RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, fs));
             continue;
         }
         if (Weff > 64 && (W % 2 == 0) && (a.col_begin % 2 == 0)) {
@@ -547,15 +582,21 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
             a.out_slice_stride = 0;
-            RB_HIP(launch_ibf_count_max(a, st));
+            RB_HIP(launch_ibf_count_max(a, fs));
         } else {
-            rc = e->d_part.ensure((size_t)a.n_slices * n_reads * 2);
+            rc = e->d_parts[fi].ensure((size_t)a.n_slices * n_reads * 2);
             if (rc != RB_OK) return rc;
-            a.out = (uint16_t *)e->d_part.p;
+            a.out = (uint16_t *)e->d_parts[fi].p;
             a.out_read_stride = 1;
             a.out_slice_stride = (uint32_t)n_reads;
-            RB_HIP(launch_ibf_count_max(a, st));
-            RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, st));
+            RB_HIP(launch_ibf_count_max(a, fs));
+            RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, fs));
+        }
+    }
+    if (fan_out) {
+        for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) {
+            RB_HIP(hipEventRecord(e->join_ev[k], e->aux[k]));
+            RB_HIP(hipStreamWaitEvent(st, e->join_ev[k], 0));
         }
     }
     if (evp) RB_HIP(hipEventRecord(evp->second, st));
