@@ -23,6 +23,8 @@
 // No MFMA anywhere: there is no multiply-accumulate structure in this path.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "rb_device.h"
 
 namespace rb {
@@ -544,12 +546,16 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
         const int nw = a.split_waves;
         const size_t lds = (size_t)nw * WPL * NP * 64 * 8 + 16 + (size_t)nw * kStageBytes;
         auto kern = ibf_count_max_split_kernel<LG, WPL, NP, H, NT>;
-        static bool attr_done = false;  // per instantiation
-        if (!attr_done) {
+        // the opt-in for > 64 KiB of dynamic LDS is per function AND per device: remember it per device id
+        static std::atomic<uint64_t> attr_done{0};  // one bit per device, per instantiation
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const uint64_t bit = (dev >= 0 && dev < 64) ? (1ULL << dev) : 0;
+        if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
-            attr_done = true;
+            attr_done.fetch_or(bit, std::memory_order_release);
         }
         dim3 grid(a.n_reads, a.n_slices);
         hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.seqs, a.offsets, a.lens, a.n_reads, a.col_begin,
