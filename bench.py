@@ -24,6 +24,31 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured achievable
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box exposes 256
+    logical CPUs but grants 16 of them; oversubscribing the quota makes the CPU baseline slower, not faster)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -262,7 +287,7 @@ def main():
             views.append(po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"],
                                            h.words()))
         od, ot = views[:len(deplete)], views[len(deplete):]
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         cap = len(buf) // read_len
         pilot = min(cap, 64 * min(cores, 64))
         tp = time.perf_counter()
