@@ -160,6 +160,7 @@ template <int WPL>
 struct LaneCols {
     uint64_t valid[WPL];        // bins of this lane's word(s) that exist (padding and foreign columns masked)
     const uint64_t *lane_base;  // f.words + first word column of this lane
+    const uint64_t *safe_base;  // lane_base, or f.words for a lane that owns no (complete) column: always loadable
     bool colok;                 // lane owns at least one existing column
     bool col_full;              // WPL == 2: both words exist, a 16-byte load is allowed
 };
@@ -184,6 +185,13 @@ __device__ __forceinline__ LaneCols<WPL> make_lane_cols(const IbfDev &f, int lan
     }
     lc.col_full = (col0 + WPL) <= col_end;
     lc.lane_base = f.words + col0;
+    // WPL == 2 is only dispatched for even W and even slice bounds, so a lane owns both words or none
+    const bool loadable = (WPL == 1) ? lc.colok : lc.col_full;
+    if (WPL == 2 && !lc.col_full) {
+        lc.colok = false;
+        for (int w = 0; w < WPL; ++w) lc.valid[w] = 0ULL;
+    }
+    lc.safe_base = loadable ? lc.lane_base : f.words;
     return lc;
 }
 
@@ -232,7 +240,12 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
             }
         }
 
-        // ---- phase B: gather + count, eight steps at a time
+        // ---- phase B: gather + count, eight steps at a time.
+        // The loads of a batch of steps are issued back to back and consumed afterwards, so that a wave keeps
+        // 8*H (WPL = 1) or 4*H (WPL = 2) gathers in flight.  There is no control flow around the loads: steps past
+        // the end of the read and lanes without a column read block 0 of the filter (always a valid, cache-resident
+        // address) and are masked out of the result -- a branch per step would make the compiler drain the
+        // memory pipe after every step (3 loads in flight instead of 24).
 #pragma unroll 1
         for (int blk = 0; blk < STEPS / 8; ++blk) {
             {
@@ -241,43 +254,59 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 if (first >= n) break;  // wave-uniform
             }
             uint64_t x[WPL][8];
+            if constexpr (H > 0) {
+                constexpr int HALF = (WPL == 1) ? 8 : 4;  // steps per load batch
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = blk * 8 + u;
-                const int j = (SPT >= 8) ? 0 : (u / SPT);  // compile-time either way
-                const int it = (s % SPT) * NG + g;          // k-mer of this group within tile j
-                const uint32_t p = mt + (uint32_t)(j * 64 + it);
-                const bool ok = (p < n) && lc.colok;
-                uint64_t acc[WPL];
+                for (int half = 0; half < 8 / HALF; ++half) {
+                    uint64_t ld[HALF][H][WPL];
+                    bool okv[HALF];
 #pragma unroll
-                for (int w = 0; w < WPL; ++w) acc[w] = ok ? lc.valid[w] : 0ULL;
-                if constexpr (H > 0) {
-                    uint32_t b[H];
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        if constexpr (LG == 0) b[h] = idx[j][h];
-                        else if constexpr (LG == 6) b[h] = readlane32(idx[j][h], it);
-                        else b[h] = shfl32(idx[j][h], it);
-                    }
-                    if (ok) {
+                    for (int uu = 0; uu < HALF; ++uu) {
+                        const int u = half * HALF + uu;
+                        const int s = blk * 8 + u;
+                        const int j = (SPT >= 8) ? 0 : (u / SPT);  // compile-time either way
+                        const int it = (s % SPT) * NG + g;          // k-mer of this group within tile j
+                        const uint32_t p = mt + (uint32_t)(j * 64 + it);
+                        const bool ok = (p < n) && lc.colok;
+                        okv[uu] = ok;
 #pragma unroll
                         for (int h = 0; h < H; ++h) {
-                            const uint64_t *src = lc.lane_base + (uint64_t)b[h] * W;
+                            uint32_t b;
+                            if constexpr (LG == 0) b = idx[j][h];
+                            else if constexpr (LG == 6) b = readlane32(idx[j][h], it);
+                            else b = shfl32(idx[j][h], it);
+                            const uint64_t *src = lc.safe_base + (uint64_t)(ok ? b : 0u) * W;
                             if constexpr (WPL == 1) {
-                                acc[0] &= load_word<NT>(src);
+                                ld[uu][h][0] = load_word<NT>(src);
                             } else {
-                                if (lc.col_full) {
-                                    const rb_u64x2 q = load_word2<NT>(src);
-                                    acc[0] &= q.x;
-                                    acc[1] &= q.y;
-                                } else {
-                                    acc[0] &= load_word<NT>(src);
-                                    acc[1] = 0;
-                                }
+                                const rb_u64x2 q = load_word2<NT>(src);
+                                ld[uu][h][0] = q.x;
+                                ld[uu][h][1] = q.y;
                             }
                         }
                     }
-                } else {
+#pragma unroll
+                    for (int uu = 0; uu < HALF; ++uu) {
+#pragma unroll
+                        for (int w = 0; w < WPL; ++w) {
+                            uint64_t acc = okv[uu] ? lc.valid[w] : 0ULL;
+#pragma unroll
+                            for (int h = 0; h < H; ++h) acc &= ld[uu][h][w];
+                            x[w][half * HALF + uu] = acc;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = blk * 8 + u;
+                    const int j = (SPT >= 8) ? 0 : (u / SPT);
+                    const int it = (s % SPT) * NG + g;
+                    const uint32_t p = mt + (uint32_t)(j * 64 + it);
+                    const bool ok = (p < n) && lc.colok;
+                    uint64_t acc[WPL];
+#pragma unroll
+                    for (int w = 0; w < WPL; ++w) acc[w] = ok ? lc.valid[w] : 0ULL;
                     const uint64_t v = (LG == 0) ? kv[j] : shfl64(kv[j], it);
                     if (ok) {
                         for (uint32_t h = 0; h < f.n_hash; ++h) {
@@ -287,9 +316,9 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                             for (int w = 0; w < WPL; ++w) acc[w] &= (lc.valid[w] ? load_word<NT>(src + w) : 0ULL);
                         }
                     }
-                }
 #pragma unroll
-                for (int w = 0; w < WPL; ++w) x[w][u] = acc[w];
+                    for (int w = 0; w < WPL; ++w) x[w][u] = acc[w];
+                }
             }
 #pragma unroll
             for (int w = 0; w < WPL; ++w) pl[w].add8(x[w]);
@@ -339,7 +368,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 // latency form for micro-batches: one workgroup per (read, column slice); wave w takes strand w&1 and every
 // (blockDim/128)-th macro tile starting at w>>1.  Partial counters meet in LDS (bit-sliced adds), then max.
 template <int LG, int WPL, int NP, int H, bool NT>
-__global__ __launch_bounds__((WPL == 2 && NP > 10) ? 512 : 1024) void ibf_count_max_split_kernel(
+__global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
     IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
     const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
@@ -586,7 +615,7 @@ int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
     int nw = 2 * (tiles < 1 ? 1 : tiles);
     if (nw > by_lds) nw = by_lds;
     if (nw > 16) nw = 16;
-    if (wpl == 2 && np > 10 && nw > 8) nw = 8;  // that instantiation is built for 512 threads
+    if (wpl == 2 && nw > (np > 10 ? 8 : 12)) nw = np > 10 ? 8 : 12;  // those instantiations are built for 512 / 768 threads
     nw &= ~1;
     return nw >= 4 ? nw : 0;
 }
