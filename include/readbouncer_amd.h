@@ -115,6 +115,9 @@ RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
 RB_API void *rb_dibf_device_words(rb_dibf *f);
 RB_API int rb_dibf_device(const rb_dibf *f);
 RB_API void rb_dibf_free(rb_dibf *f);
+/* resizeBins of IBF::update_filter (src/IBF/IBFBuild.cpp:274): same blocks and hash positions, every block widened
+ * to ceil(new_bins/64) words, new bins empty, noOfBits = noOfBlocks * new block size.  Returns a new filter. */
+RB_API int rb_dibf_resize_bins(const rb_dibf *f, uint64_t new_bins, rb_dibf **out);
 /* synthetic filler for benchmarks: every bin bit ~ Bernoulli(55/256), padding bits clear */
 RB_API int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed);
 /* seqan::insertKmer for a batch of fragments (src/IBF/IBFBuild.cpp:189-190) on the GPU:

@@ -240,6 +240,45 @@ public:
         return stats;
     }
 
+    // IBF::update_filter, IBFBuild.cpp:223-321: load update_filter_file, resizeBins(old + new), add the new
+    // sequences starting at bin id totalBinsFile, store back to update_filter_file
+    FilterStats update_filter(IBFConfig& config, const std::vector<RefSeq>& records)
+    {
+        if (!config.validate()) throw InvalidConfigException("Config not valid!");
+        const std::string path = config.update_filter_file;
+        FilterStats stats = load_filter(config);  // sets config.kmer_size from the file
+        std::vector<std::string> cleaned;
+        for (const RefSeq& r : records) {
+            stats.totalSeqsFile += 1;
+            if (r.seq.size() < config.kmer_size) { stats.invalidSeqs += 1; continue; }
+            std::string c(r.seq.size(), '\0');
+            c.resize(rb_cut_out_nnns(r.seq.data(), r.seq.size(), &c[0]));
+            stats.totalBinsBinId += (uint32_t)(c.size() / config.fragment_length) + 1;
+            stats.sumSeqLen += c.size();
+            cleaned.push_back(std::move(c));
+        }
+        const uint32_t number_new_bins = stats.totalBinsBinId + stats.totalBinsFile;
+        if (number_new_bins > stats.totalBinsFile) {
+            rb_dibf* wider = nullptr;
+            throw_status(rb_dibf_resize_bins(filter.handle(), number_new_bins, &wider), "resizeBins");
+            filter = TIbf(wider);
+            stats.newBins = stats.totalBinsBinId;
+            stats.totalBinsBinId = number_new_bins;
+        }
+        uint64_t binid = stats.totalBinsFile;
+        for (const std::string& c : cleaned) {
+            const int st = rb_dibf_add_sequence(filter.handle(), c.data(), c.size(), config.fragment_length,
+                                                config.overlap_length, binid, &binid);
+            if (st != RB_OK) throw InsertSequenceException(std::string("Error inserting a sequence to the IBF: ") + rb_last_error());
+        }
+        try {
+            filter.store(path);
+        } catch (const IBFBuildException& e) {
+            throw StoreFilterException("Could not store IBF to " + path + ":" + e.what());
+        }
+        return stats;
+    }
+
     inline TIbf getFilter() { return filter; }
 };
 

@@ -605,6 +605,20 @@ uint64_t orc_add_sequence(orc_ibf *f, const uint8_t *ord, size_t len, uint64_t f
     return binid;
 }
 
+/* [SeqAn] resizeBins(bins) as used by IBF::update_filter (src/IBF/IBFBuild.cpp:274): the number of blocks is
+ * kept (hash positions stay valid), every block is widened to ceil(bins/64) words, old words stay at the start
+ * of their block, new columns are empty, noOfBits = noOfBlocks * newBlockBitSize.  Returns a new filter. */
+orc_ibf *orc_ibf_resize_bins(const orc_ibf *f, uint64_t new_bins)
+{
+    if (new_bins < f->n_bins) return NULL;
+    uint64_t new_width = (new_bins + 63) / 64;
+    orc_ibf *g = orc_ibf_new(new_bins, f->n_hash, f->kmer_size, f->n_blocks * new_width * 64);
+    if (!g) return NULL;
+    for (uint64_t b = 0; b < f->n_blocks; ++b)
+        memcpy(g->words + b * new_width, f->words + b * f->bin_width, (size_t)f->bin_width * 8);
+    return g;
+}
+
 /* ------------------------------------------------------- synthetic filler -- */
 static inline uint64_t orc_mix64(uint64_t z)
 {

@@ -141,6 +141,9 @@ size_t orc_cut_out_nnns(const char *seq, size_t len, char *out);
 uint64_t orc_add_sequence(orc_ibf *f, const uint8_t *ord, size_t len, uint64_t fragment_length,
                           uint64_t kmer_size, uint64_t overlap_length, uint64_t first_bin);
 
+/* resizeBins of IBF::update_filter (IBFBuild.cpp:274); new filter, caller frees */
+orc_ibf *orc_ibf_resize_bins(const orc_ibf *f, uint64_t new_bins);
+
 /* deterministic synthetic filler shared with the GPU fill kernel's definition:
  * bit j of word w (w < n_blocks*bin_width) is set with probability 55/256, bins >= n_bins clear */
 uint64_t orc_synth_word(uint64_t seed, uint64_t word_index);

@@ -100,6 +100,8 @@ def lib():
     L.orc_batch_check_unblock.argtypes = [_vpp, C.c_size_t, _vpp, C.c_size_t, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                           C.c_void_p, C.c_void_p]
+    L.orc_ibf_resize_bins.restype = C.c_void_p
+    L.orc_ibf_resize_bins.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_dna5_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
     L.orc_revcomp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     _lib = L
@@ -184,6 +186,12 @@ class OracleIBF:
     def add_sequence(self, ord_arr, fragment_length, first_bin=0, overlap_length=1500):
         return lib().orc_add_sequence(self.h, ord_arr.ctypes.data, len(ord_arr), fragment_length,
                                       self.kmer_size, overlap_length, first_bin)
+
+    def resize_bins(self, new_bins):
+        h = lib().orc_ibf_resize_bins(self.h, new_bins)
+        if not h:
+            raise ValueError("resize_bins: cannot shrink")
+        return OracleIBF(_handle=h)
 
     def fill_synth(self, seed):
         lib().orc_ibf_fill_synth(self.h, seed)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "rb_dibf_device_words": (_vp, [_vp]),
     "rb_dibf_device": (_int, [_vp]),
     "rb_dibf_free": (None, [_vp]),
+    "rb_dibf_resize_bins": (_int, [_vp, _u64, _pp]),
     "rb_dibf_fill_synth": (_int, [_vp, _u64]),
     "rb_dibf_insert": (_int, [_vp, _vp, _sz, _vp, _vp, _vp, _sz]),
     "rb_dibf_add_sequence": (_int, [_vp, _vp, _sz, _u64, _u64, _u64, C.POINTER(_u64)]),
@@ -213,6 +214,11 @@ class DeviceIBF:
 
     def device_words(self):
         return lib().rb_dibf_device_words(self.h)
+
+    def resize_bins(self, new_bins):
+        h = C.c_void_p()
+        _check(lib().rb_dibf_resize_bins(self.h, new_bins, C.byref(h)), "rb_dibf_resize_bins")
+        return DeviceIBF(h)
 
     def fill_synth(self, seed):
         _check(lib().rb_dibf_fill_synth(self.h, seed), "rb_dibf_fill_synth")

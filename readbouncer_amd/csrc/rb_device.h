@@ -52,6 +52,8 @@ hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const 
 hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,
                          const uint64_t *ends, const uint64_t *bins, const uint64_t *kmer_prefix,
                          uint32_t n_fragments, uint64_t total_kmers, hipStream_t st);
+hipError_t launch_widen_blocks(const uint64_t *src, uint32_t w_old, uint64_t *dst, uint32_t w_new, uint64_t n_blocks,
+                               hipStream_t st);
 hipError_t launch_fill_synth(uint64_t *words, uint64_t n_words, uint64_t used_words, uint32_t bin_width,
                              uint64_t last_mask, uint64_t seed, hipStream_t st);
 

@@ -276,6 +276,25 @@ void rb_dibf_free(rb_dibf *f)
     delete f;
 }
 
+int rb_dibf_resize_bins(const rb_dibf *f, uint64_t new_bins, rb_dibf **out)
+{
+    if (!f || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (new_bins < f->geo.n_bins) return rb::fail(RB_ERR_INVALID_ARG, "resizeBins cannot shrink a filter");
+    const uint64_t new_width = (new_bins + rbspec::kIntSize - 1) / rbspec::kIntSize;
+    rb_ibf_info g;
+    if (!geometry_from(new_bins, f->geo.n_hash, f->geo.kmer_size, f->geo.n_blocks * new_width * 64, &g))
+        return rb::fail(RB_ERR_INVALID_ARG, "bad IBF geometry");
+    rb_dibf *n = nullptr;
+    int st = dibf_alloc(f->device, g, true, &n);
+    if (st != RB_OK) return st;
+    hipError_t e = launch_widen_blocks(f->d_words, (uint32_t)f->geo.bin_width, n->d_words, (uint32_t)new_width,
+                                       f->geo.n_blocks, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { rb_dibf_free(n); return rb::fail(RB_ERR_HIP, std::string("resize: ") + hipGetErrorString(e)); }
+    *out = n;
+    return RB_OK;
+}
+
 int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
 {
     if (!f) return rb::fail(RB_ERR_INVALID_ARG, "null filter");

@@ -551,6 +551,19 @@ __global__ void ibf_insert_kernel(IbfDev f, uint64_t *__restrict__ words, const 
     }
 }
 
+// resizeBins: block b of width w_old -> block b of width w_new, old words first, new columns zero
+__global__ void widen_blocks_kernel(const uint64_t *__restrict__ src, uint32_t w_old, uint64_t *__restrict__ dst,
+                                    uint32_t w_new, uint64_t n_blocks)
+{
+    const uint64_t total = n_blocks * w_new;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t b = i / w_new;
+        const uint32_t c = (uint32_t)(i - b * w_new);
+        dst[i] = c < w_old ? src[b * w_old + c] : 0ULL;
+    }
+}
+
 __global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t n_words, uint64_t used_words,
                                   uint32_t bin_width, uint64_t last_mask, uint64_t seed)
 {
@@ -671,6 +684,16 @@ hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, c
     const uint64_t blocks = (total_kmers + 255) / 256;
     hipLaunchKernelGGL(ibf_insert_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, f, words, seq, starts, ends, bins,
                        kmer_prefix, n_fragments, total_kmers);
+    return hipGetLastError();
+}
+
+hipError_t launch_widen_blocks(const uint64_t *src, uint32_t w_old, uint64_t *dst, uint32_t w_new, uint64_t n_blocks,
+                               hipStream_t st)
+{
+    if (n_blocks == 0) return hipSuccess;
+    uint64_t blocks = (n_blocks * w_new + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(widen_blocks_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, w_old, dst, w_new, n_blocks);
     return hipGetLastError();
 }
 

@@ -392,3 +392,71 @@ def test_pool_shards_reads_across_engines():
             assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)
         pool.destroy()
     assert len(set(exp_dec.tolist())) == 3
+
+
+def test_alphabet_conversion_on_device():
+    """(seqan::Dna5String) conversion inside K1: lower case, U/u as T, IUPAC codes and any other byte as N (ordinal 4),
+    which is hashed like a fifth letter."""
+    rng = np.random.default_rng(12)
+    d = capi.DeviceIBF.create(0, 200, 3, 13, 256 * 50021)
+    ref = H.random_dna(rng, 20000)
+    d.add_sequence(ref, 100)
+    o, _k = oracle_view(d)
+    base = [ref[i:i + 300] for i in range(0, 6000, 300)]
+    reads = []
+    for i, r in enumerate(base):
+        if i % 4 == 0:
+            r = r.lower()
+        elif i % 4 == 1:
+            r = r.replace("T", "U")
+        elif i % 4 == 2:
+            r = "".join(c if rng.random() > 0.03 else "RYKMSWBDHVN-*x"[int(rng.integers(0, 14))] for c in r)
+        else:
+            r = "".join(c.lower() if rng.random() < 0.5 else c for c in r).replace("t", "u")
+        reads.append(r)
+    buf, offs, lens = H.pack_reads(reads)
+    raw = np.frombuffer(bytes(range(256)) * 2, dtype=np.uint8).copy()  # every byte value, incl. NUL and > 127
+    buf = np.concatenate([buf, raw])
+    offs = np.append(offs, np.uint64(len(buf) - len(raw)))
+    lens = np.append(lens, np.uint32(len(raw)))
+    eng = capi.Engine(0, [d], [])
+    mc, _, dec, st = eng.classify(buf, offs, lens)
+    assert np.array_equal(mc[:, 0], po.batch_raw_max(o, buf, offs, lens, 2))
+    edec, est = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=2)
+    assert np.array_equal(dec, edec) and np.array_equal(st, est)
+    assert mc[0, 0] == 288 and mc[1, 0] == 288 and mc[3, 0] == 288  # case and U do not cost a single k-mer
+    assert mc[2, 0] < 288
+
+
+@pytest.mark.parametrize("old_bins,new_bins", [(40, 60), (60, 70), (64, 65), (100, 1000), (130, 130)])
+def test_resize_bins_and_update(old_bins, new_bins):
+    """resizeBins + adding sequences to the new bins (IBF::update_filter, IBFBuild.cpp:223-321): identical to the
+    oracle's restatement, old bins keep their counts."""
+    rng = np.random.default_rng(old_bins * 1000 + new_bins)
+    ref = H.random_dna(rng, 6000)
+    add = H.random_dna(rng, 3000)
+    W = (old_bins + 63) // 64
+    d = capi.DeviceIBF.create(0, old_bins, 3, 13, W * 64 * 5003 + 40)
+    o = po.OracleIBF(old_bins, 3, 13, W * 64 * 5003 + 40)
+    frag = 6000 // min(old_bins, 30) + 1
+    d.add_sequence(ref, frag)
+    o.add_sequence(po.encode(ref), frag)
+    d2, o2 = d.resize_bins(new_bins), o.resize_bins(new_bins)
+    assert (d2.info["n_bins"], d2.info["n_blocks"], d2.info["n_bits"]) == (o2.n_bins, o2.n_blocks, o2.n_bits) == \
+           (new_bins, 5003, 5003 * 64 * ((new_bins + 63) // 64))
+    first_new = old_bins
+    if new_bins > old_bins:
+        frag2 = 3000 // (new_bins - old_bins) + 14
+        b1 = d2.add_sequence(add, frag2, first_new)
+        b2 = o2.add_sequence(po.encode(add), frag2, first_new)
+        assert b1 == b2
+    host = d2.download()
+    nw = o2.n_bits // 64
+    assert np.array_equal(host.words()[:nw], o2.words()[:nw])
+    reads = [ref[100:400], add[50:350], ref[3000:3300], H.random_dna(rng, 300)]
+    buf, offs, lens = H.pack_reads(reads)
+    mc = capi.Engine(0, [d2], []).classify(buf, offs, lens)[0][:, 0]
+    assert np.array_equal(mc, po.batch_raw_max(o2, buf, offs, lens))
+    assert mc[0] == 288 and mc[2] == 288 and (mc[1] == 288 or new_bins == old_bins)
+    with pytest.raises(capi.RBError):
+        d2.resize_bins(new_bins - 1)
