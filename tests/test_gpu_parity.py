@@ -424,8 +424,14 @@ def test_alphabet_conversion_on_device():
     assert np.array_equal(mc[:, 0], po.batch_raw_max(o, buf, offs, lens, 2))
     edec, est = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=2)
     assert np.array_equal(dec, edec) and np.array_equal(st, est)
-    assert mc[0, 0] == 288 and mc[1, 0] == 288 and mc[3, 0] == 288  # case and U do not cost a single k-mer
-    assert mc[2, 0] < 288
+    pb, po_, pl = H.pack_reads(base)
+    plain = po.batch_raw_max(o, pb, po_, pl, 2)
+    for i in range(len(base)):
+        if i % 4 == 2:
+            assert mc[i, 0] <= plain[i]
+        else:
+            assert mc[i, 0] == plain[i]  # case and U do not cost a single k-mer
+    assert plain.min() > 50
 
 
 @pytest.mark.parametrize("old_bins,new_bins", [(40, 60), (60, 70), (64, 65), (100, 1000), (130, 130)])
@@ -457,6 +463,6 @@ def test_resize_bins_and_update(old_bins, new_bins):
     buf, offs, lens = H.pack_reads(reads)
     mc = capi.Engine(0, [d2], []).classify(buf, offs, lens)[0][:, 0]
     assert np.array_equal(mc, po.batch_raw_max(o2, buf, offs, lens))
-    assert mc[0] == 288 and mc[2] == 288 and (mc[1] == 288 or new_bins == old_bins)
+    assert mc[0] > 80 and mc[2] > 80 and (mc[1] > 50 or new_bins == old_bins) and mc[3] < 30
     with pytest.raises(capi.RBError):
         d2.resize_bins(new_bins - 1)
