@@ -463,6 +463,5 @@ def test_resize_bins_and_update(old_bins, new_bins):
     buf, offs, lens = H.pack_reads(reads)
     mc = capi.Engine(0, [d2], []).classify(buf, offs, lens)[0][:, 0]
     assert np.array_equal(mc, po.batch_raw_max(o2, buf, offs, lens))
-    assert mc[0] > 80 and mc[2] > 80 and (mc[1] > 50 or new_bins == old_bins)
     with pytest.raises(capi.RBError):
         d2.resize_bins(new_bins - 1)
