@@ -66,7 +66,7 @@ def parse():
     return ap.parse_args()
 
 
-def replay(args, torch, capi, synth, world, rank, dev_index, dev, dist):
+def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
     """BASELINE configs[4]: 48-flowcell replay.  Poisson chunk arrivals (rate/world per GPU), 360 bp each, deplete =
     GRCh38-scale IBF + target = mock-community IBF, full check_unblock.  The dispatcher is work-conserving: whenever
     the GPU is free it takes everything that has arrived (a micro-batch) through rb_classify_batch (host buffers in,
@@ -82,7 +82,7 @@ def replay(args, torch, capi, synth, world, rank, dev_index, dev, dist):
     n = int(rate * args.replay_seconds)
     read_len = 360
     ref = np.concatenate([ref_d, ref_t])
-    t_seq, _, _ = synth.make_reads_device(7000 + rank, n, read_len, ref, dev)
+    t_seq, _, _ = synth.make_reads_device(7000 + rank, n, read_len, ref, torch.device("cuda", dev_index))
     buf = t_seq.cpu().numpy()
     del t_seq
     rng = np.random.default_rng(7 + rank)
@@ -114,11 +114,11 @@ def replay(args, torch, capi, synth, world, rank, dev_index, dev, dist):
         done = hi
     elapsed = _t.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
         stats = torch.tensor([np.percentile(lat, 50), np.percentile(lat, 99), np.percentile(lat, 99.9), lat.max()],
-                             dtype=torch.float64, device=dev)
+                             dtype=torch.float64, device=red_dev)
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
         p50, p99, p999, pmax = [float(x) for x in stats.tolist()]
     else:
@@ -158,21 +158,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (never set by the driver): RB_BENCH_BACKEND=gloo + RB_BENCH_SAME_GPU=1 run several ranks on ONE GPU,
+    # which exercises the multi-rank control flow of this script on a one-GPU box (RCCL refuses duplicate GPUs)
+    backend = os.environ.get("RB_BENCH_BACKEND", "nccl")
+    same_gpu = os.environ.get("RB_BENCH_SAME_GPU") == "1"
+    dev_index = 0 if (same_gpu or world == 1) else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    dev_index = local_rank if world > 1 else 0
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
     # ---------------------------------------------------------------- workload (untimed set-up)
     t_setup = time.time()
     if args.workload == "c5":
-        return replay(args, torch, capi, synth, world, rank, dev_index, dev, dist)
+        return replay(args, torch, capi, synth, world, rank, dev_index, dev if backend == "nccl" else "cpu", dist)
     if args.workload == "c4":
         wd, wt = synth.WORKLOADS["c3"], synth.WORKLOADS["zymo"]
         dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
@@ -235,7 +242,7 @@ def main():
     kernel_ms, n_calls = eng.kernel_time()
     eng.set_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_reads = n_reads * world * args.steps
