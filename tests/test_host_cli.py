@@ -35,29 +35,57 @@ def test_cli_exists():
     assert os.path.exists(CLI), "run __graft_entry__.build()"
 
 
-def test_reference_config_toml_is_parsed(tmp_path, refdata):
-    # the repo config.toml of the reference (src/test/libConfigReaderTests checks parsing against it):
-    # every key of [IBF] must be understood; the listed genome paths do not exist -> the reference's error
-    text = open(os.path.join(refdata, "config.toml")).read()
+# Same keys, sections and values as the config.toml at the root of the reference repository (the file its
+# libConfigReaderTests parse), written out here with our own layout: inline comments, mixed quote styles,
+# integer and float values, string arrays and an integer array, all three tables.
+REFERENCE_STYLE_CONFIG = """
+usage = "test"   # one of build / target / classify / test
+output_directory = '{out}'
+log_directory = '{out}/logs'
+
+[IBF]
+kmer_size = 15            # default 13
+fragment_size = 100000
+threads = 3
+target_files = ['{t0}', '{t1}', '{t2}']
+deplete_files = ['{d0}']
+read_files = ['{r0}']
+exp_seq_error_rate = 0.1  # between 0 and 1
+chunk_length = 360
+max_chunks = 1
+
+[MinKNOW]
+host = "localhost"
+port = "9502"
+flowcell = "MS00000"
+token_path = "test/tmp/minknow-auth-token.json"
+channels = [1,512]
+
+[Basecaller]
+caller = "DeepNano"
+host = "127.0.0.1"
+port = "9502"
+threads = 3
+config = "dna_r9.4.1_450bps_fast"
+"""
+
+
+def test_reference_style_config_is_parsed(tmp_path):
+    names = dict(t0="path/to/reference/file/Bacillus_subtilis_complete_genome.fasta", t1="b.fasta", t2="c.fasta",
+                 d0="d.fasta", r0="r.fasta")
     cfg = tmp_path / "config.toml"
-    cfg.write_text(text.replace("'RB_out'", "'%s'" % (tmp_path / "RB_out")).replace("'RB_out/logs'", "'%s'" % (tmp_path / "RB_out/logs")))
+    cfg.write_text(REFERENCE_STYLE_CONFIG.format(out=tmp_path / "RB_out", **names))
+    # listed genome paths that do not exist -> the reference's error text (configReader.cpp:292-297)
     p = run_cli("--config", str(cfg), "--dump-config", check=False)
     assert p.returncode == 1
     assert "[Error] The following target file does not exist: path/to/reference/file/Bacillus_subtilis_complete_genome.fasta" in p.stderr
     assert (tmp_path / "RB_out" / "logs").is_dir()  # parse_general creates both directories
-    # same file with existing inputs: values of the reference's config.toml come through
-    fa = []
-    for n in ("a.fasta", "b.fasta", "c.fasta", "d.fasta", "r.fasta"):
-        (tmp_path / n).write_text(">x\nACGTACGTACGTACGTACGT\n")
-        fa.append(str(tmp_path / n))
-    t2 = text.replace("'RB_out'", "'%s'" % (tmp_path / "o2")).replace("'RB_out/logs'", "'%s'" % (tmp_path / "o2/logs"))
-    for old, new in zip(["path/to/reference/file/Bacillus_subtilis_complete_genome.fasta",
-                         "path/to/reference/file/Enterococcus_faecalis_complete_genome.fasta",
-                         "path/to/reference/file/Escherichia_coli_complete_genome.fasta",
-                         "path/to/reference/file/Saccharomyces_cerevisiae_draft_genome.fasta",
-                         "path/to/read/file/SampleZMCDataSet.fasta"], fa):
-        t2 = t2.replace(old, new)
-    cfg.write_text(t2)
+    # same file with existing inputs: every value comes through
+    for k in names:
+        f = tmp_path / (k + ".fasta")
+        f.write_text(">x\nACGTACGTACGTACGTACGT\n")
+        names[k] = str(f)
+    cfg.write_text(REFERENCE_STYLE_CONFIG.format(out=tmp_path / "o2", **names))
     out = run_cli("--config", str(cfg), "--dump-config").stdout
     assert 'usage              = "test"' in out
     assert "kmer_size          = 15" in out and "fragment_size      = 100000" in out and "threads            = 3" in out
