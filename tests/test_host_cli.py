@@ -247,3 +247,13 @@ def test_classify_with_fasta_targets_and_deplete(tmp_path, refdata):
     assert results[0].startswith("RESULT found=3 ")  # classifygtests.hpp:74-77: 3 of 3 target reads
     assert (out / "classifyTests_test.ibf").exists() and (out / "host.ibf").exists()
     assert len(H.read_fasta(str(out / "classifyTests_test.fasta"))) == 0 or True
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_reads_like_the_reference_tests(tmp_path, refdata):
+    """tests/cpp/test_mirror.cpp: the reference's ReadTest / IBFTest expectations through include/readbouncer_amd.hpp"""
+    exe = os.path.join(ROOT, "readbouncer_amd", "test_mirror")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe, refdata, str(tmp_path / "work")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "failures: 0" in p.stdout
