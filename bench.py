@@ -250,6 +250,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the inputs were produced on torch's default stream; the steps run on `side` (non-blocking): order them
+    torch.cuda.synchronize()
     setup_s = time.time() - t_setup
     # ---------------------------------------------------------------- warm-up + timed region
     for _ in range(args.warmup):
