@@ -3,6 +3,7 @@
 // defaults and error messages; [MinKNOW] and [Basecaller] are parsed for completeness only.
 #pragma once
 #include <filesystem>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -94,7 +95,34 @@ public:
         }
     }
 
-    // echo of the effective configuration (the reference writes configLog.toml, configReader.cpp:98-200)
+    // ConfigReader::createLog, configReader.cpp:98-200: appends a [usage] table with the effective settings to
+    // <output_directory>/configLog.toml (same key names, incl. the dashes of kmer-size / fragment-size)
+    void createLog(std::string& usage_)
+    {
+        std::filesystem::path configLog(output_dir);
+        configLog /= "configLog.toml";
+        std::ofstream out(configLog, std::ios::app | std::ios::out);
+        auto arr = [](const std::vector<std::filesystem::path>& v) {
+            std::string s = "[";
+            for (size_t i = 0; i < v.size(); ++i) s += std::string(i ? "," : "") + "\"" + v[i].string() + "\"";
+            return s + "]";
+        };
+        out << "[" << usage_ << "]\n";
+        out << "target_files = " << arr(IBF_Parsed.target_files) << "\n";
+        out << "deplete_files = " << arr(IBF_Parsed.deplete_files) << "\n";
+        if (usage_ != "build") out << "read_files = " << arr(IBF_Parsed.read_files) << "\n";
+        out << "kmer-size = " << IBF_Parsed.size_k << "\n";
+        out << "threads = " << IBF_Parsed.threads << "\n";
+        out << "fragment-size = " << IBF_Parsed.fragment_size << "\n";
+        if (usage_ != "build") {
+            out << "exp_seq_error_rate = " << IBF_Parsed.error_rate << "\n";
+            out << "chunk_length = " << IBF_Parsed.chunk_length << "\n";
+            out << "max_chunks = " << IBF_Parsed.max_chunks << "\n";
+        }
+        out << "\n";
+    }
+
+    // echo of the effective configuration for --dump-config
     std::string dump() const
     {
         auto list = [](const std::vector<std::filesystem::path>& v) {

@@ -21,6 +21,13 @@
 
 bool ConfigReader::filterException(std::filesystem::path& file) { return rb_is_ibf_file(file.string().c_str()) == 1; }
 
+// plain-text stand-in for the reference's spdlog "ReadBouncerLog" (src/main/main.cpp:97): <log_directory>/ReadBouncerLog.txt
+static std::ofstream g_log;
+static void log_line(const std::string& level, const std::string& msg)
+{
+    if (g_log.is_open()) g_log << "[" << level << "] " << msg << std::endl;
+}
+
 // results struct of the reference's tests (classify.hpp:127-134)
 struct ClassificationResults
 {
@@ -248,7 +255,11 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             for (size_t i = 0; i < recs.size(); ++i) {  // outputs in read order
                 const seqio::Record& r = recs[i];
                 if (r.seq_len < chunk_length) continue;
-                if (state[i].failed) { failed++; continue; }
+                if (state[i].failed) {  // classify.hpp:306-316
+                    failed++;
+                    log_line("error", "Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
+                    continue;
+                }
                 if (state[i].classified) {
                     found++;
                     if (target && state[i].best >= 0) {
@@ -273,6 +284,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             std::cout << f.name << "\t : " << f.classified << "\t\t" << ((float)f.classified) / ((float)readCounter) << std::endl;
         std::cout << "Average Processing Time Read Classification        :   " << avg << std::endl;
         std::cout << "-----------------------------------------------------------------------------------" << std::endl;
+        log_line("info", "classified " + std::to_string(found) + " too_short " + std::to_string(too_short) + " failed " +
+                             std::to_string(failed) + " all " + std::to_string(readCounter) + " reads of " + read_file.string());
         std::cout << "RESULT found=" << found << " failed=" << failed << " too_short=" << too_short
                   << " readCounter=" << readCounter << std::endl;
         std::cout << "THROUGHPUT reads_per_s=" << (wall > 0 ? (double)readCounter / wall : 0.0) << " wall_s=" << wall
@@ -288,6 +301,9 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
 static int run_program(ConfigReader& config, size_t batch_reads, const std::vector<int>& devices)
 {
     config.parse();
+    config.createLog(config.usage);  // main.cpp:283
+    g_log.open(config.log_dir / "ReadBouncerLog.txt", std::ios::app);
+    log_line("info", "usage " + config.usage);
     if (config.usage == "build") {  // main.cpp:286-344
         for (const auto& files : {config.IBF_Parsed.target_files, config.IBF_Parsed.deplete_files}) {
             for (std::filesystem::path file : files) {

@@ -215,6 +215,10 @@ def test_config1_build_and_classify(tmp_path, refdata):
         got_un = [n for n, _ in H.read_fasta(str(out / "unclassified.fasta"))]
         assert got_un == unclassified
     assert exp["found"] >= 1  # the planted query is found
+    # createLog echo (configReader.cpp:98-200) and the run log
+    echo = (out / "configLog.toml").read_text()
+    assert "[build]" in echo and "[classify]" in echo and "kmer-size = 13" in echo and "chunk_length = 250" in echo
+    assert "classified" in (out / "logs" / "ReadBouncerLog.txt").read_text()
 
 
 @pytest.mark.gpu
