@@ -585,7 +585,7 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
             RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, fs));
             continue;
         }
-        if (Weff > 64 && (W % 2 == 0) && (a.col_begin % 2 == 0)) {
+        if (Weff > 64 && (a.col_begin % 2 == 0)) {  // 16 bytes per lane; odd widths end in a one-column lane
             a.wpl = 2; a.lg = 6;
         } else {
             a.wpl = 1; a.lg = 0;

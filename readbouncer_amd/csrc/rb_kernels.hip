@@ -185,13 +185,11 @@ __device__ __forceinline__ LaneCols<WPL> make_lane_cols(const IbfDev &f, int lan
     }
     lc.col_full = (col0 + WPL) <= col_end;
     lc.lane_base = f.words + col0;
-    // WPL == 2 is only dispatched for even W and even slice bounds, so a lane owns both words or none
-    const bool loadable = (WPL == 1) ? lc.colok : lc.col_full;
-    if (WPL == 2 && !lc.col_full) {
-        lc.colok = false;
-        for (int w = 0; w < WPL; ++w) lc.valid[w] = 0ULL;
-    }
-    lc.safe_base = loadable ? lc.lane_base : f.words;
+    // WPL == 2 with an odd column count: the last lane owns one column; its 16-byte load also fetches the word
+    // after it (next column of the block, or the first word past the block -- still inside the filter thanks to the
+    // 256 metadata bits at the tail) and valid[1] == 0 masks it.  Blocks of an odd-width filter are only 8-byte
+    // aligned: gfx950 executes 16-byte global loads at 8-byte alignment (checked on the device).
+    lc.safe_base = lc.colok ? lc.lane_base : f.words;
     return lc;
 }
 
@@ -339,16 +337,20 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
 template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
     IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
-    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
+    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
+    // work item = (read, column slice), slice fastest: the waves of a workgroup gather neighbouring parts of the same
+    // blocks at about the same time (DRAM page locality for wide filters)
+    const uint64_t item = (uint64_t)blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t read = (uint32_t)(item / n_slices);
+    const uint32_t slice = (uint32_t)(item - (uint64_t)read * n_slices);
     if (read >= n_reads) return;  // wave-uniform; there are no block-level barriers below
 
-    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, blockIdx.y);
+    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
     const uint32_t len = lens[read];
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     const uint8_t *seq = seqs + offsets[read];
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
         const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
         best = m > best ? m : best;
     }
-    if (lane == 0) out[(size_t)read * out_read_stride + (size_t)blockIdx.y * out_slice_stride] = (uint16_t)best;
+    if (lane == 0) out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)best;
 }
 
 // latency form for micro-batches: one workgroup per (read, column slice); wave w takes strand w&1 and every
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
     IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
-    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t col_begin, uint32_t col_end,
+    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -379,13 +381,14 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
     const int n_waves = blockDim.x >> 6;
     const int per_strand = n_waves >> 1;
     const int strand = wave & 1, slot = wave >> 1;
-    const uint32_t read = blockIdx.x;
+    const uint32_t read = blockIdx.x / n_slices;
+    const uint32_t slice = blockIdx.x - read * n_slices;
 
     uint64_t *s_planes = reinterpret_cast<uint64_t *>(s_dyn);  // [wave][WPL][NP][64]
     uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);
     uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
 
-    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, blockIdx.y);
+    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
     const uint32_t len = lens[read];
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     const uint8_t *seq = seqs + offsets[read];
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t a = s_max[0], b = s_max[1];
-        out[(size_t)read * out_read_stride + (size_t)blockIdx.y * out_slice_stride] = (uint16_t)(a > b ? a : b);
+        out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)(a > b ? a : b);
     }
 }
 
@@ -599,14 +602,15 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
             if (e != hipSuccess) return e;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
-        dim3 grid(a.n_reads, a.n_slices);
-        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.seqs, a.offsets, a.lens, a.n_reads, a.col_begin,
-                           a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
+        dim3 grid(a.n_reads * a.n_slices);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.seqs, a.offsets, a.lens, a.n_reads, a.n_slices,
+                           a.col_begin, a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
         return hipGetLastError();
     }
-    dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock, a.n_slices);
+    const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
+    dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock));
     hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.seqs,
-                       a.offsets, a.lens, a.n_reads, a.col_begin, a.col_end, a.out, a.out_read_stride,
+                       a.offsets, a.lens, a.n_reads, a.n_slices, a.col_begin, a.col_end, a.out, a.out_read_stride,
                        a.out_slice_stride);
     return hipGetLastError();
 }
