@@ -1,0 +1,68 @@
+"""Size-independent properties at BASELINE config-2 scale (0.41 GB filter, 10^5 reads), where the CPU oracle is too
+slow to check every read: strand symmetry, batch-partition invariance, order invariance, kernel-form invariance.
+A sample of the same batch is still compared with the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pyoracle as po
+from readbouncer_amd import capi, synth
+
+
+@pytest.fixture(scope="module")
+def c2():
+    w = synth.WORKLOADS["c2"]
+    d, ref = synth.build_device_filter(0, w, fill_seed=2, plant_seed=20)
+    buf, offs, lens = synth.make_reads(77, 100_000, 360, ref)
+    eng = capi.Engine(0, [d], [])
+    base = eng.classify(buf, offs, lens)
+    return d, eng, buf, offs, lens, base
+
+
+def test_strand_symmetry(c2):
+    # max over bins of max(fwd, rev) is invariant under reverse-complementing the read (IBFClassify.cpp:149-162)
+    d, eng, buf, offs, lens, base = c2
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
+    rc = comp[buf.reshape(-1, 360)[:, ::-1]].reshape(-1).copy()
+    got = eng.classify(rc, offs, lens)
+    assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2])
+    assert base[2].sum() > 40_000  # about half of the reads are planted positives
+
+
+def test_partition_and_order_invariance(c2):
+    d, eng, buf, offs, lens, base = c2
+    n = len(lens)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(n)
+    got = eng.classify(buf, offs[perm], lens[perm])  # same buffer, shuffled work order
+    assert np.array_equal(got[0], base[0][perm]) and np.array_equal(got[2], base[2][perm])
+    pos = 0
+    for size in (1, 7, 63, 64, 65, 2047, 2048, 2049, 30000):  # ragged batches across the latency/throughput switch
+        sl = slice(pos, pos + size)
+        g = eng.classify(buf, offs[sl], lens[sl])
+        assert np.array_equal(g[0], base[0][sl]) and np.array_equal(g[2], base[2][sl]), size
+        pos += size
+
+
+def test_kernel_forms_and_load_policies_agree(c2):
+    d, eng, buf, offs, lens, base = c2
+    sl = slice(0, 1500)
+    for split, nt in ((0, 512 << 20), (2048, 512 << 20), (0, 0), (2048, 0)):
+        eng.set_split_threshold(split)
+        eng.set_nt_threshold(nt)
+        g = eng.classify(buf, offs[sl], lens[sl])
+        assert np.array_equal(g[0], base[0][sl]) and np.array_equal(g[2], base[2][sl]), (split, nt)
+    eng.set_split_threshold(2048)
+    eng.set_nt_threshold(512 << 20)
+
+
+def test_sample_against_oracle(c2):
+    d, eng, buf, offs, lens, base = c2
+    host = d.download()
+    o = po.OracleIBF.wrap(host.info["n_bins"], 3, 13, host.info["n_bits"], host.words())
+    idx = np.random.default_rng(9).choice(len(lens), size=3000, replace=False)
+    exp_max = po.batch_raw_max(o, buf, offs[idx], lens[idx], 8)
+    exp_dec, _ = po.batch_check_unblock([o], [], buf, offs[idx], lens[idx], n_threads=8)
+    assert np.array_equal(base[0][idx, 0], exp_max) and np.array_equal(base[2][idx], exp_dec)
