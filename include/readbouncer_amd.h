@@ -161,9 +161,16 @@ RB_API int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *off
                              uint16_t *out_maxcount, int32_t *out_best_target, uint8_t *out_decision,
                              uint8_t *out_status);
 
+/* Pointer-array form of rb_classify_batch: read i = seq_ptrs[i][0 .. lens[i]) (one buffer per read, as a basecaller
+ * hands them over; the reference's RTPair carries one std::string per read, src/interfaces/ont_read.hpp:24-61). */
+RB_API int rb_classify_batch_ptrs(rb_engine *e, const char *const *seq_ptrs, const uint32_t *lens, size_t n_reads,
+                                  double error_rate, double significance, int mode, uint16_t *out_maxcount,
+                                  int32_t *out_best_target, uint8_t *out_decision, uint8_t *out_status);
+
 /* Same with every buffer already resident in HBM (device pointers) and asynchronous on
  * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
- * before returning).  max_len = an upper bound of lens[]. */
+ * before returning).  max_len = an upper bound of lens[].  The inputs must be complete on `stream`
+ * (work that produces them on another stream has to be ordered before this call by the caller). */
 RB_API int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens,
                                     size_t n_reads, uint32_t max_len, double error_rate, double significance,
                                     int mode, void *d_maxcount, void *d_best_target, void *d_decision,

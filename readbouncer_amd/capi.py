@@ -65,6 +65,7 @@ SIGNATURES = {
     "rb_engine_create": (_int, [_int, _pp, _sz, _pp, _sz, _pp]),
     "rb_engine_destroy": (None, [_vp]),
     "rb_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_classify_batch_ptrs": (_int, [_vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
@@ -285,6 +286,22 @@ class Engine:
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
         _check(lib().rb_classify_batch(self.h, _ptr(seqs), _ptr(offsets), _ptr(lens), n, error_rate, significance, mode,
                                        _ptr(maxcount), _ptr(best), _ptr(decision), _ptr(status)), "rb_classify_batch")
+        return maxcount, best, decision, status
+
+    def classify_reads(self, reads, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
+        """list of bytes objects (one buffer per read) through rb_classify_batch_ptrs"""
+        n = len(reads)
+        nf = self.nd + self.nt
+        keep = [r.encode() if isinstance(r, str) else r for r in reads]
+        ptrs = (C.c_char_p * max(1, n))(*keep)
+        lens = np.array([len(r) for r in keep], dtype=np.uint32)
+        maxcount = np.zeros((n, nf), dtype=np.uint16)
+        best = np.full(n, -1, dtype=np.int32)
+        decision = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint8)
+        _check(lib().rb_classify_batch_ptrs(self.h, C.cast(ptrs, C.c_void_p), _ptr(lens), n, error_rate, significance, mode,
+                                            _ptr(maxcount), _ptr(best), _ptr(decision), _ptr(status)),
+               "rb_classify_batch_ptrs")
         return maxcount, best, decision, status
 
     def classify_device(self, d_seqs, d_offsets, d_lens, n_reads, max_len, error_rate=0.1, significance=0.95,

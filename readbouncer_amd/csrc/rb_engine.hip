@@ -741,4 +741,30 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
     return RB_OK;
 }
 
+// pointer-array form: read i = seq_ptrs[i][0 .. lens[i]) -- what a basecaller hands over (one buffer per read)
+int rb_classify_batch_ptrs(rb_engine *e, const char *const *seq_ptrs, const uint32_t *lens, size_t n_reads,
+                           double error_rate, double significance, int mode, uint16_t *out_maxcount,
+                           int32_t *out_best_target, uint8_t *out_decision, uint8_t *out_status)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    if (n_reads == 0) return RB_OK;
+    if (!seq_ptrs || !lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
+    // the reads are gathered once on the host; rb_classify_batch then stages them (pinned, one copy) or copies the block
+    uint64_t sum = 0;
+    for (size_t i = 0; i < n_reads; ++i) {
+        if (lens[i] && !seq_ptrs[i]) return rb::fail(RB_ERR_INVALID_ARG, "null read pointer");
+        sum += lens[i];
+    }
+    std::vector<char> flat((size_t)sum + 1);
+    std::vector<uint64_t> offsets(n_reads);
+    uint64_t pos = 0;
+    for (size_t i = 0; i < n_reads; ++i) {
+        offsets[i] = pos;
+        if (lens[i]) std::memcpy(flat.data() + pos, seq_ptrs[i], lens[i]);
+        pos += lens[i];
+    }
+    return rb_classify_batch(e, flat.data(), offsets.data(), lens, n_reads, error_rate, significance, mode, out_maxcount,
+                             out_best_target, out_decision, out_status);
+}
+
 }  // extern "C"

@@ -317,6 +317,10 @@ def test_host_api_micro_and_large_paths():
     assert np.array_equal(mc[:, 0], po.batch_raw_max(o, pool, offs, lens, 4))
     edec, est = po.batch_check_unblock([o], [], pool, offs, lens, n_threads=4)
     assert np.array_equal(dec, edec) and np.array_equal(st, est)
+    # pointer-array form (one buffer per read)
+    reads = [bytes(pool[int(o):int(o) + int(l)]) for o, l in zip(offs[:200], lens[:200])]
+    mc2, _, dec2, st2 = eng.classify_reads(reads)
+    assert np.array_equal(mc2, mc[:200]) and np.array_equal(dec2, dec[:200]) and np.array_equal(st2, st[:200])
     # large: > 8 MB of read bytes
     n = 32000
     offs = rng.integers(1000, len(pool) - 300, size=n).astype(np.uint64)
