@@ -176,6 +176,37 @@ RB_API int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void
                                     int mode, void *d_maxcount, void *d_best_target, void *d_decision,
                                     void *d_status, void *stream);
 
+/* Descriptor form of the device entry point: packed reads and on-GPU chunking.
+ *   d_nmask != NULL : d_seqs holds 2 bits per base (A0 C1 G2 T3; base i of a read in bits 2*(i&3) of byte i>>2 of the
+ *                     read's payload, d_offsets[] = byte offset of that payload) and d_nmask an N bitmap (bit i&7 of
+ *                     byte i>>3, d_nmask_offsets[]); a flagged base is hashed as Dna5 ordinal 4 exactly like an
+ *                     'N' in ASCII input.  rb_pack_reads builds both arrays on the host.
+ *   chunk_start / chunk_length : classify bases [chunk_start, min(chunk_start+chunk_length, len)) of every read
+ *                     (chunk_length 0 = to the end) -- chunk i of classify_reads is chunk_start = i*chunk_length
+ *                     (src/main/classify.hpp:264-271); reads uploaded once serve every chunk iteration.  A chunk that
+ *                     starts beyond the read's end gets status RB_ERR_BAD_CHUNK.
+ *   d_read_ids      : optional u32[n_items]: work item j classifies read d_read_ids[j] (the reads still unclassified
+ *                     after the previous chunk); outputs are indexed by work item.  d_lens/d_offsets stay per read. */
+typedef struct rb_batch_desc {
+    const void *d_seqs;
+    const void *d_offsets;        /* u64 per read */
+    const void *d_lens;           /* u32 per read: full read lengths */
+    size_t n_items;               /* work items (= reads unless d_read_ids is given) */
+    uint32_t max_len;             /* upper bound of the full read lengths */
+    const void *d_nmask;          /* NULL = ASCII input */
+    const void *d_nmask_offsets;  /* u64 per read */
+    uint32_t chunk_start;
+    uint32_t chunk_length;
+    const void *d_read_ids;       /* NULL = identity */
+} rb_batch_desc;
+RB_API int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance,
+                                       int mode, void *d_maxcount, void *d_best_target, void *d_decision,
+                                       void *d_status, void *stream);
+/* host helper for the packed form; call once with packed == NULL to obtain the sizes and offsets */
+RB_API int rb_pack_reads(const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n_reads, uint8_t *packed,
+                         uint64_t *packed_offsets, uint8_t *nmask, uint64_t *nmask_offsets, uint64_t *packed_bytes,
+                         uint64_t *nmask_bytes);
+
 /* bin-sharded operation: restrict the engine to word columns
  * [rank*ceil(W/world) , ...) of every block; out_maxcount then holds PARTIAL maxima that the
  * caller combines with an all-reduce(max) before rb_decide_device. world=1 restores the default. */

@@ -18,6 +18,12 @@ LIB_PATH = os.path.join(_HERE, "libreadbouncer_amd.so")
 RB_MODE_CHECK_UNBLOCK, RB_MODE_CLASSIFY_CHUNK = 0, 1
 
 
+class BatchDesc(C.Structure):
+    _fields_ = [("d_seqs", C.c_void_p), ("d_offsets", C.c_void_p), ("d_lens", C.c_void_p), ("n_items", C.c_size_t),
+                ("max_len", C.c_uint32), ("d_nmask", C.c_void_p), ("d_nmask_offsets", C.c_void_p),
+                ("chunk_start", C.c_uint32), ("chunk_length", C.c_uint32), ("d_read_ids", C.c_void_p)]
+
+
 class IbfInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("n_bins", "n_hash", "kmer_size", "n_bits", "bin_width", "n_blocks", "n_words")]
@@ -66,6 +72,8 @@ SIGNATURES = {
     "rb_engine_destroy": (None, [_vp]),
     "rb_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_classify_batch_ptrs": (_int, [_vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_classify_batch_device_ex": (_int, [_vp, C.POINTER(BatchDesc), _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
+    "rb_pack_reads": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
@@ -312,6 +320,15 @@ class Engine:
                                               significance, mode, d_maxcount, d_best, d_decision, d_status, stream),
                "rb_classify_batch_device")
 
+    def classify_device_ex(self, d_seqs, d_offsets, d_lens, n_items, max_len, d_nmask=None, d_nmask_offsets=None,
+                           chunk_start=0, chunk_length=0, d_read_ids=None, error_rate=0.1, significance=0.95,
+                           mode=RB_MODE_CHECK_UNBLOCK, d_maxcount=None, d_best=None, d_decision=None, d_status=None,
+                           stream=None):
+        desc = BatchDesc(d_seqs, d_offsets, d_lens, n_items, max_len, d_nmask, d_nmask_offsets, chunk_start, chunk_length,
+                         d_read_ids)
+        _check(lib().rb_classify_batch_device_ex(self.h, C.byref(desc), error_rate, significance, mode, d_maxcount, d_best,
+                                                 d_decision, d_status, stream), "rb_classify_batch_device_ex")
+
     def decide_device(self, d_maxcount, d_lens, n_reads, max_len, error_rate=0.1, significance=0.95,
                       mode=RB_MODE_CHECK_UNBLOCK, d_best=None, d_decision=None, d_status=None, stream=None):
         _check(lib().rb_decide_device(self.h, d_maxcount, d_lens, n_reads, max_len, error_rate, significance, mode,
@@ -444,6 +461,23 @@ class Live:
             self.destroy()
         except Exception:
             pass
+
+
+def pack_reads(seqs, offsets, lens):
+    """ASCII batch -> (packed uint8, packed_offsets uint64, nmask uint8, nmask_offsets uint64)"""
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    n = len(lens)
+    po_, no_ = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    pb, nb = C.c_uint64(0), C.c_uint64(0)
+    _check(lib().rb_pack_reads(_ptr(seqs), _ptr(offsets), _ptr(lens), n, None, _ptr(po_), None, _ptr(no_), C.byref(pb),
+                               C.byref(nb)), "rb_pack_reads")
+    packed = np.zeros(max(1, pb.value), dtype=np.uint8)
+    nmask = np.zeros(max(1, nb.value), dtype=np.uint8)
+    _check(lib().rb_pack_reads(_ptr(seqs), _ptr(offsets), _ptr(lens), n, _ptr(packed), _ptr(po_), _ptr(nmask), _ptr(no_),
+                               None, None), "rb_pack_reads")
+    return packed, po_, nmask, no_
 
 
 def threshold(readlen, k, error_rate=0.1, significance=0.95):

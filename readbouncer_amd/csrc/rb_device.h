@@ -21,12 +21,21 @@ struct IbfDev {
     uint32_t n_hash;
 };
 
+// where the bases of a batch live (by-value kernel argument)
+struct ReadSrc {
+    const uint8_t *seqs;            // ASCII bytes, or the 2-bit payload when nmask != nullptr
+    const uint64_t *offsets;        // per READ: byte offset of its bases / of its packed payload
+    const uint32_t *lens;           // per ITEM: effective length (whole read, or the chunk after chunk_prep)
+    const uint8_t *nmask;           // packed input only: N bitmap payload
+    const uint64_t *nmask_offsets;  // per READ: byte offset of its N bitmap
+    const uint32_t *ids;            // optional item -> read indirection (nullptr = identity)
+    uint32_t base_off;              // bases skipped at the start of every read (chunk start)
+};
+
 struct CountLaunch {
     IbfDev f;
-    const uint8_t *seqs;
-    const uint64_t *offsets;
-    const uint32_t *lens;
-    uint32_t n_reads;
+    ReadSrc src;
+    uint32_t n_reads;               // number of work items
     uint32_t col_begin, col_end;  // word columns of every block this launch covers
     uint32_t n_slices;            // column slices of 2^lg * wpl words
     int lg, wpl, planes;
@@ -47,8 +56,11 @@ hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
 hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,
                                 uint32_t nf, uint32_t fidx, hipStream_t st);
-hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, uint32_t n_reads,
-                         int mode, int32_t *best_target, uint8_t *decision, uint8_t *status, hipStream_t st);
+hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, const uint8_t *pre_status,
+                         uint32_t n_reads, int mode, int32_t *best_target, uint8_t *decision, uint8_t *status,
+                         hipStream_t st);
+hipError_t launch_chunk_prep(const uint32_t *lens, const uint32_t *ids, uint32_t n_items, uint32_t chunk_start,
+                             uint32_t chunk_len, uint32_t *eff_lens, uint8_t *pre_status, hipStream_t st);
 hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,
                          const uint64_t *ends, const uint64_t *bins, const uint64_t *kmer_prefix,
                          uint32_t n_fragments, uint64_t total_kmers, hipStream_t st);

@@ -107,6 +107,7 @@ struct rb_engine {
     bool overlap = true;
     // staging for the host-pointer API
     DevBuf d_seqs, d_offsets, d_lens, d_best, d_decision, d_status;
+    DevBuf d_efflens, d_prestatus;  // on-GPU chunking: effective lengths and the bad-chunk status per item
     PinnedBuf h_in, h_out;
     std::mutex mu;
 };
@@ -408,7 +409,7 @@ void rb_engine_destroy(rb_engine *e)
     for (hipEvent_t ev : e->join_ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     for (DevBuf &b : e->d_parts) b.release();
-    for (DevBuf *b : {&e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+    for (DevBuf *b : {&e->d_efflens, &e->d_prestatus, &e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
     e->h_in.release();
@@ -506,9 +507,9 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     return RB_OK;
 }
 
-static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, size_t n_reads, uint32_t max_len,
-                      double r, double conf, int mode, int32_t *d_best, uint8_t *d_decision, uint8_t *d_status,
-                      hipStream_t st)
+static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
+                      size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
+                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st)
 {
     int rc = ensure_thresholds(e, max_len, r, conf, st);
     if (rc != RB_OK) return rc;
@@ -518,7 +519,7 @@ static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *
     for (size_t i = 0; i < e->filters.size(); ++i) P.k[i] = (uint32_t)e->filters[i]->geo.kmer_size;
     P.thr = (const uint16_t *)e->d_thr.p;
     P.thr_len = e->thr_len;
-    RB_HIP(launch_decide(P, d_maxcount, d_lens, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
+    RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
 }
 
@@ -528,16 +529,50 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
                              uint32_t max_len, double error_rate, double significance, int mode, void *d_maxcount,
                              void *d_best_target, void *d_decision, void *d_status, void *stream)
 {
-    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    rb_batch_desc desc;
+    std::memset(&desc, 0, sizeof desc);
+    desc.d_seqs = d_seqs;
+    desc.d_offsets = d_offsets;
+    desc.d_lens = d_lens;
+    desc.n_items = n_reads;
+    desc.max_len = max_len;
+    return rb_classify_batch_device_ex(e, &desc, error_rate, significance, mode, d_maxcount, d_best_target, d_decision,
+                                       d_status, stream);
+}
+
+int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
+                                void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream)
+{
+    if (!e || !desc) return rb::fail(RB_ERR_INVALID_ARG, "null engine or descriptor");
     if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK) return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
+    const size_t n_reads = desc->n_items;
     if (n_reads >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "batch too large");
     if (n_reads == 0) return RB_OK;
-    if (!d_seqs || !d_offsets || !d_lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
+    const void *d_seqs = desc->d_seqs, *d_offsets = desc->d_offsets;
+    if (!d_seqs || !d_offsets || !desc->d_lens) return rb::fail(RB_ERR_INVALID_ARG, "null input buffer");
+    if ((desc->d_nmask == nullptr) != (desc->d_nmask_offsets == nullptr))
+        return rb::fail(RB_ERR_INVALID_ARG, "packed input needs both the N bitmap and its offsets");
     std::lock_guard<std::mutex> lock(e->mu);
     int rc = check_device(e->device);
     if (rc != RB_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     const size_t nf = e->filters.size();
+    // on-GPU chunking / read indirection: effective per-item lengths (+ the bad-chunk status) are made on the device
+    const bool chunked = desc->chunk_start != 0 || desc->chunk_length != 0 || desc->d_read_ids != nullptr;
+    const void *d_lens = desc->d_lens;
+    const uint8_t *d_pre_status = nullptr;
+    uint32_t max_len = desc->max_len;
+    if (chunked) {
+        rc = e->d_efflens.ensure(n_reads * 4);
+        if (rc == RB_OK) rc = e->d_prestatus.ensure(n_reads);
+        if (rc != RB_OK) return rc;
+        RB_HIP(launch_chunk_prep((const uint32_t *)desc->d_lens, (const uint32_t *)desc->d_read_ids, (uint32_t)n_reads,
+                                 desc->chunk_start, desc->chunk_length, (uint32_t *)e->d_efflens.p,
+                                 (uint8_t *)e->d_prestatus.p, st));
+        d_lens = e->d_efflens.p;
+        d_pre_status = (const uint8_t *)e->d_prestatus.p;
+        if (desc->chunk_length && desc->chunk_length < max_len) max_len = desc->chunk_length;
+    }
 
     uint16_t *maxcount = (uint16_t *)d_maxcount;
     if (!maxcount) {
@@ -566,9 +601,13 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
         hipStream_t fs = (fan_out && fi > 0) ? e->aux[(fi - 1) % e->aux.size()] : st;
         CountLaunch a{};
         a.f = f->dev;
-        a.seqs = (const uint8_t *)d_seqs;
-        a.offsets = (const uint64_t *)d_offsets;
-        a.lens = (const uint32_t *)d_lens;
+        a.src.seqs = (const uint8_t *)d_seqs;
+        a.src.offsets = (const uint64_t *)d_offsets;
+        a.src.lens = (const uint32_t *)d_lens;
+        a.src.nmask = (const uint8_t *)desc->d_nmask;
+        a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
+        a.src.ids = (const uint32_t *)desc->d_read_ids;
+        a.src.base_off = desc->chunk_start;
         a.n_reads = (uint32_t)n_reads;
         const uint32_t W = (uint32_t)f->geo.bin_width;
         // bin-sharded operation: contiguous word-column range of every block per rank
@@ -620,8 +659,8 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
     }
     if (evp) RB_HIP(hipEventRecord(evp->second, st));
     if (e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
-        rc = run_decide(e, maxcount, (const uint32_t *)d_lens, n_reads, max_len, error_rate, significance, mode,
-                        (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+        rc = run_decide(e, maxcount, (const uint32_t *)d_lens, d_pre_status, n_reads, max_len, error_rate, significance,
+                        mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
         if (rc != RB_OK) return rc;
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
@@ -638,8 +677,8 @@ int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, s
     int rc = check_device(e->device);
     if (rc != RB_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
-    rc = run_decide(e, (const uint16_t *)d_maxcount, (const uint32_t *)d_lens, n_reads, max_len, error_rate, significance,
-                    mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+    rc = run_decide(e, (const uint16_t *)d_maxcount, (const uint32_t *)d_lens, nullptr, n_reads, max_len, error_rate,
+                    significance, mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
     if (rc != RB_OK) return rc;
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     return RB_OK;

@@ -313,6 +313,35 @@ size_t rb_cut_out_nnns(const char *seq, size_t len, char *out)
     return n;
 }
 
+// 2-bit payload + N bitmap of a batch; every read starts at a byte boundary in both arrays
+int rb_pack_reads(const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n_reads, uint8_t *packed,
+                  uint64_t *packed_offsets, uint8_t *nmask, uint64_t *nmask_offsets, uint64_t *packed_bytes,
+                  uint64_t *nmask_bytes)
+{
+    if (n_reads && (!seqs || !offsets || !lens)) return fail(RB_ERR_INVALID_ARG, "null input buffer");
+    uint64_t pp = 0, np = 0;
+    for (size_t r = 0; r < n_reads; ++r) {
+        const uint64_t pb = ((uint64_t)lens[r] + 3) / 4, nb = ((uint64_t)lens[r] + 7) / 8;
+        if (packed_offsets) packed_offsets[r] = pp;
+        if (nmask_offsets) nmask_offsets[r] = np;
+        if (packed && nmask) {
+            std::memset(packed + pp, 0, pb);
+            std::memset(nmask + np, 0, nb);
+            const unsigned char *s = (const unsigned char *)seqs + offsets[r];
+            for (uint32_t i = 0; i < lens[r]; ++i) {
+                const uint32_t o = rbspec::dna5_ord(s[i]);
+                if (o < 4) packed[pp + (i >> 2)] |= (uint8_t)(o << ((i & 3u) << 1));
+                else nmask[np + (i >> 3)] |= (uint8_t)(1u << (i & 7u));
+            }
+        }
+        pp += pb;
+        np += nb;
+    }
+    if (packed_bytes) *packed_bytes = pp;
+    if (nmask_bytes) *nmask_bytes = np;
+    return RB_OK;
+}
+
 size_t rb_fragment_bounds(uint64_t len, uint64_t fragment_length, uint64_t kmer_size, uint64_t overlap_length,
                           uint64_t *starts, uint64_t *ends, size_t cap)
 {

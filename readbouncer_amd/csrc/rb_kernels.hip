@@ -193,11 +193,27 @@ __device__ __forceinline__ LaneCols<WPL> make_lane_cols(const IbfDev &f, int lan
     return lc;
 }
 
+// Bases of one read as the kernel sees them: ASCII bytes (nm == nullptr) or the packed form of SURVEY 8f.4 --
+// 2 bits per base (A0 C1 G2 T3; base i in bits 2*(i&3) of byte i>>2) plus an N bitmap (bit i&7 of byte i>>3) that
+// turns a base into Dna5 ordinal 4.  `first` = bases skipped at the start of the read (on-GPU chunking).
+struct BaseSrc {
+    const uint8_t *bytes;  // ASCII: already advanced to the first base; packed: start of the read's 2-bit payload
+    const uint8_t *nm;     // packed: start of the read's N bitmap; ASCII: nullptr
+    uint32_t first;        // packed: index of the first base of the chunk inside the read
+    __device__ __forceinline__ uint32_t ord(uint32_t i) const
+    {
+        if (nm == nullptr) return rbspec::dna5_ord(bytes[i]);
+        const uint32_t b = first + i;
+        const uint32_t code = (bytes[b >> 2] >> ((b & 3u) << 1)) & 3u;
+        return ((nm[b >> 3] >> (b & 7u)) & 1u) ? 4u : code;
+    }
+};
+
 // Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
 // mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves).
 template <int LG, int WPL, int NP, int H, bool NT>
 __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
-                                             const uint8_t *__restrict__ seq, uint32_t len, uint32_t n, int strand,
+                                             const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
                                              uint32_t mt_first, uint32_t mt_step, uint8_t *stage, int lane)
 {
     using T = TileShape<LG>;
@@ -211,7 +227,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
         // ---- stage the bases of this macro tile as Dna5 ordinals ((Dna5String) conversion)
         const uint32_t wlen = min((uint32_t)(ITEMS + k - 1), len - mt);
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t i = lane; i < wlen; i += 64) stage[i] = (uint8_t)rbspec::dna5_ord(seq[mt + i]);
+        for (uint32_t i = lane; i < wlen; i += 64) stage[i] = (uint8_t)seq.ord(mt + i);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
 
@@ -333,11 +349,27 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
     }
 }
 
+__device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item, uint32_t *len_out)
+{
+    const uint32_t rid = r.ids ? r.ids[item] : item;
+    *len_out = r.lens[item];  // effective length of this work item (chunked or whole read)
+    BaseSrc b;
+    if (r.nmask) {
+        b.bytes = r.seqs + r.offsets[rid];
+        b.nm = r.nmask + r.nmask_offsets[rid];
+        b.first = r.base_off;
+    } else {
+        b.bytes = r.seqs + r.offsets[rid] + r.base_off;
+        b.nm = nullptr;
+        b.first = 0;
+    }
+    return b;
+}
+
 // throughput form: one wave per (read, column slice), both strands in sequence
 template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
-    IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
-    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
+    IbfDev f, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
@@ -351,9 +383,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
     if (read >= n_reads) return;  // wave-uniform; there are no block-level barriers below
 
     const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
-    const uint32_t len = lens[read];
+    uint32_t len;
+    const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
-    const uint8_t *seq = seqs + offsets[read];
 
     uint32_t best = 0;
     for (int strand = 0; strand < 2; ++strand) {
@@ -371,8 +403,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 // (blockDim/128)-th macro tile starting at w>>1.  Partial counters meet in LDS (bit-sliced adds), then max.
 template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
-    IbfDev f, const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offsets,
-    const uint32_t *__restrict__ lens, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
+    IbfDev f, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
     uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
@@ -389,9 +420,9 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
     uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
 
     const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
-    const uint32_t len = lens[read];
+    uint32_t len;
+    const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
-    const uint8_t *seq = seqs + offsets[read];
     constexpr uint32_t ITEMS = TileShape<LG>::ITEMS;
 
     Planes<NP> pl[WPL];
@@ -447,13 +478,35 @@ __global__ void reduce_slices_kernel(const uint16_t *__restrict__ part, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// on-GPU chunking (classify.hpp:264-271): work item i looks at bases [chunk_start, min(chunk_start+chunk_len, len)) of
+// its read; a chunk that starts beyond the read's end is the reference's undefined infix -> RB_ERR_BAD_CHUNK
+__global__ void chunk_prep_kernel(const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ids, uint32_t n_items,
+                                  uint32_t chunk_start, uint32_t chunk_len, uint32_t *__restrict__ eff_lens,
+                                  uint8_t *__restrict__ pre_status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t len = lens[ids ? ids[i] : i];
+    const bool bad = chunk_start > len;
+    const uint32_t rest = bad ? 0u : len - chunk_start;
+    eff_lens[i] = (chunk_len && chunk_len < rest) ? chunk_len : rest;
+    pre_status[i] = bad ? (uint8_t)RB_ERR_BAD_CHUNK : (uint8_t)RB_OK;
+}
+
 // K2: one thread per read.
 __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxcount, const uint32_t *__restrict__ lens,
-                              uint32_t n_reads, int mode, int32_t *__restrict__ out_best_target,
-                              uint8_t *__restrict__ out_decision, uint8_t *__restrict__ out_status)
+                              const uint8_t *__restrict__ pre_status, uint32_t n_reads, int mode,
+                              int32_t *__restrict__ out_best_target, uint8_t *__restrict__ out_decision,
+                              uint8_t *__restrict__ out_status)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
+    if (pre_status && pre_status[i] != RB_OK) {  // e.g. a chunk beyond the end of the read: no decision
+        if (out_best_target) out_best_target[i] = -1;
+        if (out_decision) out_decision[i] = 0;
+        if (out_status) out_status[i] = pre_status[i];
+        return;
+    }
     const uint32_t len = lens[i];
     const uint32_t nf = P.nd + P.nt;
     const uint32_t tl = len < P.thr_len ? len : P.thr_len - 1;  // host guarantees len < thr_len
@@ -603,15 +656,14 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
             attr_done.fetch_or(bit, std::memory_order_release);
         }
         dim3 grid(a.n_reads * a.n_slices);
-        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.seqs, a.offsets, a.lens, a.n_reads, a.n_slices,
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.src, a.n_reads, a.n_slices,
                            a.col_begin, a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
         return hipGetLastError();
     }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
     dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock));
-    hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.seqs,
-                       a.offsets, a.lens, a.n_reads, a.n_slices, a.col_begin, a.col_end, a.out, a.out_read_stride,
-                       a.out_slice_stride);
+    hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.src,
+                       a.n_reads, a.n_slices, a.col_begin, a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
     return hipGetLastError();
 }
 
@@ -671,12 +723,22 @@ hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, uint32_t n_reads,
-                         int mode, int32_t *best_target, uint8_t *decision, uint8_t *status, hipStream_t st)
+hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, const uint8_t *pre_status,
+                         uint32_t n_reads, int mode, int32_t *best_target, uint8_t *decision, uint8_t *status,
+                         hipStream_t st)
 {
     if (n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(decide_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, P, maxcount, lens, n_reads, mode,
-                       best_target, decision, status);
+    hipLaunchKernelGGL(decide_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, P, maxcount, lens, pre_status, n_reads,
+                       mode, best_target, decision, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_chunk_prep(const uint32_t *lens, const uint32_t *ids, uint32_t n_items, uint32_t chunk_start,
+                             uint32_t chunk_len, uint32_t *eff_lens, uint8_t *pre_status, hipStream_t st)
+{
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(chunk_prep_kernel, dim3((n_items + 255) / 256), dim3(256), 0, st, lens, ids, n_items, chunk_start,
+                       chunk_len, eff_lens, pre_status);
     return hipGetLastError();
 }
 

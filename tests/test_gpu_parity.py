@@ -469,3 +469,89 @@ def test_resize_bins_and_update(old_bins, new_bins):
     assert np.array_equal(mc, po.batch_raw_max(o2, buf, offs, lens))
     with pytest.raises(capi.RBError):
         d2.resize_bins(new_bins - 1)
+
+
+def test_packed_reads_and_on_gpu_chunking():
+    """2-bit + N-bitmap reads and chunk selection on the device (classify.hpp:262-271) give exactly what the
+    ASCII path gives on the sliced strings; read-id indirection covers the 'still unclassified' subset of a chunk loop."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(19)
+    ref = H.random_dna(rng, 30000)
+    dep = capi.DeviceIBF.create(0, 300, 3, 13, 320 * 50021)
+    tgt = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 200003)
+    dep.add_sequence(ref[:15000], 500)
+    tgt.add_sequence(ref[15000:], 500)
+    od, _k1 = oracle_view(dep)
+    ot, _k2 = oracle_view(tgt)
+    reads = make_reads(rng, ref, 300, lo=5, hi=1500, err=0.1, n_frac=0.3)
+    reads += ["", "ACGTN", "n" * 400, ref[100:460].lower(), ref[20000:20360].replace("T", "U")]
+    buf, offs, lens = H.pack_reads(reads)
+    n = len(reads)
+    eng = capi.Engine(0, [dep], [tgt])
+    packed, p_off, nmask, n_off = capi.pack_reads(buf, offs, lens)
+    assert len(packed) < len(buf) // 3 + n  # ~4x smaller payload
+    dev = torch.device("cuda:0")
+    up = lambda a, dt: torch.from_numpy(a.view(dt)).to(dev)
+    t_buf, t_offs, t_lens = up(buf, np.uint8), up(offs, np.int64), up(lens, np.int32)
+    t_pk, t_poff, t_nm, t_noff = up(packed, np.uint8), up(p_off, np.int64), up(nmask, np.uint8), up(n_off, np.int64)
+    max_len = int(lens.max())
+
+    def run(packed_input, chunk_start, chunk_length, ids=None, mode=capi.RB_MODE_CLASSIFY_CHUNK):
+        m = n if ids is None else len(ids)
+        t_ids = None if ids is None else torch.from_numpy(ids.astype(np.int32)).to(dev)
+        t_mc = torch.zeros((m, 2), dtype=torch.int16, device=dev)
+        t_best = torch.zeros(m, dtype=torch.int32, device=dev)
+        t_dec = torch.zeros(m, dtype=torch.uint8, device=dev)
+        t_st = torch.zeros(m, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.classify_device_ex(t_pk.data_ptr() if packed_input else t_buf.data_ptr(),
+                               t_poff.data_ptr() if packed_input else t_offs.data_ptr(), t_lens.data_ptr(), m, max_len,
+                               d_nmask=t_nm.data_ptr() if packed_input else None,
+                               d_nmask_offsets=t_noff.data_ptr() if packed_input else None,
+                               chunk_start=chunk_start, chunk_length=chunk_length,
+                               d_read_ids=None if ids is None else t_ids.data_ptr(), mode=mode,
+                               d_maxcount=t_mc.data_ptr(), d_best=t_best.data_ptr(), d_decision=t_dec.data_ptr(),
+                               d_status=t_st.data_ptr())
+        torch.cuda.synchronize()
+        return (t_mc.cpu().numpy().view(np.uint16), t_best.cpu().numpy(), t_dec.cpu().numpy(), t_st.cpu().numpy())
+
+    # whole reads: packed == ASCII == oracle
+    whole = eng.classify(buf, offs, lens, mode=capi.RB_MODE_CLASSIFY_CHUNK)
+    for packed_input in (False, True):
+        got = run(packed_input, 0, 0)
+        for a, b in zip(got, whole):
+            assert np.array_equal(a, b)
+    assert np.array_equal(whole[0][:, 0], po.batch_raw_max(od, buf, offs, lens, 4))
+    assert np.array_equal(whole[0][:, 1], po.batch_raw_max(ot, buf, offs, lens, 4))
+
+    # chunk c of length L, as classify_reads forms it
+    for L in (250, 360):
+        for c in range(0, 5):
+            frags, bad = [], np.zeros(n, dtype=bool)
+            for i, r in enumerate(reads):
+                s, e = c * L, min((c + 1) * L, len(r))
+                bad[i] = s > e
+                frags.append("" if bad[i] else r[s:e])
+            fb, fo, fl = H.pack_reads(frags)
+            exp = eng.classify(fb, fo, fl, mode=capi.RB_MODE_CLASSIFY_CHUNK)
+            for packed_input in (False, True):
+                mc, best, dec, st = run(packed_input, c * L, L)
+                ok = ~bad
+                assert np.array_equal(mc[ok], exp[0][ok]) and np.array_equal(best[ok], exp[1][ok])
+                assert np.array_equal(dec[ok], exp[2][ok]) and np.array_equal(st[ok], exp[3][ok])
+                assert (st[bad] == capi.RB_ERR_BAD_CHUNK).all() and not dec[bad].any()
+            # against the oracle's chunk driver semantics for this very chunk
+            for i in rng.choice(n, size=40, replace=False):
+                if bad[i] or len(frags[i]) == 0:
+                    continue
+                res = po.classify_read_chunks([od], [ot], frags[i], len(frags[i]), 1)
+                assert res["status"] == st[i] and res["classified"] == bool(dec[i])
+
+    # the 'still unclassified' subset through read ids (check_unblock mode this time)
+    ids = np.sort(rng.choice(n, size=77, replace=False)).astype(np.uint32)
+    sub_b, sub_o, sub_l = H.pack_reads([reads[i][360:720] for i in ids if len(reads[i]) >= 360])
+    keep = np.array([i for i in ids if len(reads[i]) >= 360], dtype=np.uint32)
+    exp = eng.classify(sub_b, sub_o, sub_l)
+    got = run(True, 360, 360, ids=keep, mode=capi.RB_MODE_CHECK_UNBLOCK)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
