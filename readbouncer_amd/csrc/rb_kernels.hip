@@ -299,6 +299,10 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                             }
                         }
                     }
+                    // every gather of the batch is issued before the first one is consumed: without this fence the
+                    // scheduler sinks loads next to their uses to save registers (seen in the ISA: vmcnt(3) instead
+                    // of vmcnt(11..23)) and the wave is back to a few gathers in flight
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int uu = 0; uu < HALF; ++uu) {
 #pragma unroll
