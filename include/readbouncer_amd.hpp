@@ -185,6 +185,36 @@ struct RefSeq
 class IBF
 {
     TIbf filter{};
+
+    // add_sequences_to_filter (IBFBuild.cpp:143-215) for every queued sequence in ONE device call: the fragments
+    // of all sequences (reference fragmenter, bins numbered consecutively across sequences) go into one table, the
+    // sequences into one buffer -- a reference of 100 000 contigs costs one launch, not 100 000
+    void insert_all(const std::vector<std::string>& cleaned, const IBFConfig& config, uint64_t first_bin)
+    {
+        std::string all;
+        size_t total = 0;
+        for (const std::string& c : cleaned) total += c.size();
+        all.reserve(total);
+        std::vector<uint64_t> starts, ends, bins, s, e;
+        uint64_t binid = first_bin;
+        for (const std::string& c : cleaned) {
+            const size_t n = rb_fragment_bounds(c.size(), config.fragment_length, config.kmer_size, config.overlap_length,
+                                                nullptr, nullptr, 0);
+            s.resize(n);
+            e.resize(n);
+            rb_fragment_bounds(c.size(), config.fragment_length, config.kmer_size, config.overlap_length, s.data(), e.data(), n);
+            for (size_t i = 0; i < n; ++i) {
+                starts.push_back(all.size() + s[i]);
+                ends.push_back(all.size() + e[i]);
+                bins.push_back(binid++);
+            }
+            all += c;
+        }
+        const int st = rb_dibf_insert(filter.handle(), all.data(), all.size(), starts.data(), ends.data(), bins.data(),
+                                      starts.size());
+        if (st != RB_OK) throw InsertSequenceException(std::string("Error inserting the sequences to the IBF: ") + rb_last_error());
+    }
+
 public:
     // IBF::load_filter, IBFBuild.cpp:329-396: input_filter_file or update_filter_file must be set
     FilterStats load_filter(IBFConfig& config)
@@ -230,12 +260,7 @@ public:
             throw NullFilterException("Could not instantiate IBF Filter");
         }
         stats.totalBinsFile = (uint32_t)getNumberOfBins(filter);
-        uint64_t binid = 0;
-        for (const std::string& c : cleaned) {
-            const int st = rb_dibf_add_sequence(filter.handle(), c.data(), c.size(), config.fragment_length,
-                                                config.overlap_length, binid, &binid);
-            if (st != RB_OK) throw InsertSequenceException(std::string("Error inserting a sequence to the IBF: ") + rb_last_error());
-        }
+        insert_all(cleaned, config, 0);
         if (!config.output_filter_file.empty()) filter.store(config.output_filter_file);
         return stats;
     }
@@ -265,12 +290,7 @@ public:
             stats.newBins = stats.totalBinsBinId;
             stats.totalBinsBinId = number_new_bins;
         }
-        uint64_t binid = stats.totalBinsFile;
-        for (const std::string& c : cleaned) {
-            const int st = rb_dibf_add_sequence(filter.handle(), c.data(), c.size(), config.fragment_length,
-                                                config.overlap_length, binid, &binid);
-            if (st != RB_OK) throw InsertSequenceException(std::string("Error inserting a sequence to the IBF: ") + rb_last_error());
-        }
+        insert_all(cleaned, config, stats.totalBinsFile);
         try {
             filter.store(path);
         } catch (const IBFBuildException& e) {
