@@ -235,3 +235,42 @@ def test_synth_fill_density_and_padding():
     assert abs(ones0 / (64 * len(w)) - 55 / 256) < 0.01
     assert all(int(x) >> 36 == 0 for x in w[:, 1])  # bins >= 100 stay clear
     assert f.words()[f.n_blocks * f.bin_width:].sum() == 0
+
+
+def _py_count(words, n_bins, n_hash, k, n_blocks, bin_width, ords):
+    """pure-Python restatement of the spec in oracle/ibf_oracle.h (small cases only): independent of the C code"""
+    M = 2**64 - 1
+    counts = [0] * n_bins
+    for p in range(len(ords) - k + 1):
+        v = 0
+        for o in ords[p:p + k]:
+            v = (v * 5 + int(o)) & M
+        present = None
+        for i in range(n_hash):
+            x = ((i ^ ((k * 0x90b45d39fb6da1fa) & M)) * v) & M
+            x ^= x >> 27
+            base = (x % n_blocks) * bin_width * 64
+            bits = {b for b in range(n_bins) if (int(words[(base + b) // 64]) >> ((base + b) % 64)) & 1}
+            present = bits if present is None else present & bits
+        for b in present:
+            counts[b] += 1
+    return counts
+
+
+@pytest.mark.parametrize("n_bins,n_hash,k,n_blocks", [(70, 3, 13, 211), (5, 2, 7, 97), (130, 4, 15, 53)])
+def test_c_oracle_against_python_restatement(n_bins, n_hash, k, n_blocks):
+    rng = np.random.default_rng(n_bins + k)
+    bw = (n_bins + 63) // 64
+    f = po.OracleIBF(n_bins, n_hash, k, n_blocks * bw * 64 + 9)
+    ref = H.random_dna(rng, 400, with_n=0.02)
+    for b in range(0, n_bins, max(1, n_bins // 7)):
+        s = int(rng.integers(0, 300))
+        f.insert(po.encode(ref[s:s + 90]), b)
+    w = f.words()
+    for read in (ref[20:140], ref[250:330], H.random_dna(rng, 60), "ACGTN" * 10):
+        o = po.encode(read)
+        assert f.count(o).tolist() == _py_count(w, n_bins, n_hash, k, n_blocks, bw, o)
+        rc = po.revcomp(o)
+        assert f.count(rc).tolist() == _py_count(w, n_bins, n_hash, k, n_blocks, bw, rc)
+        exp = max(max(_py_count(w, n_bins, n_hash, k, n_blocks, bw, o)), max(_py_count(w, n_bins, n_hash, k, n_blocks, bw, rc)))
+        assert f.raw_max(o) == exp
