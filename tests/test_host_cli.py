@@ -250,7 +250,10 @@ def test_classify_with_fasta_targets_and_deplete(tmp_path, refdata):
         assert line == "RESULT found=%d failed=%d too_short=%d readCounter=%d" % (found, failed, too_short, len(recs))
     assert results[0].startswith("RESULT found=3 ")  # classifygtests.hpp:74-77: 3 of 3 target reads
     assert (out / "classifyTests_test.ibf").exists() and (out / "host.ibf").exists()
-    assert len(H.read_fasta(str(out / "classifyTests_test.fasta"))) == 0 or True
+    # outputs of the LAST read file (extra.fasta): nothing hits the target, the host read is neither target nor
+    # unclassified-by-failure: both records land in unclassified.fasta (classify.hpp:300-301)
+    assert H.read_fasta(str(out / "classifyTests_test.fasta")) == []
+    assert [n for n, _ in H.read_fasta(str(out / "unclassified.fasta"))] == ["hostread", "noise"]
 
 
 @pytest.mark.gpu
