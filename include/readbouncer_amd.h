@@ -169,7 +169,7 @@ RB_API int rb_classify_batch_ptrs(rb_engine *e, const char *const *seq_ptrs, con
 
 /* Same with every buffer already resident in HBM (device pointers) and asynchronous on
  * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
- * before returning).  max_len = an upper bound of lens[].  The inputs must be complete on `stream`
+ * before returning).  max_len = an upper bound of lens[] (a longer read gets status RB_ERR_INVALID_ARG).  The inputs must be complete on `stream`
  * (work that produces them on another stream has to be ordered before this call by the caller). */
 RB_API int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens,
                                     size_t n_reads, uint32_t max_len, double error_rate, double significance,

@@ -50,6 +50,7 @@ struct DecideParams {
     uint32_t k[kMaxFilters];
     const uint16_t *thr;  // [nf][2][thr_len]: thresholds at r and at r-0.02 by read length
     uint32_t thr_len;
+    uint32_t max_len;  // declared upper bound of the read lengths of this batch
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);

@@ -519,6 +519,7 @@ static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *
     for (size_t i = 0; i < e->filters.size(); ++i) P.k[i] = (uint32_t)e->filters[i]->geo.kmer_size;
     P.thr = (const uint16_t *)e->d_thr.p;
     P.thr_len = e->thr_len;
+    P.max_len = max_len;
     RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
 }

@@ -518,8 +518,14 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
         return;
     }
     const uint32_t len = lens[i];
+    if (len > P.max_len) {  // the caller understated max_len: counter width and threshold table were sized for less
+        if (out_best_target) out_best_target[i] = -1;
+        if (out_decision) out_decision[i] = 0;
+        if (out_status) out_status[i] = RB_ERR_INVALID_ARG;
+        return;
+    }
     const uint32_t nf = P.nd + P.nt;
-    const uint32_t tl = len < P.thr_len ? len : P.thr_len - 1;  // host guarantees len < thr_len
+    const uint32_t tl = len < P.thr_len ? len : P.thr_len - 1;  // len <= max_len < thr_len
     // group maxima at r (1) and at r - 0.02 (2), strictly-greater argmax at r (first wins ties)
     uint32_t D1 = 0, T1 = 0, D2 = 0, T2 = 0;
     int best_d = -1, best_t = -1;

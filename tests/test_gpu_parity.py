@@ -267,6 +267,14 @@ def test_device_pointer_api_and_column_shards():
     assert np.array_equal(t_max.cpu().numpy().view(np.uint16)[:, 0], expect)
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
     assert np.array_equal(t_dec.cpu().numpy(), exp_dec)
+    # an understated max_len is reported per read, not silently miscounted
+    t_st2 = torch.zeros(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, 200, d_maxcount=t_max.data_ptr(),
+                        d_decision=t_dec.data_ptr(), d_status=t_st2.data_ptr(), stream=stream)
+    torch.cuda.synchronize()
+    too_long = lens > 200
+    assert (t_st2.cpu().numpy()[too_long] == capi.RB_ERR_INVALID_ARG).all() and (t_st2.cpu().numpy()[~too_long] == exp_st[~too_long]).all()
     # bin-sharded layout: per-rank partial maxima, element-wise max == unsharded result
     for world in (2, 3, 8):
         acc = np.zeros(n, dtype=np.uint16)
