@@ -4,6 +4,8 @@
 // batch-wise: all reads of a batch are classified on chunk i in one GPU launch, reads that are still
 // unclassified go on to chunk i+1 -- per read this is the reference's loop (classify.hpp:262-299).
 // usage = "target" (live MinKNOW sampling) and "test" (connection test) are out of scope.
+#include <sys/resource.h>
+
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -388,7 +390,16 @@ int main(int argc, char const* argv[])
             std::cout << config.dump();
             return 0;
         }
-        return run_program(config, batch_reads, devices);
+        // end-of-run report of main.cpp:438-444 (getrusage on Linux, main.cpp:140-152)
+        const auto t_begin = std::chrono::steady_clock::now();
+        const int rc = run_program(config, batch_reads, devices);
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        const double cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+        std::cout << "Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() << " sec" << std::endl;
+        std::cout << "CPU time  : " << cpu << " sec" << std::endl;
+        std::cout << "Peak RSS  : " << (int)((ru.ru_maxrss * 1024L) / (1024 * 1024)) << " MByte" << std::endl;
+        return rc;
     } catch (const ConfigReaderException& e) {
         std::cerr << "Error in reading TOML configuration file!" << std::endl << e.what() << std::endl;
         return 1;
