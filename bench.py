@@ -195,7 +195,7 @@ def main():
     else:
         w = synth.WORKLOADS[args.workload]
         seeds = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60),
-                 "grch38_f100k": (8, 80)}[args.workload]
+                 "grch38_f100k": (8, 80), "zymo16": (6, 60)}[args.workload]
         dep, ref = synth.build_device_filter(dev_index, w, fill_seed=seeds[0], plant_seed=seeds[1])
         deplete, target = [dep], []
         wname = w["name"]

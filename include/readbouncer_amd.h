@@ -101,8 +101,11 @@ RB_API size_t rb_fragment_bounds(uint64_t len, uint64_t fragment_length, uint64_
                                  uint64_t overlap_length, uint64_t *starts, uint64_t *ends, size_t cap);
 
 /* ---- device-resident filter (the IBF in HBM) -------------------------------------------
- * Layout in HBM is the reference's own: block-major bit matrix, bin j of block b at bit
- * b*64*bin_width + j, so a .ibf payload is uploaded verbatim. */
+ * Layout in HBM: the reference's block-major bit matrix with every block starting on a boundary that suits the
+ * memory system -- block b at word b*stride, stride >= bin_width (equal when bin_width is a multiple of 16 words, i.e.
+ * the .ibf payload is then uploaded verbatim; otherwise blocks are padded to the next power of two / multiple of
+ * 128 bytes).  Bin j of block b is bit b*64*stride + j.  Upload, download, build and resize convert; the .ibf file
+ * format never changes. */
 typedef struct rb_dibf rb_dibf;
 
 RB_API int rb_dibf_create(int device, uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits,
@@ -113,6 +116,8 @@ RB_API int rb_dibf_open(int device, const char *path, rb_dibf **out);
 RB_API int rb_dibf_download(const rb_dibf *f, rb_ibf **out);
 RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
 RB_API void *rb_dibf_device_words(rb_dibf *f);
+/* words between consecutive blocks of the device image (see above) */
+RB_API uint64_t rb_dibf_device_stride(const rb_dibf *f);
 RB_API int rb_dibf_device(const rb_dibf *f);
 RB_API void rb_dibf_free(rb_dibf *f);
 /* resizeBins of IBF::update_filter (src/IBF/IBFBuild.cpp:274): same blocks and hash positions, every block widened

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rb_dibf_download": (_int, [_vp, _pp]),
     "rb_dibf_get_info": (_int, [_vp, C.POINTER(IbfInfo)]),
     "rb_dibf_device_words": (_vp, [_vp]),
+    "rb_dibf_device_stride": (_u64, [_vp]),
     "rb_dibf_device": (_int, [_vp]),
     "rb_dibf_free": (None, [_vp]),
     "rb_dibf_resize_bins": (_int, [_vp, _u64, _pp]),
@@ -223,6 +224,9 @@ class DeviceIBF:
 
     def device_words(self):
         return lib().rb_dibf_device_words(self.h)
+
+    def device_stride(self):
+        return lib().rb_dibf_device_stride(self.h)
 
     def resize_bins(self, new_bins):
         h = C.c_void_p()

@@ -17,6 +17,7 @@ struct IbfDev {
     uint32_t pow2_mask;  // n_blocks - 1 when n_blocks is a power of two, else 0xFFFFFFFF
     uint32_t n_bins;
     uint32_t bin_width;
+    uint32_t stride;  // words from one block to the next in HBM (>= bin_width; padded layout)
     uint32_t k;
     uint32_t n_hash;
 };
@@ -65,9 +66,9 @@ hipError_t launch_chunk_prep(const uint32_t *lens, const uint32_t *ids, uint32_t
 hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,
                          const uint64_t *ends, const uint64_t *bins, const uint64_t *kmer_prefix,
                          uint32_t n_fragments, uint64_t total_kmers, hipStream_t st);
-hipError_t launch_widen_blocks(const uint64_t *src, uint32_t w_old, uint64_t *dst, uint32_t w_new, uint64_t n_blocks,
-                               hipStream_t st);
-hipError_t launch_fill_synth(uint64_t *words, uint64_t n_words, uint64_t used_words, uint32_t bin_width,
+hipError_t launch_restride_blocks(const uint64_t *src, uint32_t s_src, uint64_t *dst, uint32_t s_dst, uint32_t w_copy,
+                                  uint64_t n_blocks, hipStream_t st);
+hipError_t launch_fill_synth(uint64_t *words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
                              uint64_t last_mask, uint64_t seed, hipStream_t st);
 
 }  // namespace rb

@@ -29,6 +29,7 @@ struct rb_dibf {
     int device = 0;
     rb_ibf_info geo{};
     uint64_t *d_words = nullptr;
+    uint64_t stride = 0;  // words between consecutive blocks in HBM (>= geo.bin_width)
     IbfDev dev{};
 };
 
@@ -123,7 +124,25 @@ static int check_device(int device)
     return RB_OK;
 }
 
-static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, IbfDev *d)
+// ---- HBM layout -------------------------------------------------------------------------------------------
+// The .ibf file stores the blocks back to back (W = bin_width words each).  In HBM a block starts every `stride`
+// words, stride >= W chosen so that a block never straddles more 128-byte lines than it has to:
+//   W a multiple of 16 (128 B): stride = W (file layout, verbatim);  W < 16: next power of two;  else: next multiple of 16.
+// Measured on a 600-bin filter (W = 10, 80-byte blocks): the same gathers from 128-byte aligned blocks run 1.37x faster
+// although 1.6x more bytes are fetched; gfx950 also needs 16-byte alignment for the dwordx4 lanes of odd widths only
+// to be fast, not to be correct.  Upload widens, download narrows; the file format is untouched.
+static uint64_t hbm_stride(uint64_t W)
+{
+    if (W % 16 == 0) return W;
+    if (W < 16) {
+        uint64_t s = 1;
+        while (s < W) s <<= 1;
+        return s;
+    }
+    return (W + 15) / 16 * 16;
+}
+
+static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, uint64_t stride, IbfDev *d)
 {
     if (g.n_hash > rbspec::kMaxHash) return rb::fail(RB_ERR_UNSUPPORTED, "more than 8 hash functions");
     if (g.kmer_size > rbspec::kMaxKmer) return rb::fail(RB_ERR_UNSUPPORTED, "k-mer size above 32");
@@ -138,10 +157,14 @@ static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, IbfDev *
     for (unsigned i = 0; i < rbspec::kMaxHash; ++i) d->precalc[i] = rbspec::precalc(g.kmer_size, i);
     d->n_bins = (uint32_t)g.n_bins;
     d->bin_width = (uint32_t)g.bin_width;
+    d->stride = (uint32_t)stride;
     d->k = (uint32_t)g.kmer_size;
     d->n_hash = (uint32_t)g.n_hash;
     return RB_OK;
 }
+
+// device words of a filter: n_blocks * stride, plus a small zero tail (a 16-byte lane may read one word past a block)
+static uint64_t dibf_device_words(const rb_dibf *f) { return f->geo.n_blocks * f->stride + 8; }
 
 static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out)
 {
@@ -151,18 +174,32 @@ static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out
     if (!f) return rb::fail(RB_ERR_NOMEM, "alloc");
     f->device = device;
     f->geo = g;
-    hipError_t e = hipMalloc((void **)&f->d_words, std::max<uint64_t>(g.n_words, 1) * 8);
+    f->stride = hbm_stride(g.bin_width);
+    hipError_t e = hipMalloc((void **)&f->d_words, dibf_device_words(f) * 8);
     if (e != hipSuccess) {
         delete f;
         return rb::fail(RB_ERR_HIP, std::string("hipMalloc of the IBF failed: ") + hipGetErrorString(e));
     }
     if (zero) {
-        e = hipMemset(f->d_words, 0, g.n_words * 8);
+        e = hipMemset(f->d_words, 0, dibf_device_words(f) * 8);
+        if (e != hipSuccess) { rb_dibf_free(f); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
+    } else {
+        e = hipMemset(f->d_words + f->geo.n_blocks * f->stride, 0, 8 * 8);
         if (e != hipSuccess) { rb_dibf_free(f); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
     }
-    st = make_dev_desc(g, f->d_words, &f->dev);
+    st = make_dev_desc(g, f->d_words, f->stride, &f->dev);
     if (st != RB_OK) { rb_dibf_free(f); return st; }
     *out = f;
+    return RB_OK;
+}
+
+// file-layout words already on the device (d_compact: n_blocks * W words) -> this filter's padded layout
+static int dibf_from_compact(rb_dibf *f, const uint64_t *d_compact)
+{
+    hipError_t e = launch_restride_blocks(d_compact, (uint32_t)f->geo.bin_width, f->d_words, (uint32_t)f->stride,
+                                          (uint32_t)f->geo.bin_width, f->geo.n_blocks, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return rb::fail(RB_ERR_HIP, std::string("layout conversion: ") + hipGetErrorString(e));
     return RB_OK;
 }
 
@@ -190,8 +227,20 @@ int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out)
     rb_dibf *f = nullptr;
     int st = dibf_alloc(device, host->geo, false, &f);
     if (st != RB_OK) return st;
-    hipError_t e = hipMemcpy(f->d_words, host->words, host->geo.n_words * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { rb_dibf_free(f); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
+    const uint64_t used = host->geo.n_blocks * host->geo.bin_width;  // block payload; tail bits and metadata stay on the host
+    hipError_t e = hipSuccess;
+    if (f->stride == host->geo.bin_width) {
+        e = hipMemcpy(f->d_words, host->words, used * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = rb::fail(RB_ERR_HIP, hipGetErrorString(e));
+    } else {
+        uint64_t *tmp = nullptr;
+        e = hipMalloc((void **)&tmp, std::max<uint64_t>(used, 1) * 8);
+        if (e == hipSuccess) e = hipMemcpy(tmp, host->words, used * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) st = rb::fail(RB_ERR_HIP, hipGetErrorString(e));
+        else st = dibf_from_compact(f, tmp);
+        if (tmp) (void)hipFree(tmp);
+    }
+    if (st != RB_OK) { rb_dibf_free(f); return st; }
     *out = f;
     return RB_OK;
 }
@@ -206,12 +255,18 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     rb_dibf *f = nullptr;
     st = dibf_alloc(device, g, false, &f);
     if (st != RB_OK) { std::fclose(fp); return st; }
-    // stream the payload through two pinned staging buffers: file read of chunk i+1 overlaps the
-    // H2D copy of chunk i; the 8 GB GRCh38 filter never needs a host-side image.
+    // stream the block payload through two pinned staging buffers: file read of chunk i+1 overlaps the H2D copy of
+    // chunk i; the 8 GB GRCh38 filter never needs a host-side image.  A padded layout lands in a temporary
+    // file-layout buffer on the device first and is widened there.
+    const uint64_t used = g.n_blocks * g.bin_width;
+    const bool padded = f->stride != g.bin_width;
+    uint64_t *d_dst = f->d_words;
+    hipError_t e = hipSuccess;
+    if (padded) e = hipMalloc((void **)&d_dst, std::max<uint64_t>(used, 1) * 8);
     const size_t chunk_words = (size_t)8 << 20;  // 64 MiB
     uint64_t *stage[2] = {nullptr, nullptr};
     hipStream_t s = nullptr;
-    hipError_t e = hipStreamCreate(&s);
+    if (e == hipSuccess) e = hipStreamCreate(&s);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipHostMalloc((void **)&stage[i], chunk_words * 8, hipHostMallocDefault);
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
@@ -219,15 +274,15 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     if (e != hipSuccess) rc = rb::fail(RB_ERR_HIP, std::string("staging setup: ") + hipGetErrorString(e));
     uint64_t pos = 0;
     int slot = 0;
-    bool used[2] = {false, false};
-    while (rc == RB_OK && pos < g.n_words) {
-        const size_t nw = (size_t)std::min<uint64_t>(chunk_words, g.n_words - pos);
-        if (used[slot]) (void)hipEventSynchronize(done[slot]);
+    bool used_slot[2] = {false, false};
+    while (rc == RB_OK && pos < used) {
+        const size_t nw = (size_t)std::min<uint64_t>(chunk_words, used - pos);
+        if (used_slot[slot]) (void)hipEventSynchronize(done[slot]);
         if (std::fread(stage[slot], 8, nw, fp) != nw) { rc = rb::fail(RB_ERR_PARSE_IBF, std::string(path) + ": short read"); break; }
-        e = hipMemcpyAsync(f->d_words + pos, stage[slot], nw * 8, hipMemcpyHostToDevice, s);
+        e = hipMemcpyAsync(d_dst + pos, stage[slot], nw * 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipEventRecord(done[slot], s);
         if (e != hipSuccess) { rc = rb::fail(RB_ERR_HIP, hipGetErrorString(e)); break; }
-        used[slot] = true;
+        used_slot[slot] = true;
         pos += nw;
         slot ^= 1;
     }
@@ -238,6 +293,8 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     }
     if (s) (void)hipStreamDestroy(s);
     std::fclose(fp);
+    if (rc == RB_OK && padded) rc = dibf_from_compact(f, d_dst);
+    if (padded && d_dst) (void)hipFree(d_dst);
     if (rc != RB_OK) { rb_dibf_free(f); return rc; }
     *out = f;
     return RB_OK;
@@ -247,11 +304,23 @@ int rb_dibf_download(const rb_dibf *f, rb_ibf **out)
 {
     if (!f || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
     rb_ibf *h = nullptr;
-    int st = rb_ibf_create(f->geo.n_bins, f->geo.n_hash, f->geo.kmer_size, f->geo.n_bits, &h);
+    int st = rb_ibf_create(f->geo.n_bins, f->geo.n_hash, f->geo.kmer_size, f->geo.n_bits, &h);  // zeroed: tail + metadata
     if (st != RB_OK) return st;
     st = check_device(f->device);
     if (st != RB_OK) { rb_ibf_close(h); return st; }
-    hipError_t e = hipMemcpy(h->words, f->d_words, f->geo.n_words * 8, hipMemcpyDeviceToHost);
+    const uint64_t used = f->geo.n_blocks * f->geo.bin_width;
+    hipError_t e = hipSuccess;
+    if (f->stride == f->geo.bin_width) {
+        e = hipMemcpy(h->words, f->d_words, used * 8, hipMemcpyDeviceToHost);
+    } else {
+        uint64_t *tmp = nullptr;
+        e = hipMalloc((void **)&tmp, std::max<uint64_t>(used, 1) * 8);
+        if (e == hipSuccess)
+            e = launch_restride_blocks(f->d_words, (uint32_t)f->stride, tmp, (uint32_t)f->geo.bin_width,
+                                       (uint32_t)f->geo.bin_width, f->geo.n_blocks, nullptr);
+        if (e == hipSuccess) e = hipMemcpy(h->words, tmp, used * 8, hipMemcpyDeviceToHost);
+        if (tmp) (void)hipFree(tmp);
+    }
     if (e != hipSuccess) { rb_ibf_close(h); return rb::fail(RB_ERR_HIP, hipGetErrorString(e)); }
     *out = h;
     return RB_OK;
@@ -265,6 +334,7 @@ int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info)
 }
 
 void *rb_dibf_device_words(rb_dibf *f) { return f ? f->d_words : nullptr; }
+uint64_t rb_dibf_device_stride(const rb_dibf *f) { return f ? f->stride : 0; }
 int rb_dibf_device(const rb_dibf *f) { return f ? f->device : -1; }
 
 void rb_dibf_free(rb_dibf *f)
@@ -288,8 +358,8 @@ int rb_dibf_resize_bins(const rb_dibf *f, uint64_t new_bins, rb_dibf **out)
     rb_dibf *n = nullptr;
     int st = dibf_alloc(f->device, g, true, &n);
     if (st != RB_OK) return st;
-    hipError_t e = launch_widen_blocks(f->d_words, (uint32_t)f->geo.bin_width, n->d_words, (uint32_t)new_width,
-                                       f->geo.n_blocks, nullptr);
+    hipError_t e = launch_restride_blocks(f->d_words, (uint32_t)f->stride, n->d_words, (uint32_t)n->stride,
+                                          (uint32_t)f->geo.bin_width, f->geo.n_blocks, nullptr);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { rb_dibf_free(n); return rb::fail(RB_ERR_HIP, std::string("resize: ") + hipGetErrorString(e)); }
     *out = n;
@@ -304,7 +374,8 @@ int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
     const uint64_t used = f->geo.n_blocks * f->geo.bin_width;
     const uint64_t rem = f->geo.n_bins & 63;
     const uint64_t last_mask = rem ? ((1ULL << rem) - 1) : ~0ULL;
-    RB_HIP(launch_fill_synth(f->d_words, f->geo.n_words, used, (uint32_t)f->geo.bin_width, last_mask, seed, nullptr));
+    RB_HIP(hipMemset(f->d_words, 0, dibf_device_words(f) * 8));
+    RB_HIP(launch_fill_synth(f->d_words, used, (uint32_t)f->geo.bin_width, (uint32_t)f->stride, last_mask, seed, nullptr));
     RB_HIP(hipDeviceSynchronize());
     return RB_OK;
 }
@@ -619,7 +690,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
         const uint32_t Weff = a.col_end - a.col_begin;
         const uint32_t kmers = max_len >= f->geo.kmer_size ? max_len - (uint32_t)f->geo.kmer_size + 1 : 0;
         a.planes = kmers <= 1023 ? 10 : 16;
-        a.nt = f->geo.n_words * 8 > e->nt_threshold_bytes;
+        a.nt = f->geo.n_blocks * f->stride * 8 > e->nt_threshold_bytes;
         if (Weff == 0) {
             // this rank holds no column of this filter: its partial maxima are 0
             RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, fs));

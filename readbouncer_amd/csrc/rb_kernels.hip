@@ -226,7 +226,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
     constexpr int NG = T::NG, SPT = T::SPT, J = T::J, STEPS = T::STEPS, ITEMS = T::ITEMS;
     constexpr int HR = H > 0 ? H : 1;
     const int g = lane >> LG;
-    const uint32_t W = f.bin_width;
+    const uint32_t S = f.stride;  // words between consecutive blocks in HBM (>= bin_width, see rb_engine.hip)
     const uint32_t k = f.k;
 
     for (uint32_t mt = mt_first; mt < n; mt += mt_step) {
@@ -295,7 +295,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                             if constexpr (LG == 0) b = idx[j][h];
                             else if constexpr (LG == 6) b = readlane32(idx[j][h], it);
                             else b = shfl32(idx[j][h], it);
-                            const uint64_t *src = lc.safe_base + (uint64_t)(ok ? b : 0u) * W;
+                            const uint64_t *src = lc.safe_base + (uint64_t)(ok ? b : 0u) * S;
                             if constexpr (WPL == 1) {
                                 ld[uu][h][0] = load_word<NT>(src);
                             } else {
@@ -335,7 +335,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                     if (ok) {
                         for (uint32_t h = 0; h < f.n_hash; ++h) {
                             const uint32_t bi = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
-                            const uint64_t *src = lc.lane_base + (uint64_t)bi * W;
+                            const uint64_t *src = lc.lane_base + (uint64_t)bi * S;
 #pragma unroll
                             for (int w = 0; w < WPL; ++w) acc[w] &= (lc.valid[w] ? load_word<NT>(src + w) : 0ULL);
                         }
@@ -618,35 +618,38 @@ __global__ void ibf_insert_kernel(IbfDev f, uint64_t *__restrict__ words, const 
     const uint64_t bin = bins[lo];
     for (uint32_t h = 0; h < f.n_hash; ++h) {
         const uint64_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
-        const uint64_t bit = blk * ((uint64_t)f.bin_width * 64u) + bin;
+        const uint64_t bit = blk * ((uint64_t)f.stride * 64u) + bin;  // padded HBM layout
         atomicOr(reinterpret_cast<unsigned long long *>(words + (bit >> 6)), 1ULL << (bit & 63));
     }
 }
 
-// resizeBins: block b of width w_old -> block b of width w_new, old words first, new columns zero
-__global__ void widen_blocks_kernel(const uint64_t *__restrict__ src, uint32_t w_old, uint64_t *__restrict__ dst,
-                                    uint32_t w_new, uint64_t n_blocks)
+// Re-stride a block matrix: block b = src[b*s_src .. +w_copy) -> dst[b*s_dst .. +w_copy), the rest of each destination
+// block (s_dst - w_copy words) is zero.  Serves resizeBins (wider blocks, new bins empty), the padded HBM layout
+// (file layout -> aligned blocks) and the way back (download).
+__global__ void restride_blocks_kernel(const uint64_t *__restrict__ src, uint32_t s_src, uint64_t *__restrict__ dst,
+                                       uint32_t s_dst, uint32_t w_copy, uint64_t n_blocks)
 {
-    const uint64_t total = n_blocks * w_new;
+    const uint64_t total = n_blocks * s_dst;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint64_t b = i / w_new;
-        const uint32_t c = (uint32_t)(i - b * w_new);
-        dst[i] = c < w_old ? src[b * w_old + c] : 0ULL;
+        const uint64_t b = i / s_dst;
+        const uint32_t c = (uint32_t)(i - b * s_dst);
+        dst[i] = c < w_copy ? src[b * s_src + c] : 0ULL;
     }
 }
 
-__global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t n_words, uint64_t used_words,
-                                  uint32_t bin_width, uint64_t last_mask, uint64_t seed)
+// word w of the FILE layout (block w / bin_width, column w % bin_width) gets synth_word(seed, w); it is stored at the
+// padded position of that block
+__global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
+                                  uint64_t last_mask, uint64_t seed)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += stride) {
-        uint64_t x = 0;
-        if (w < used_words) {
-            x = rbspec::synth_word(seed, w);
-            if ((w % bin_width) == bin_width - 1) x &= last_mask;
-        }
-        words[w] = x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < used_words; w += stride) {
+        const uint64_t b = w / bin_width;
+        const uint32_t c = (uint32_t)(w - b * bin_width);
+        uint64_t x = rbspec::synth_word(seed, w);
+        if (c == bin_width - 1) x &= last_mask;
+        words[b * stride_words + c] = x;
     }
 }
 
@@ -769,24 +772,25 @@ hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, c
     return hipGetLastError();
 }
 
-hipError_t launch_widen_blocks(const uint64_t *src, uint32_t w_old, uint64_t *dst, uint32_t w_new, uint64_t n_blocks,
-                               hipStream_t st)
+hipError_t launch_restride_blocks(const uint64_t *src, uint32_t s_src, uint64_t *dst, uint32_t s_dst, uint32_t w_copy,
+                                  uint64_t n_blocks, hipStream_t st)
 {
     if (n_blocks == 0) return hipSuccess;
-    uint64_t blocks = (n_blocks * w_new + 255) / 256;
+    uint64_t blocks = (n_blocks * s_dst + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(widen_blocks_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, w_old, dst, w_new, n_blocks);
+    hipLaunchKernelGGL(restride_blocks_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, dst, s_dst, w_copy,
+                       n_blocks);
     return hipGetLastError();
 }
 
-hipError_t launch_fill_synth(uint64_t *words, uint64_t n_words, uint64_t used_words, uint32_t bin_width,
+hipError_t launch_fill_synth(uint64_t *words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
                              uint64_t last_mask, uint64_t seed, hipStream_t st)
 {
-    if (n_words == 0) return hipSuccess;
-    uint64_t blocks = (n_words + 255) / 256;
+    if (used_words == 0) return hipSuccess;
+    uint64_t blocks = (used_words + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(fill_synth_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, words, n_words, used_words,
-                       bin_width, last_mask, seed);
+    hipLaunchKernelGGL(fill_synth_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, words, used_words, bin_width,
+                       stride_words, last_mask, seed);
     return hipGetLastError();
 }
 

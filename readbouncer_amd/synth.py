@@ -18,6 +18,9 @@ WORKLOADS = {
     # config 3 with the reference's own sizing rule (non-power-of-two block count)
     "c3np2": dict(name="config3 (BinSizeBits*8256 sizing): 360bp prefixes vs 8192-bin IBF, generic modulus",
                   n_bins=8192, k=13, h=3, fragment=370000, n_bits=None, reads=10_000_000, read_len=360),
+    # the same filter size class with 128-byte aligned blocks (what a padded HBM layout of "zymo" would look like)
+    "zymo16": dict(name="1024-bin IBF at F=100000 (aligned 128-byte blocks, 168 MB)",
+                   n_bins=1024, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=360),
     # GRCh38 exactly as ReadBouncer itself would build it: fragment_size 100000 (its default) -> ~31 000 bins,
     # W = 485 words (odd: 8-byte lanes, 8 column slices), 4.8 GB, odd block count
     "grch38_f100k": dict(name="GRCh38 at ReadBouncer's default fragment_size=100000: 31000 bins (3.9 KB blocks), 4.8 GB",

@@ -215,14 +215,18 @@ def test_decisions_match_oracle(nd, nt):
             assert res["best_target"] == best[i]
 
 
-def test_ibf_file_roundtrip_through_hbm(tmp_path):
+@pytest.mark.parametrize("fragment_length", [1500, 150, 31])
+def test_ibf_file_roundtrip_through_hbm(tmp_path, fragment_length):
+    # 14 bins (one word per block, file layout kept), 134 bins (3 words -> padded to 4 in HBM), 646 bins (11 -> 16)
     rng = np.random.default_rng(3)
     ref = H.random_dna(rng, 20000)
-    o = H.build_filter_like_reference([ref], k=13, fragment_length=1500)
+    o = H.build_filter_like_reference([ref], k=13, fragment_length=fragment_length)
     p = tmp_path / "ref.ibf"
     o.store(str(p))  # written by the oracle's restatement of seqan::store
     assert capi.is_ibf_file(str(p))
     d = capi.DeviceIBF.open(0, str(p))  # load_filter straight into HBM
+    W = d.info["bin_width"]
+    assert d.device_stride() == {1: 1, 3: 4, 11: 16}[W]
     assert (d.info["n_bins"], d.info["n_hash"], d.info["kmer_size"], d.info["n_bits"]) == (o.n_bins, 3, 13, o.n_bits)
     reads = make_reads(rng, ref, 64)
     buf, offs, lens = H.pack_reads(reads)
