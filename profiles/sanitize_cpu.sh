@@ -1,0 +1,17 @@
+#!/bin/bash
+# AddressSanitizer + UBSan on the CPU builds (GPU sanitizers are not available on the pool): the oracle under the KAT and
+# C-ABI tests, and the host CLI (TOML, FASTA/FASTQ ingest, config reader, drivers) under its CPU tests.
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd)
+T=$(mktemp -d)
+cp $R/oracle/libibf_oracle.so $T/oracle.so; cp $R/readbouncer_amd/readbouncer_amd_cli $T/cli
+trap 'cp $T/oracle.so $R/oracle/libibf_oracle.so; cp $T/cli $R/readbouncer_amd/readbouncer_amd_cli; touch $R/oracle/libibf_oracle.so' EXIT
+gcc -O1 -g -std=c11 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -D_POSIX_C_SOURCE=200809L \
+    -shared -o $R/oracle/libibf_oracle.so $R/oracle/ibf_oracle.c -lm -lpthread
+touch $R/oracle/libibf_oracle.so
+(cd $R && ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
+    python -m pytest tests/test_oracle_kat.py tests/test_capi_cpu.py -x -q)
+(cd $R/readbouncer_amd/host && g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer rb_main.cpp \
+    -o ../readbouncer_amd_cli -L.. -lreadbouncer_amd -Wl,-rpath,'$ORIGIN' -lpthread)
+(cd $R && ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_cli.py -x -q -m "not gpu")
+echo "sanitizers: clean"
