@@ -567,3 +567,43 @@ def test_packed_reads_and_on_gpu_chunking():
     got = run(True, 360, 360, ids=keep, mode=capi.RB_MODE_CHECK_UNBLOCK)
     for a, b in zip(got, exp):
         assert np.array_equal(a, b)
+
+
+def test_engine_is_thread_safe():
+    """SURVEY 8b threading: the reference's N classify threads share the filters read-only (adaptive_sampling.hpp:745-750).
+    Several host threads call rb_classify_batch on ONE engine and on separate engines over the same filters."""
+    import threading
+    rng = np.random.default_rng(55)
+    ref = H.random_dna(rng, 30000)
+    d = capi.DeviceIBF.create(0, 500, 3, 13, 512 * 60013)
+    d.add_sequence(ref, 200)
+    o, _k = oracle_view(d)
+    batches = []
+    for t in range(6):
+        reads = make_reads(np.random.default_rng(100 + t), ref, 150 + 40 * t, lo=5, hi=420)
+        buf, offs, lens = H.pack_reads(reads)
+        exp_max = po.batch_raw_max(o, buf, offs, lens, 4)
+        exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
+        batches.append((buf, offs, lens, exp_max, exp_dec, exp_st))
+    shared = capi.Engine(0, [d], [])
+    own = [capi.Engine(0, [d], []) for _ in range(3)]
+    errors = []
+
+    def worker(t):
+        try:
+            eng = shared if t < 3 else own[t - 3]
+            buf, offs, lens, exp_max, exp_dec, exp_st = batches[t]
+            for _ in range(25):
+                mc, _, dec, st = eng.classify(buf, offs, lens)
+                if not (np.array_equal(mc[:, 0], exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)):
+                    errors.append("mismatch in thread %d" % t)
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert errors == []
