@@ -33,6 +33,16 @@ struct ReadSrc {
     uint32_t base_off;              // bases skipped at the start of every read (chunk start)
 };
 
+constexpr unsigned kMaxFused = 8;
+
+// by-value kernel argument of the latency kernel: up to 8 filters of equal kernel geometry served by one launch
+struct FilterSet {
+    uint32_t n;
+    uint32_t col_begin[kMaxFused], col_end[kMaxFused];
+    uint32_t out_offset[kMaxFused];  // element offset of the filter's column in the output
+    IbfDev f[kMaxFused];
+};
+
 struct CountLaunch {
     IbfDev f;
     ReadSrc src;
@@ -44,6 +54,10 @@ struct CountLaunch {
     int split_waves;              // >= 2: latency form, one workgroup of split_waves waves per read
     uint16_t *out;
     uint32_t out_read_stride, out_slice_stride;
+    // latency form only: n_fused > 0 = several filters in one launch (then f/col_begin/col_end above describe the first)
+    int n_fused;
+    IbfDev fused_f[kMaxFused];
+    uint32_t fused_col_begin[kMaxFused], fused_col_end[kMaxFused], fused_out_offset[kMaxFused];
 };
 
 struct DecideParams {

@@ -663,11 +663,15 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
         evp = &e->ev_ring[e->ev_used++];
         RB_HIP(hipEventRecord(evp->first, st));
     }
-    const bool fan_out = e->overlap && nf > 1 && !e->aux.empty();
+    // fork/join over auxiliary streams costs ~20-40 us of event traffic per call (measured): worth it for large
+    // batches only; micro-batches queue their few short kernels on the one stream
+    const bool fan_out = e->overlap && nf > 1 && !e->aux.empty() && n_reads > e->split_threshold;
     if (fan_out) {
         RB_HIP(hipEventRecord(e->fork_ev, st));
         for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) RB_HIP(hipStreamWaitEvent(e->aux[k], e->fork_ev, 0));
     }
+    std::vector<CountLaunch> pending;
+    std::vector<uint32_t> pending_fi;
     for (size_t fi = 0; fi < nf; ++fi) {
         const rb_dibf *f = e->filters[fi];
         hipStream_t fs = (fan_out && fi > 0) ? e->aux[(fi - 1) % e->aux.size()] : st;
@@ -712,7 +716,12 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
             a.out_slice_stride = 0;
-            RB_HIP(launch_ibf_count_max(a, fs));
+            if (a.split_waves >= 2 && !fan_out) {
+                pending.push_back(a);  // latency form: fused below with the filters of equal kernel geometry
+                pending_fi.push_back((uint32_t)fi);
+            } else {
+                RB_HIP(launch_ibf_count_max(a, fs));
+            }
         } else {
             rc = e->d_parts[fi].ensure((size_t)a.n_slices * n_reads * 2);
             if (rc != RB_OK) return rc;
@@ -721,6 +730,29 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             a.out_slice_stride = (uint32_t)n_reads;
             RB_HIP(launch_ibf_count_max(a, fs));
             RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, fs));
+        }
+    }
+    // latency form: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves)
+    {
+        std::vector<bool> done(pending.size(), false);
+        for (size_t i = 0; i < pending.size(); ++i) {
+            if (done[i]) continue;
+            CountLaunch g = pending[i];
+            g.n_fused = 0;
+            for (size_t j = i; j < pending.size() && g.n_fused < (int)kMaxFused; ++j) {
+                const CountLaunch &b = pending[j];
+                if (done[j] || b.lg != g.lg || b.wpl != g.wpl || b.planes != g.planes || b.nt != g.nt ||
+                    b.split_waves != g.split_waves || b.f.n_hash != g.f.n_hash)
+                    continue;
+                g.fused_f[g.n_fused] = b.f;
+                g.fused_col_begin[g.n_fused] = b.col_begin;
+                g.fused_col_end[g.n_fused] = b.col_end;
+                g.fused_out_offset[g.n_fused] = pending_fi[j];
+                ++g.n_fused;
+                done[j] = true;
+            }
+            g.out = maxcount;  // per-filter column offsets travel in the set
+            RB_HIP(launch_ibf_count_max(g, st));
         }
     }
     if (fan_out) {

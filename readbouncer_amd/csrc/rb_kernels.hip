@@ -412,11 +412,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 // latency form for micro-batches: one workgroup per (read, column slice); wave w takes strand w&1 and every
 // (blockDim/128)-th macro tile starting at w>>1.  Partial counters meet in LDS (bit-sliced adds), then max.
 template <int LG, int WPL, int NP, int H, bool NT>
+// blockIdx.y selects one filter of the set: filters of equal kernel geometry share ONE launch (a micro-batch against
+// deplete + several targets would otherwise queue one short kernel per filter, ~25 us each).
 __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
-    IbfDev f, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
-    uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const IbfDev &f = set.f[blockIdx.y];
+    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
+    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
@@ -674,9 +679,24 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
             if (e != hipSuccess) return e;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
-        dim3 grid(a.n_reads * a.n_slices);
-        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, a.f, a.src, a.n_reads, a.n_slices,
-                           a.col_begin, a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
+        FilterSet set;
+        set.n = a.n_fused > 0 ? (uint32_t)a.n_fused : 1u;
+        if (a.n_fused > 0) {
+            for (uint32_t i = 0; i < set.n; ++i) {
+                set.f[i] = a.fused_f[i];
+                set.col_begin[i] = a.fused_col_begin[i];
+                set.col_end[i] = a.fused_col_end[i];
+                set.out_offset[i] = a.fused_out_offset[i];
+            }
+        } else {
+            set.f[0] = a.f;
+            set.col_begin[0] = a.col_begin;
+            set.col_end[0] = a.col_end;
+            set.out_offset[0] = 0;
+        }
+        dim3 grid(a.n_reads * a.n_slices, set.n);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
+                           a.out_slice_stride);
         return hipGetLastError();
     }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
