@@ -716,8 +716,8 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
             a.out_slice_stride = 0;
-            if (a.split_waves >= 2 && !fan_out) {
-                pending.push_back(a);  // latency form: fused below with the filters of equal kernel geometry
+            if (!fan_out && nf > 1 && n_reads <= e->split_threshold) {
+                pending.push_back(a);  // micro-batch: fused below with the filters of equal kernel geometry
                 pending_fi.push_back((uint32_t)fi);
             } else {
                 RB_HIP(launch_ibf_count_max(a, fs));
@@ -732,7 +732,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, fs));
         }
     }
-    // latency form: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves)
+    // micro-batches: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves)
     {
         std::vector<bool> done(pending.size(), false);
         for (size_t i = 0; i < pending.size(); ++i) {

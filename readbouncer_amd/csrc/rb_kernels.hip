@@ -379,10 +379,13 @@ __device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item
 // throughput form: one wave per (read, column slice), both strands in sequence
 template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
-    IbfDev f, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint32_t col_begin, uint32_t col_end,
-    uint16_t *__restrict__ out, uint32_t out_read_stride, uint32_t out_slice_stride)
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+    const IbfDev &f = set.f[blockIdx.y];  // filters of equal kernel geometry may share a launch (micro-batches)
+    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
+    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // work item = (read, column slice), slice fastest: the waves of a workgroup gather neighbouring parts of the same
@@ -663,6 +666,21 @@ __global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t used_wo
 template <int LG, int WPL, int NP, int H, bool NT>
 static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
 {
+    FilterSet set;
+    set.n = a.n_fused > 0 ? (uint32_t)a.n_fused : 1u;
+    if (a.n_fused > 0) {
+        for (uint32_t i = 0; i < set.n; ++i) {
+            set.f[i] = a.fused_f[i];
+            set.col_begin[i] = a.fused_col_begin[i];
+            set.col_end[i] = a.fused_col_end[i];
+            set.out_offset[i] = a.fused_out_offset[i];
+        }
+    } else {
+        set.f[0] = a.f;
+        set.col_begin[0] = a.col_begin;
+        set.col_end[0] = a.col_end;
+        set.out_offset[0] = 0;
+    }
     if (a.split_waves >= 2) {
         // latency form: one workgroup per read; dynamic LDS = plane exchange + maxima + per-wave staging
         const int nw = a.split_waves;
@@ -679,30 +697,15 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
             if (e != hipSuccess) return e;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
-        FilterSet set;
-        set.n = a.n_fused > 0 ? (uint32_t)a.n_fused : 1u;
-        if (a.n_fused > 0) {
-            for (uint32_t i = 0; i < set.n; ++i) {
-                set.f[i] = a.fused_f[i];
-                set.col_begin[i] = a.fused_col_begin[i];
-                set.col_end[i] = a.fused_col_end[i];
-                set.out_offset[i] = a.fused_out_offset[i];
-            }
-        } else {
-            set.f[0] = a.f;
-            set.col_begin[0] = a.col_begin;
-            set.col_end[0] = a.col_end;
-            set.out_offset[0] = 0;
-        }
         dim3 grid(a.n_reads * a.n_slices, set.n);
         hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
                            a.out_slice_stride);
         return hipGetLastError();
     }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
-    dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock));
-    hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.src,
-                       a.n_reads, a.n_slices, a.col_begin, a.col_end, a.out, a.out_read_stride, a.out_slice_stride);
+    dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock), set.n);
+    hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, set, a.src,
+                       a.n_reads, a.n_slices, a.out, a.out_read_stride, a.out_slice_stride);
     return hipGetLastError();
 }
 
