@@ -728,7 +728,7 @@ int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
     if (nw > 16) nw = 16;
     if (wpl == 2 && nw > (np > 10 ? 8 : 12)) nw = np > 10 ? 8 : 12;  // those instantiations are built for 512 / 768 threads
     nw &= ~1;
-    return nw >= 4 ? nw : 0;
+    return nw >= 2 ? nw : 0;  // two waves = one per strand (reads that fit one macro tile, e.g. one-word filters)
 }
 
 template <int NP, int H>
