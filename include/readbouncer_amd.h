@@ -271,6 +271,10 @@ RB_API int rb_engine_set_overlap(rb_engine *e, int enabled);
  * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
 
+/* Host batches above 8 MB of read bytes cross PCIe in slices of about slice_bytes (default 32 MiB): slice i+1 is
+ * copied on a copy stream while slice i is counted.  0 = one slice (no overlap).  Results are identical. */
+RB_API int rb_engine_set_host_slice_bytes(rb_engine *e, uint64_t slice_bytes);
+
 /* Kernel timing for the roofline figure: when enabled every rb_classify_batch* call brackets its
  * count kernels (K1, all filters) with a hipEvent pair recorded on the launch stream, without
  * synchronising.  rb_engine_kernel_time waits for the recorded pairs, returns their summed elapsed

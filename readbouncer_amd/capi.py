@@ -91,6 +91,7 @@ SIGNATURES = {
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
+    "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
 }
@@ -349,6 +350,9 @@ class Engine:
 
     def set_nt_threshold(self, table_bytes):
         _check(lib().rb_engine_set_nt_threshold(self.h, table_bytes), "rb_engine_set_nt_threshold")
+
+    def set_host_slice_bytes(self, slice_bytes):
+        _check(lib().rb_engine_set_host_slice_bytes(self.h, slice_bytes), "rb_engine_set_host_slice_bytes")
 
     def set_timing(self, on):
         _check(lib().rb_engine_set_timing(self.h, int(on)), "rb_engine_set_timing")

@@ -110,6 +110,10 @@ struct rb_engine {
     DevBuf d_seqs, d_offsets, d_lens, d_best, d_decision, d_status;
     DevBuf d_efflens, d_prestatus;  // on-GPU chunking: effective lengths and the bad-chunk status per item
     PinnedBuf h_in, h_out;
+    // large host batches: slice i+1 is copied on this stream while slice i is counted on `stream`
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> copy_ev;
+    uint64_t host_slice_bytes = (uint64_t)32 << 20;
     std::mutex mu;
 };
 
@@ -465,6 +469,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (he == hipSuccess) e->join_ev.push_back(ev);
     }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
     if (he != hipSuccess) { rb_engine_destroy(e); return rb::fail(RB_ERR_HIP, hipGetErrorString(he)); }
     *out = e;
     return RB_OK;
@@ -479,6 +484,8 @@ void rb_engine_destroy(rb_engine *e)
     for (hipStream_t s : e->aux) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (hipEvent_t ev : e->join_ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
+    for (hipEvent_t ev : e->copy_ev) (void)hipEventDestroy(ev);
     for (DevBuf &b : e->d_parts) b.release();
     for (DevBuf *b : {&e->d_efflens, &e->d_prestatus, &e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
@@ -491,6 +498,7 @@ void rb_engine_destroy(rb_engine *e)
 int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
 {
     if (!e || world < 1 || rank < 0 || rank >= world) return rb::fail(RB_ERR_INVALID_ARG, "bad shard");
+    std::lock_guard<std::mutex> lock(e->mu);
     e->shard_rank = rank;
     e->shard_world = world;
     return RB_OK;
@@ -517,6 +525,14 @@ int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes)
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
     std::lock_guard<std::mutex> lock(e->mu);
     e->nt_threshold_bytes = table_bytes;
+    return RB_OK;
+}
+
+int rb_engine_set_host_slice_bytes(rb_engine *e, uint64_t slice_bytes)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->host_mu);
+    e->host_slice_bytes = slice_bytes ? slice_bytes : ~0ULL;
     return RB_OK;
 }
 
@@ -553,6 +569,9 @@ int rb_engine_kernel_time(rb_engine *e, double *total_ms, uint64_t *n_calls)
 // thresholds by read length for every filter at r and r-0.02 (host doubles, device table)
 static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st)
 {
+    // one table row per read length: 16 Mbp is far beyond any read the callers classify whole (chunk prefixes, 1.5 kbp
+    // live cut-off) and keeps the table (4 bytes x filters x length) small
+    if (max_len > (1u << 24)) return rb::fail(RB_ERR_UNSUPPORTED, "reads longer than 2^24 bases");
     const uint32_t need = max_len + 1;
     if (e->thr_len >= need && e->thr_r == r && e->thr_conf == conf) return RB_OK;
     uint32_t cap = 1024;
@@ -653,7 +672,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
         maxcount = (uint16_t *)e->d_maxcount.p;
     }
     std::pair<hipEvent_t, hipEvent_t> *evp = nullptr;
-    if (e->timing) {
+    if (e->timing && e->ev_used < ((size_t)1 << 16)) {  // bounded: a caller that never collects stops being timed
         if (e->ev_used == e->ev_ring.size()) {
             hipEvent_t a = nullptr, b = nullptr;
             RB_HIP(hipEventCreate(&a));
@@ -855,7 +874,9 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         return RB_OK;
     }
 
-    // ---- large batches: copy the spanned byte range as it is (offsets stay valid relative to a shifted base)
+    // ---- large batches: the spanned byte range goes over as it is (offsets stay valid relative to a shifted base), in
+    // slices of consecutive reads: slice i+1 crosses PCIe on the copy stream while slice i is counted.  A pageable
+    // source makes hipMemcpyAsync block the host while it stages, which is exactly when the GPU works on the slice before.
     const uint64_t span = hi - lo;
     {
         std::lock_guard<std::mutex> lock(e->mu);
@@ -867,14 +888,49 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         if ((rc = e->d_decision.ensure(n)) != RB_OK) return rc;
         if ((rc = e->d_status.ensure(n)) != RB_OK) return rc;
     }
-    RB_HIP(hipMemcpyAsync(e->d_seqs.p, seqs + lo, span, hipMemcpyHostToDevice, st));
-    RB_HIP(hipMemcpyAsync(e->d_offsets.p, offsets, n * 8, hipMemcpyHostToDevice, st));
-    RB_HIP(hipMemcpyAsync(e->d_lens.p, lens, n * 4, hipMemcpyHostToDevice, st));
-    const char *d_base = (const char *)e->d_seqs.p - lo;  // device address of the caller's seqs[0]
-    rc = rb_classify_batch_device(e, d_base, e->d_offsets.p, e->d_lens.p, n, max_len, error_rate, significance, mode,
-                                  e->d_maxcount.p, e->d_best.p, e->d_decision.p, e->d_status.p, (void *)st);
-    if (rc != RB_OK) return rc;
-    if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, e->d_maxcount.p, n * nf * 2, hipMemcpyDeviceToHost, st));
+    char *d_seqs = (char *)e->d_seqs.p;
+    uint64_t *d_off = (uint64_t *)e->d_offsets.p;
+    uint32_t *d_len = (uint32_t *)e->d_lens.p;
+    uint16_t *d_max = (uint16_t *)e->d_maxcount.p;
+    const char *d_base = d_seqs - lo;  // device address of the caller's seqs[0]
+    hipStream_t cs = e->copy_stream;
+    size_t i0 = 0, slice = 0;
+    while (i0 < n) {
+        uint64_t bytes = 0, s_lo = ~0ULL, s_hi = 0;
+        size_t i1 = i0;
+        while (i1 < n && (i1 == i0 || bytes + lens[i1] <= e->host_slice_bytes)) {
+            bytes += lens[i1];
+            s_lo = std::min<uint64_t>(s_lo, offsets[i1]);
+            s_hi = std::max<uint64_t>(s_hi, offsets[i1] + lens[i1]);
+            ++i1;
+        }
+        const size_t cnt = i1 - i0;
+        // a wait binds to the record that precedes it, so a small ring of events can be re-recorded by later slices
+        const size_t evi = slice % 64;
+        if (evi == e->copy_ev.size()) {
+            hipEvent_t ev = nullptr;
+            RB_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->copy_ev.push_back(ev);
+        }
+        // reads that alias or interleave across slices are copied again to the same place: same bytes, no hazard for the
+        // kernels already reading them
+        if (s_hi > s_lo) RB_HIP(hipMemcpyAsync(d_seqs + (s_lo - lo), seqs + s_lo, s_hi - s_lo, hipMemcpyHostToDevice, cs));
+        RB_HIP(hipMemcpyAsync(d_off + i0, offsets + i0, cnt * 8, hipMemcpyHostToDevice, cs));
+        RB_HIP(hipMemcpyAsync(d_len + i0, lens + i0, cnt * 4, hipMemcpyHostToDevice, cs));
+        RB_HIP(hipEventRecord(e->copy_ev[evi], cs));
+        RB_HIP(hipStreamWaitEvent(st, e->copy_ev[evi], 0));
+        rc = rb_classify_batch_device(e, d_base, d_off + i0, d_len + i0, cnt, max_len, error_rate, significance, mode,
+                                      d_max + i0 * nf, (int32_t *)e->d_best.p + i0, (uint8_t *)e->d_decision.p + i0,
+                                      (uint8_t *)e->d_status.p + i0, (void *)st);
+        if (rc != RB_OK) {
+            (void)hipStreamSynchronize(cs);
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+        i0 = i1;
+        ++slice;
+    }
+    if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, d_max, n * nf * 2, hipMemcpyDeviceToHost, st));
     if (!sharded) {
         if (out_best_target) RB_HIP(hipMemcpyAsync(out_best_target, e->d_best.p, n * 4, hipMemcpyDeviceToHost, st));
         if (out_decision) RB_HIP(hipMemcpyAsync(out_decision, e->d_decision.p, n, hipMemcpyDeviceToHost, st));

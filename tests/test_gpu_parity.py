@@ -342,6 +342,18 @@ def test_host_api_micro_and_large_paths():
     edec, est = po.batch_check_unblock([o], [], pool, offs, lens, n_threads=8)
     assert np.array_equal(dec, edec) and np.array_equal(st, est)
     assert 0 < dec.sum() < n
+    # the same batch in many PCIe slices (shuffled, aliasing offsets: slices re-copy shared bytes), ragged slice size,
+    # tiny slices, and no slicing at all
+    lens_r = rng.integers(0, 600, size=n).astype(np.uint32)
+    offs = rng.integers(1000, len(pool) - 600, size=n).astype(np.uint64)
+    exp_mc = po.batch_raw_max(o, pool, offs, lens_r, 8)
+    edec, est = po.batch_check_unblock([o], [], pool, offs, lens_r, n_threads=8)
+    for slice_bytes in (1 << 20, 777_777, 4096, 0):  # 4096: a dozen reads per slice, thousands of slices
+        eng.set_host_slice_bytes(slice_bytes)
+        mc, _, dec, st = eng.classify(pool, offs, lens_r)
+        assert np.array_equal(mc[:, 0], exp_mc), slice_bytes
+        assert np.array_equal(dec, edec) and np.array_equal(st, est), slice_bytes
+    eng.set_host_slice_bytes(32 << 20)
 
 
 def test_more_ranks_than_columns():
