@@ -267,6 +267,11 @@ RB_API int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads);
  * (src/IBF/IBFClassify.cpp:256-260).  0 serialises them on one stream.  Default on. */
 RB_API int rb_engine_set_overlap(rb_engine *e, int enabled);
 
+/* Latency kernel on wide filters (blocks of 17+ word columns): up to max_parts workgroups share one read, each wave
+ * walking 1/max_shares of a 64-k-mer tile (default 8 and 4); 0 or 1 parts = one workgroup per read.  The partial
+ * counters are added by the last workgroup to finish.  Results are identical. */
+RB_API int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t max_shares);
+
 /* Filters larger than table_bytes are gathered with non-temporal loads (default 512 MiB = 2x the Infinity
  * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);

@@ -90,6 +90,7 @@ SIGNATURES = {
     "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
+    "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
@@ -347,6 +348,9 @@ class Engine:
 
     def set_overlap(self, on):
         _check(lib().rb_engine_set_overlap(self.h, int(on)), "rb_engine_set_overlap")
+
+    def set_split_parts(self, max_parts, max_shares=4):
+        _check(lib().rb_engine_set_split_parts(self.h, max_parts, max_shares), "rb_engine_set_split_parts")
 
     def set_nt_threshold(self, table_bytes):
         _check(lib().rb_engine_set_nt_threshold(self.h, table_bytes), "rb_engine_set_nt_threshold")

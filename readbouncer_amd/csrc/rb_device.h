@@ -51,7 +51,10 @@ struct CountLaunch {
     uint32_t n_slices;            // column slices of 2^lg * wpl words
     int lg, wpl, planes;
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
-    int split_waves;              // >= 2: latency form, one workgroup of split_waves waves per read
+    int split_waves;              // >= 2: latency form, workgroups of split_waves waves
+    int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
+    uint64_t *split_ws;           // parts > 1: partial counters [filter][item][part][strand][wpl][planes][64]
+    uint32_t *split_tickets;      // parts > 1: arrival counters [filter][item], zero between launches
     uint16_t *out;
     uint32_t out_read_stride, out_slice_stride;
     // latency form only: n_fused > 0 = several filters in one launch (then f/col_begin/col_end above describe the first)
@@ -70,6 +73,8 @@ struct DecideParams {
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
+int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n_items, uint32_t max_parts, uint32_t max_sub,
+                     int *nw, int *sub);
 hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,
                                 uint32_t nf, uint32_t fidx, hipStream_t st);
 hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, const uint8_t *pre_status,

@@ -94,6 +94,8 @@ struct rb_engine {
     int shard_rank = 0, shard_world = 1;
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
+    uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
+    DevBuf d_split_ws, d_split_tickets;
     // threshold tables
     DevBuf d_thr;
     uint32_t thr_len = 0;
@@ -487,7 +489,7 @@ void rb_engine_destroy(rb_engine *e)
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     for (hipEvent_t ev : e->copy_ev) (void)hipEventDestroy(ev);
     for (DevBuf &b : e->d_parts) b.release();
-    for (DevBuf *b : {&e->d_efflens, &e->d_prestatus, &e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+    for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_efflens, &e->d_prestatus, &e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
     e->h_in.release();
@@ -509,6 +511,15 @@ int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads)
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
     std::lock_guard<std::mutex> lock(e->mu);
     e->split_threshold = max_reads;
+    return RB_OK;
+}
+
+int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t max_shares)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->split_max_parts = max_parts;
+    e->split_max_sub = max_shares ? max_shares : 1;
     return RB_OK;
 }
 
@@ -594,6 +605,26 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     e->thr_len = cap;
     e->thr_r = r;
     e->thr_conf = conf;
+    return RB_OK;
+}
+
+// workspace of a multi-workgroup latency launch: partial counters + arrival counters (zero between launches; a fresh
+// or grown allocation is zeroed on the stream that will use it)
+static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipStream_t st)
+{
+    if (a.split_parts <= 1) return RB_OK;
+    const size_t items = n_filters * (size_t)a.n_reads * a.n_slices;
+    const size_t np = a.planes <= 10 ? 10 : 16;
+    int rc = e->d_split_ws.ensure(items * (size_t)a.split_parts * 2 * (size_t)a.wpl * np * 64 * 8);
+    if (rc != RB_OK) return rc;
+    const void *old = e->d_split_tickets.p;
+    const size_t old_cap = e->d_split_tickets.cap;
+    rc = e->d_split_tickets.ensure(items * 4);
+    if (rc != RB_OK) return rc;
+    if (e->d_split_tickets.p != old || e->d_split_tickets.cap != old_cap)
+        RB_HIP(hipMemsetAsync(e->d_split_tickets.p, 0, e->d_split_tickets.cap, st));
+    a.split_ws = (uint64_t *)e->d_split_ws.p;
+    a.split_tickets = (uint32_t *)e->d_split_tickets.p;
     return RB_OK;
 }
 
@@ -731,6 +762,11 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
         a.split_waves = 0;
         if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
             a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
+        a.split_parts = 1;
+        a.split_sub = 1;
+        if (a.split_waves >= 2)
+            a.split_parts = split_parts_plan(a.wpl, a.planes, kmers, a.lg, (uint32_t)n_reads * a.n_slices, e->split_max_parts,
+                                             e->split_max_sub, &a.split_waves, &a.split_sub);
         if (a.n_slices == 1) {
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
@@ -739,6 +775,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
                 pending.push_back(a);  // micro-batch: fused below with the filters of equal kernel geometry
                 pending_fi.push_back((uint32_t)fi);
             } else {
+                if ((rc = ensure_split_ws(e, a, 1, fs)) != RB_OK) return rc;
                 RB_HIP(launch_ibf_count_max(a, fs));
             }
         } else {
@@ -747,6 +784,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             a.out = (uint16_t *)e->d_parts[fi].p;
             a.out_read_stride = 1;
             a.out_slice_stride = (uint32_t)n_reads;
+            if ((rc = ensure_split_ws(e, a, 1, fs)) != RB_OK) return rc;
             RB_HIP(launch_ibf_count_max(a, fs));
             RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, fs));
         }
@@ -761,7 +799,8 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
             for (size_t j = i; j < pending.size() && g.n_fused < (int)kMaxFused; ++j) {
                 const CountLaunch &b = pending[j];
                 if (done[j] || b.lg != g.lg || b.wpl != g.wpl || b.planes != g.planes || b.nt != g.nt ||
-                    b.split_waves != g.split_waves || b.f.n_hash != g.f.n_hash)
+                    b.split_waves != g.split_waves || b.split_parts != g.split_parts || b.split_sub != g.split_sub ||
+                    b.f.n_hash != g.f.n_hash)
                     continue;
                 g.fused_f[g.n_fused] = b.f;
                 g.fused_col_begin[g.n_fused] = b.col_begin;
@@ -771,6 +810,7 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
                 done[j] = true;
             }
             g.out = maxcount;  // per-filter column offsets travel in the set
+            if ((rc = ensure_split_ws(e, g, (size_t)g.n_fused, st)) != RB_OK) return rc;
             RB_HIP(launch_ibf_count_max(g, st));
         }
     }

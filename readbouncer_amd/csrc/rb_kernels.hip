@@ -216,14 +216,16 @@ struct BaseSrc {
 };
 
 // Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
-// mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves).
+// mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves) and of
+// each macro tile the eight-step blocks [blk_first, blk_end) (all STEPS / 8 of them, or a wave's share in the split kernel).
 template <int LG, int WPL, int NP, int H, bool NT>
 __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
                                              const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
-                                             uint32_t mt_first, uint32_t mt_step, uint8_t *stage, int lane)
+                                             uint32_t mt_first, uint32_t mt_step, int blk_first, int blk_end,
+                                             uint8_t *stage, int lane)
 {
     using T = TileShape<LG>;
-    constexpr int NG = T::NG, SPT = T::SPT, J = T::J, STEPS = T::STEPS, ITEMS = T::ITEMS;
+    constexpr int NG = T::NG, SPT = T::SPT, J = T::J, ITEMS = T::ITEMS;
     constexpr int HR = H > 0 ? H : 1;
     const int g = lane >> LG;
     const uint32_t S = f.stride;  // words between consecutive blocks in HBM (>= bin_width, see rb_engine.hip)
@@ -267,7 +269,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
         // address) and are masked out of the result -- a branch per step would make the compiler drain the
         // memory pipe after every step (3 loads in flight instead of 24).
 #pragma unroll 1
-        for (int blk = 0; blk < STEPS / 8; ++blk) {
+        for (int blk = blk_first; blk < blk_end; ++blk) {
             {
                 const int s0 = blk * 8;
                 const uint32_t first = mt + (uint32_t)((s0 / SPT) * 64 + (s0 % SPT) * NG);
@@ -405,21 +407,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
         Planes<NP> pl[WPL];
 #pragma unroll
         for (int w = 0; w < WPL; ++w) pl[w].clear();
-        count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, s_stage[wave], lane);
+        count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0,
+                                         TileShape<LG>::STEPS / 8, s_stage[wave], lane);
         const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
         best = m > best ? m : best;
     }
     if (lane == 0) out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)best;
 }
 
-// latency form for micro-batches: one workgroup per (read, column slice); wave w takes strand w&1 and every
-// (blockDim/128)-th macro tile starting at w>>1.  Partial counters meet in LDS (bit-sliced adds), then max.
-template <int LG, int WPL, int NP, int H, bool NT>
+// latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
+// slot = p * (waves/2) + (w>>1) of the per-strand work: share slot % sub of the eight-step blocks of every
+// (slots/sub)-th macro tile starting at slot / sub.  Partial counters meet in LDS (bit-sliced adds); with parts > 1 the
+// workgroups leave their sums in a workspace and the last one to finish (ticket counter) adds them and takes the max.
+// A wide filter is latency bound per read -- 2088 dependent-free gathers, but only 12-24 of them in flight per wave --
+// so the way to a short kernel is more waves per read than one workgroup holds.
 // blockIdx.y selects one filter of the set: filters of equal kernel geometry share ONE launch (a micro-batch against
 // deplete + several targets would otherwise queue one short kernel per filter, ~25 us each).
+template <int LG, int WPL, int NP, int H, bool NT>
 __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
     FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
-    uint32_t out_read_stride, uint32_t out_slice_stride)
+    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t parts, uint32_t sub, uint64_t *__restrict__ ws,
+    uint32_t *__restrict__ tickets)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
     const IbfDev &f = set.f[blockIdx.y];
@@ -428,13 +436,17 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
-    const int per_strand = n_waves >> 1;
-    const int strand = wave & 1, slot = wave >> 1;
-    const uint32_t read = blockIdx.x / n_slices;
-    const uint32_t slice = blockIdx.x - read * n_slices;
+    const int wps = n_waves >> 1;  // waves per strand in this workgroup
+    const int strand = wave & 1, lslot = wave >> 1;
+    const uint32_t item = blockIdx.x / parts;
+    const uint32_t part = blockIdx.x - item * parts;
+    const uint32_t read = item / n_slices;
+    const uint32_t slice = item - read * n_slices;
+    const uint32_t slots = (uint32_t)wps * parts;  // per strand, over all parts
+    const uint32_t slot = part * (uint32_t)wps + (uint32_t)lslot;
 
     uint64_t *s_planes = reinterpret_cast<uint64_t *>(s_dyn);  // [wave][WPL][NP][64]
-    uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);
+    uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);  // [0..1] maxima, [2] ticket
     uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
 
     const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
@@ -442,21 +454,26 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
     const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     constexpr uint32_t ITEMS = TileShape<LG>::ITEMS;
+    constexpr int BPT = TileShape<LG>::STEPS / 8;  // eight-step blocks per macro tile
+    const int bps = BPT / (int)sub;                // ... per share (sub divides BPT and slots)
+    const int sb = (int)(slot % sub);
 
     Planes<NP> pl[WPL];
 #pragma unroll
     for (int w = 0; w < WPL; ++w) pl[w].clear();
-    count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, (uint32_t)slot * ITEMS, (uint32_t)per_strand * ITEMS, stage, lane);
+    count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, (slot / sub) * ITEMS, (slots / sub) * ITEMS, sb * bps,
+                                     (sb + 1) * bps, stage, lane);
 
-    if (slot != 0) {
+    if (lslot != 0) {
 #pragma unroll
         for (int w = 0; w < WPL; ++w)
 #pragma unroll
             for (int i = 0; i < NP; ++i) s_planes[(((size_t)wave * WPL + w) * NP + i) * 64 + lane] = pl[w].p[i];
     }
     __syncthreads();
-    if (slot == 0) {
-        for (int o = 1; o < per_strand; ++o) {
+    const size_t gitem = (size_t)blockIdx.y * ((size_t)n_reads * n_slices) + item;
+    if (lslot == 0) {
+        for (int o = 1; o < wps; ++o) {
             const int ow = (o << 1) | strand;
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
@@ -471,10 +488,54 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
                 }
             }
         }
-        const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
-        if (lane == 0) s_max[strand] = m;
+        if (parts == 1) {
+            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
+            if (lane == 0) s_max[strand] = m;
+        } else {
+            uint64_t *dst = ws + ((gitem * parts + part) * 2 + (size_t)strand) * (WPL * NP * 64);
+#pragma unroll
+            for (int w = 0; w < WPL; ++w)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) dst[(w * NP + i) * 64 + lane] = pl[w].p[i];
+        }
     }
     __syncthreads();
+    if (parts > 1) {
+        // The last workgroup of this (read, slice, filter) to arrive owns the result.  One agent-scope release per
+        // workgroup (the barrier above orders the other waves' stores before it) and one acquire in the last one (the
+        // barrier below orders it before the other waves' loads): on gfx950 a release writes the XCD's L2 back, which
+        // costs about a microsecond and serialises per XCD -- fences per wave made 64-read batches 2.4x slower.
+        if (threadIdx.x == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(&tickets[gitem], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == parts - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_max[2] = t;
+        }
+        __syncthreads();
+        if (s_max[2] != parts - 1) return;  // workgroup-uniform
+        if (lslot == 0) {
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) pl[w].clear();
+            for (uint32_t q = 0; q < parts; ++q) {
+                const uint64_t *srcp = ws + ((gitem * parts + q) * 2 + (size_t)strand) * (WPL * NP * 64);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    uint64_t carry = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const uint64_t other = srcp[(w * NP + i) * 64 + lane];
+                        uint64_t h, l;
+                        RB_CSA(h, l, pl[w].p[i], other, carry);
+                        pl[w].p[i] = l;
+                        carry = h;
+                    }
+                }
+            }
+            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
+            if (lane == 0) s_max[strand] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) tickets[gitem] = 0;  // ready for the next launch on this stream
+    }
     if (threadIdx.x == 0) {
         const uint32_t a = s_max[0], b = s_max[1];
         out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)(a > b ? a : b);
@@ -697,9 +758,12 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
             if (e != hipSuccess) return e;
             attr_done.fetch_or(bit, std::memory_order_release);
         }
-        dim3 grid(a.n_reads * a.n_slices, set.n);
+        const uint32_t parts = a.split_parts > 1 ? (uint32_t)a.split_parts : 1u;
+        const uint32_t sub = a.split_sub > 1 ? (uint32_t)a.split_sub : 1u;
+        if (parts > 1 && (!a.split_ws || !a.split_tickets)) return hipErrorInvalidValue;
+        dim3 grid(a.n_reads * a.n_slices * parts, set.n);
         hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
-                           a.out_slice_stride);
+                           a.out_slice_stride, parts, sub, a.split_ws, a.split_tickets);
         return hipGetLastError();
     }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
@@ -729,6 +793,43 @@ int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
     if (wpl == 2 && nw > (np > 10 ? 8 : 12)) nw = np > 10 ? 8 : 12;  // those instantiations are built for 512 / 768 threads
     nw &= ~1;
     return nw >= 2 ? nw : 0;  // two waves = one per strand (reads that fit one macro tile, e.g. one-word filters)
+}
+
+// Several workgroups per read for the latency form (see ibf_count_max_split_kernel): worth it when a wave would
+// otherwise walk many eight-step blocks in sequence, i.e. for blocks of 32+ lanes (filters of 17+ word columns).
+// Returns parts (1 = keep the one-workgroup form and *nw untouched); with parts > 1 sets the waves per workgroup and
+// the shares per macro tile.  parts * (*nw / 2) is a multiple of *sub, and *sub divides the blocks per macro tile.
+int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n_items, uint32_t max_parts, uint32_t max_sub,
+                     int *nw, int *sub)
+{
+    *sub = 1;
+    if (max_parts <= 1 || lg < 5 || *nw < 2) return 1;
+    const int bpt = lg == 6 ? 8 : 4;           // TileShape<LG>::STEPS / 8
+    const uint32_t tiles = (max_kmers + 63) / 64;  // J == 1 for these shapes
+    if (tiles == 0) return 1;
+    const int np = planes <= 10 ? 10 : 16;
+    const int max_nw = (wpl == 2) ? (np > 10 ? 8 : 12) : 16;
+    const int wps = max_nw >= 8 ? 4 : 2;       // waves per strand and workgroup (a power of two)
+    uint32_t cap = max_parts;
+    // measured on the 8 GiB filter: beyond ~256 workgroups per launch the extra parts only queue behind each other
+    // (64 reads: 4 parts 67 us, 6 parts 87 us, 1 part 82 us; 256 reads: 1 part is best)
+    const uint32_t by_grid = n_items ? 256u / n_items : 1u;
+    if (cap > by_grid) cap = by_grid;
+    if (cap <= 1) return 1;
+    int s0 = 1;
+    while (s0 * 2 <= bpt && (uint32_t)(s0 * 2) <= max_sub) s0 *= 2;
+    for (int s = s0; s >= 1; s >>= 1) {
+        uint32_t p = (tiles * (uint32_t)s + (uint32_t)wps - 1) / (uint32_t)wps;
+        if (p > cap) p = cap;
+        const uint32_t m = s > wps ? (uint32_t)(s / wps) : 1u;
+        p = p / m * m;
+        if (p >= 2) {
+            *nw = 2 * wps;
+            *sub = s;
+            return (int)p;
+        }
+    }
+    return 1;
 }
 
 template <int NP, int H>

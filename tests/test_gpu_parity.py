@@ -92,6 +92,13 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     eng.set_split_threshold(2048)
     assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], expect)
     eng.set_nt_threshold(512 << 20)
+    # latency form with several workgroups per read (wide filters only; a no-op setting for the narrow ones):
+    # workgroups per read x shares per 64-k-mer tile, twice each (the arrival counters must come back to zero)
+    for parts, shares in ((1, 1), (2, 1), (8, 2), (8, 8), (3, 4), (16, 8), (8, 4)):
+        eng.set_split_parts(parts, shares)
+        for n_sub in (len(reads), 5, 5):
+            sub_mc = eng.classify(buf, offs[:n_sub], lens[:n_sub])[0][:, 0]
+            assert np.array_equal(sub_mc, expect[:n_sub]), (parts, shares, n_sub)
     # deplete-only decision + status against the oracle's check_unblock
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
     assert np.array_equal(decision, exp_dec)
@@ -116,8 +123,36 @@ def test_long_reads_use_wide_counters(n_bins, n_blocks):
     eng.set_split_threshold(0)
     assert np.array_equal(eng.classify(buf, offs, lens)[0], maxcount)
     eng.set_split_threshold(2048)
+    for parts, shares in ((1, 1), (8, 8), (5, 2)):
+        eng.set_split_parts(parts, shares)
+        assert np.array_equal(eng.classify(buf, offs, lens)[0], maxcount), (parts, shares)
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens)
     assert np.array_equal(decision, exp_dec) and np.array_equal(status, exp_st)
+
+
+def test_fused_wide_filters_with_split_parts():
+    """Four filters of one kernel geometry (40 word columns) share ONE latency launch; with several workgroups per
+    read the workspace and the arrival counters are indexed by (filter, read)."""
+    rng = np.random.default_rng(77)
+    ref = H.random_dna(rng, 40000)
+    filters, oracles, keep = [], [], []
+    for i in range(4):
+        d = capi.DeviceIBF.create(0, 2500 + 13 * i, 3, 13, 40 * 64 * (30011 + 7 * i))
+        d.add_sequence(ref[i * 10000:(i + 1) * 10000], 500)
+        o, h = oracle_view(d)
+        filters.append(d); oracles.append(o); keep.append(h)
+    reads = make_reads(rng, ref, 40, lo=10, hi=700)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, filters[:2], filters[2:])
+    exp = np.stack([po.batch_raw_max(o, buf, offs, lens, 4) for o in oracles], axis=1)
+    edec, est = po.batch_check_unblock(oracles[:2], oracles[2:], buf, offs, lens, n_threads=4)
+    for parts, shares in ((8, 4), (1, 1), (4, 8), (8, 4)):
+        eng.set_split_parts(parts, shares)
+        for n_sub in (len(reads), 3, len(reads)):
+            mc, _, dec, st = eng.classify(buf, offs[:n_sub], lens[:n_sub])
+            assert np.array_equal(mc, exp[:n_sub]), (parts, shares, n_sub)
+            assert np.array_equal(dec, edec[:n_sub]) and np.array_equal(st, est[:n_sub])
+    assert len(set(edec.tolist())) >= 2
 
 
 def test_fill_kernel_matches_oracle_definition():
