@@ -69,6 +69,7 @@ struct DecideParams {
     const uint16_t *thr;  // [nf][2][thr_len]: thresholds at r and at r-0.02 by read length
     uint32_t thr_len;
     uint32_t max_len;  // declared upper bound of the read lengths of this batch
+    uint16_t *maxcount_copy;  // optional second destination of the maxcount rows (pinned host memory of the micro-batch path)
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);

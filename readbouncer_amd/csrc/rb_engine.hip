@@ -630,7 +630,7 @@ static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipSt
 
 static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
                       size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
-                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st)
+                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr)
 {
     int rc = ensure_thresholds(e, max_len, r, conf, st);
     if (rc != RB_OK) return rc;
@@ -641,6 +641,7 @@ static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *
     P.thr = (const uint16_t *)e->d_thr.p;
     P.thr_len = e->thr_len;
     P.max_len = max_len;
+    P.maxcount_copy = maxcount_copy;
     RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
 }
@@ -662,8 +663,12 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
                                        d_status, stream);
 }
 
-int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
-                                void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream)
+}  // extern "C"
+
+// host_maxcount: optional pinned host destination for a copy of the maxcount rows, written by the decision kernel
+static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
+                                void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream,
+                                uint16_t *host_maxcount)
 {
     if (!e || !desc) return rb::fail(RB_ERR_INVALID_ARG, "null engine or descriptor");
     if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK) return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
@@ -823,11 +828,20 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
     if (evp) RB_HIP(hipEventRecord(evp->second, st));
     if (e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
         rc = run_decide(e, maxcount, (const uint32_t *)d_lens, d_pre_status, n_reads, max_len, error_rate, significance,
-                        mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+                        mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st, host_maxcount);
         if (rc != RB_OK) return rc;
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     return RB_OK;
+}
+
+extern "C" {
+
+int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
+                                void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream)
+{
+    return classify_device_impl(e, desc, error_rate, significance, mode, d_maxcount, d_best_target, d_decision, d_status,
+                                stream, nullptr);
 }
 
 int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads, uint32_t max_len,
@@ -871,7 +885,8 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
     const bool sharded = e->shard_world != 1;
 
     if (sum_len + 16 * n <= ((uint64_t)8 << 20)) {
-        // ---- micro-batch path: one pinned staging block each way -> one H2D and one D2H copy.
+        // ---- micro-batch path: one pinned staging block each way -> one H2D copy in; results are written into the pinned
+        // output block by the decision kernel itself.
         // in : u64 offsets[n] | u32 lens[n] | compacted read bytes      out: i32 best[n] | u16 maxcount[n*nf] | u8 decision[n] | u8 status[n]
         const size_t in_bytes = 12 * n + (size_t)sum_len + 1;
         const size_t out_bytes = 4 * n + 2 * nf * n + 2 * n;
@@ -894,17 +909,29 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         }
         char *din = (char *)e->d_seqs.p;
         char *dout = (char *)e->d_maxcount.p;
+        char *hout = (char *)e->h_out.p;
         RB_HIP(hipMemcpyAsync(din, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
-        int32_t *d_best = (int32_t *)dout;
+        rb_batch_desc desc;
+        std::memset(&desc, 0, sizeof desc);
+        desc.d_seqs = din + 12 * n;
+        desc.d_offsets = din;
+        desc.d_lens = din + 8 * n;
+        desc.n_items = n;
+        desc.max_len = max_len;
         uint16_t *d_max = (uint16_t *)(dout + 4 * n);
-        uint8_t *d_dec = (uint8_t *)(dout + 4 * n + 2 * nf * n);
-        uint8_t *d_st = d_dec + n;
-        rc = rb_classify_batch_device(e, din + 12 * n, din, din + 8 * n, n, max_len, error_rate, significance, mode, d_max,
-                                      d_best, d_dec, d_st, (void *)st);
-        if (rc != RB_OK) return rc;
-        RB_HIP(hipMemcpyAsync(e->h_out.p, dout, out_bytes, hipMemcpyDeviceToHost, st));
+        if (!sharded) {
+            // the decision kernel writes its results (and a copy of the maxcount rows) straight into the pinned block:
+            // posted PCIe writes, no device-to-host copy command behind the kernels (one dependent launch less per call)
+            rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max, hout, hout + 4 * n + 2 * nf * n,
+                                      hout + 4 * n + 2 * nf * n + n, (void *)st, (uint16_t *)(hout + 4 * n));
+            if (rc != RB_OK) return rc;
+        } else {
+            rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max, nullptr, nullptr, nullptr, (void *)st,
+                                      nullptr);
+            if (rc != RB_OK) return rc;
+            RB_HIP(hipMemcpyAsync(hout + 4 * n, d_max, 2 * nf * n, hipMemcpyDeviceToHost, st));
+        }
         RB_HIP(hipStreamSynchronize(st));
-        const char *hout = (const char *)e->h_out.p;
         if (out_maxcount) std::memcpy(out_maxcount, hout + 4 * n, 2 * nf * n);
         if (!sharded) {
             if (out_best_target) std::memcpy(out_best_target, hout, 4 * n);

@@ -580,6 +580,10 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
+    if (P.maxcount_copy) {
+        for (uint32_t fi = 0; fi < P.nd + P.nt; ++fi)
+            P.maxcount_copy[(size_t)i * (P.nd + P.nt) + fi] = maxcount[(size_t)i * (P.nd + P.nt) + fi];
+    }
     if (pre_status && pre_status[i] != RB_OK) {  // e.g. a chunk beyond the end of the read: no decision
         if (out_best_target) out_best_target[i] = -1;
         if (out_decision) out_decision[i] = 0;
