@@ -175,7 +175,10 @@ RB_API int rb_classify_batch_ptrs(rb_engine *e, const char *const *seq_ptrs, con
 /* Same with every buffer already resident in HBM (device pointers) and asynchronous on
  * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
  * before returning).  max_len = an upper bound of lens[] (a longer read gets status RB_ERR_INVALID_ARG).  The inputs must be complete on `stream`
- * (work that produces them on another stream has to be ordered before this call by the caller). */
+ * (work that produces them on another stream has to be ordered before this call by the caller).  An engine's
+ * workspaces (partial maxima, threshold tables, arrival counters) are per engine: calls on one engine may come from
+ * several threads, but their GPU work must be ordered -- use one stream per engine, or order the streams with events;
+ * for independent streams create one engine per stream (filters are shared, not copied). */
 RB_API int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens,
                                     size_t n_reads, uint32_t max_len, double error_rate, double significance,
                                     int mode, void *d_maxcount, void *d_best_target, void *d_decision,

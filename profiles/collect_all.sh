@@ -14,6 +14,8 @@ python3 bench.py --workload grch38_f100k --steps 3 --warmup 1 --cpu-seconds 8 > 
 python3 bench.py --workload c1 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/bench_c1.json 2> /dev/null
 python3 bench.py --workload c5 > $OUT/bench_c5_150k.json 2> /dev/null
 python3 bench.py --workload c5 --rate 18750 > $OUT/bench_c5_18750.json 2> /dev/null
+python3 profiles/latency_floor.py 2>/dev/null > $OUT/latency_floor.txt
+python3 profiles/latency_wide.py 2>/dev/null > $OUT/latency_wide.txt
 cd /tmp && export TMPDIR=/tmp
 for w in c2 c3 c4; do
   N=1000000; [ $w != c2 ] && N=2000000

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Turns the scratch output of `profiles/collect_all.sh <tag>` (gpurun_out/<tag>) into the tracked evidence:
+profiles/<round>/{bench_*.json, *_kernel_stats.csv, pmc_summary.csv, hbm_peak_raw.txt, latency_*.txt} and
+profiles/traffic.json (HBM bytes per launch of the count kernel from the separate --pmc passes, corrected as
+MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and gfx950 reports 128-byte requests at 64 bytes).
+Usage: python3 profiles/summarize.py gpurun_out/r01e profiles/r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+os.makedirs(dst, exist_ok=True)
+
+for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(src, "latency_*.txt")):
+    shutil.copy(f, dst)
+if os.path.exists(os.path.join(src, "hbm_peak.txt")):
+    shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
+for w in ("c2", "c3", "c4", "c5"):
+    hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
+    if hits:
+        shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
+
+
+def counter_means(path):
+    """{counter: (dispatches, mean value, mean kernel ms)} over the dispatches of the throughput count kernel"""
+    acc = {}
+    with open(path, newline="") as fh:
+        for r in csv.DictReader(fh):
+            if "ibf_count_max_kernel" not in r["Kernel_Name"]:
+                continue
+            a = acc.setdefault(r["Counter_Name"], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    return {k: (n, v / n, ms / n) for k, (n, v, ms) in acc.items()}
+
+
+from readbouncer_amd import synth  # noqa: E402
+
+rows, traffic = [], {}
+for w in ("c2", "c3"):
+    d = os.path.join(src, "pmc_" + w)
+    if not os.path.isdir(d):
+        continue
+    m = {}
+    for p in ("fetch", "l2", "ea", "sq"):
+        hits = glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)
+        if not hits:
+            continue
+        for name, (n, v, ms) in counter_means(hits[0]).items():
+            rows.append((w, p, name, n, v, ms))
+            m[name] = v
+    if "FETCH_SIZE" not in m:
+        continue
+    reads = 1_000_000
+    wl = synth.WORKLOADS[w]
+    alg = synth.algorithmic_bytes_per_read(wl["read_len"], [(wl["n_bins"], wl["k"], wl["h"])])
+    hbm = m["FETCH_SIZE"] * 1024 * 2
+    traffic[w] = {
+        "reads_per_launch": reads,
+        "FETCH_SIZE_KiB": m["FETCH_SIZE"],
+        "hbm_bytes_per_launch": hbm,
+        "hbm_bytes_per_read": hbm / reads,
+        "TCC_EA0_RDREQ": m.get("TCC_EA0_RDREQ_sum"),
+        "rdreq_x128B": m.get("TCC_EA0_RDREQ_sum", 0) * 128,
+        "algorithmic_bytes_per_read": alg,
+        "traffic_over_algorithmic": hbm / reads / alg,
+        "l2_hit_rate": m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) if "TCC_HIT_sum" in m else None,
+        "valu_insts_per_read": m.get("SQ_INSTS_VALU", 0) / reads,
+        "wait_any_frac_of_wave_cycles": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+        "note": "separate rocprofv3 --pmc passes (profiles/collect_pmc.sh); FETCH_SIZE x1024 x2 per MI355X_MICROARCH.md "
+                "HBM section; cross-checked by TCC_EA0_RDREQ x 128 B",
+    }
+with open(os.path.join(dst, "pmc_summary.csv"), "w") as fh:
+    fh.write("workload,pass,counter,dispatches,mean_value,mean_kernel_ms\n")
+    for r in rows:
+        fh.write("%s,%s,%s,%d,%g,%.3f\n" % r)
+if traffic:
+    with open(os.path.join(root, "profiles", "traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+for w, t in traffic.items():
+    print(w, "traffic/algorithmic %.4f" % t["traffic_over_algorithmic"], "rdreq x128 / fetch %.4f" % (t["rdreq_x128B"] / t["hbm_bytes_per_launch"]))

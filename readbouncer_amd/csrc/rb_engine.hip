@@ -608,6 +608,74 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     return RB_OK;
 }
 
+// Kernel geometry of one filter for a batch: the rank's word columns (bin-sharded operation), lanes per block, words
+// per lane, counter planes, column slices, and the form of K1 (throughput, or latency with its waves / workgroups per
+// read).  false = this rank owns no column of the filter.
+static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, uint32_t max_len, CountLaunch &a)
+{
+    const uint32_t W = (uint32_t)f->geo.bin_width;
+    // bin-sharded operation: contiguous word-column range of every block per rank
+    uint32_t per = (W + e->shard_world - 1) / e->shard_world;
+    if (e->shard_world > 1 && (per & 1)) ++per;  // keep 16-byte alignment of the slices
+    a.col_begin = std::min<uint32_t>(W, per * e->shard_rank);
+    a.col_end = std::min<uint32_t>(W, a.col_begin + per);
+    const uint32_t Weff = a.col_end - a.col_begin;
+    const uint32_t kmers = max_len >= f->geo.kmer_size ? max_len - (uint32_t)f->geo.kmer_size + 1 : 0;
+    a.planes = kmers <= 1023 ? 10 : 16;
+    a.nt = f->geo.n_blocks * f->stride * 8 > e->nt_threshold_bytes;
+    if (Weff == 0) return false;
+    if (Weff > 64 && (a.col_begin % 2 == 0)) {  // 16 bytes per lane; odd widths end in a one-column lane
+        a.wpl = 2; a.lg = 6;
+    } else {
+        a.wpl = 1; a.lg = 0;
+        while ((1u << a.lg) < std::min<uint32_t>(Weff, 64)) ++a.lg;
+    }
+    const uint32_t slice_words = (1u << a.lg) * a.wpl;
+    a.n_slices = (Weff + slice_words - 1) / slice_words;
+    // micro-batches cannot fill 256 CUs with one wave per read: spread each read over a workgroup, or several
+    a.split_waves = 0;
+    if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
+        a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
+    a.split_parts = 1;
+    a.split_sub = 1;
+    if (a.split_waves >= 2)
+        a.split_parts = split_parts_plan(a.wpl, a.planes, kmers, a.lg, (uint32_t)n_reads * a.n_slices, e->split_max_parts,
+                                         e->split_max_sub, &a.split_waves, &a.split_sub);
+    return true;
+}
+
+static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipStream_t st);
+
+// micro-batches: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves, parts)
+static int launch_fused_groups(rb_engine *e, const std::vector<CountLaunch> &pending, const std::vector<uint32_t> &pending_fi,
+                               uint16_t *maxcount, hipStream_t st)
+{
+    std::vector<bool> done(pending.size(), false);
+    for (size_t i = 0; i < pending.size(); ++i) {
+        if (done[i]) continue;
+        CountLaunch g = pending[i];
+        g.n_fused = 0;
+        for (size_t j = i; j < pending.size() && g.n_fused < (int)kMaxFused; ++j) {
+            const CountLaunch &b = pending[j];
+            if (done[j] || b.lg != g.lg || b.wpl != g.wpl || b.planes != g.planes || b.nt != g.nt ||
+                b.split_waves != g.split_waves || b.split_parts != g.split_parts || b.split_sub != g.split_sub ||
+                b.f.n_hash != g.f.n_hash)
+                continue;
+            g.fused_f[g.n_fused] = b.f;
+            g.fused_col_begin[g.n_fused] = b.col_begin;
+            g.fused_col_end[g.n_fused] = b.col_end;
+            g.fused_out_offset[g.n_fused] = pending_fi[j];
+            ++g.n_fused;
+            done[j] = true;
+        }
+        g.out = maxcount;  // per-filter column offsets travel in the set
+        int rc = ensure_split_ws(e, g, (size_t)g.n_fused, st);
+        if (rc != RB_OK) return rc;
+        RB_HIP(launch_ibf_count_max(g, st));
+    }
+    return RB_OK;
+}
+
 // workspace of a multi-workgroup latency launch: partial counters + arrival counters (zero between launches; a fresh
 // or grown allocation is zeroed on the stream that will use it)
 static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipStream_t st)
@@ -740,38 +808,11 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         a.src.ids = (const uint32_t *)desc->d_read_ids;
         a.src.base_off = desc->chunk_start;
         a.n_reads = (uint32_t)n_reads;
-        const uint32_t W = (uint32_t)f->geo.bin_width;
-        // bin-sharded operation: contiguous word-column range of every block per rank
-        uint32_t per = (W + e->shard_world - 1) / e->shard_world;
-        if (e->shard_world > 1 && (per & 1)) ++per;  // keep 16-byte alignment of the slices
-        a.col_begin = std::min<uint32_t>(W, per * e->shard_rank);
-        a.col_end = std::min<uint32_t>(W, a.col_begin + per);
-        const uint32_t Weff = a.col_end - a.col_begin;
-        const uint32_t kmers = max_len >= f->geo.kmer_size ? max_len - (uint32_t)f->geo.kmer_size + 1 : 0;
-        a.planes = kmers <= 1023 ? 10 : 16;
-        a.nt = f->geo.n_blocks * f->stride * 8 > e->nt_threshold_bytes;
-        if (Weff == 0) {
+        if (!plan_geometry(e, f, n_reads, max_len, a)) {
             // this rank holds no column of this filter: its partial maxima are 0
             RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, fs));
             continue;
         }
-        if (Weff > 64 && (a.col_begin % 2 == 0)) {  // 16 bytes per lane; odd widths end in a one-column lane
-            a.wpl = 2; a.lg = 6;
-        } else {
-            a.wpl = 1; a.lg = 0;
-            while ((1u << a.lg) < std::min<uint32_t>(Weff, 64)) ++a.lg;
-        }
-        const uint32_t slice_words = (1u << a.lg) * a.wpl;
-        a.n_slices = (Weff + slice_words - 1) / slice_words;
-        // micro-batches cannot fill 256 CUs with one wave per read: spread each read over a workgroup
-        a.split_waves = 0;
-        if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
-            a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
-        a.split_parts = 1;
-        a.split_sub = 1;
-        if (a.split_waves >= 2)
-            a.split_parts = split_parts_plan(a.wpl, a.planes, kmers, a.lg, (uint32_t)n_reads * a.n_slices, e->split_max_parts,
-                                             e->split_max_sub, &a.split_waves, &a.split_sub);
         if (a.n_slices == 1) {
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
@@ -794,31 +835,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
             RB_HIP(launch_reduce_slices(a.out, a.n_slices, (uint32_t)n_reads, maxcount, (uint32_t)nf, (uint32_t)fi, fs));
         }
     }
-    // micro-batches: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves)
-    {
-        std::vector<bool> done(pending.size(), false);
-        for (size_t i = 0; i < pending.size(); ++i) {
-            if (done[i]) continue;
-            CountLaunch g = pending[i];
-            g.n_fused = 0;
-            for (size_t j = i; j < pending.size() && g.n_fused < (int)kMaxFused; ++j) {
-                const CountLaunch &b = pending[j];
-                if (done[j] || b.lg != g.lg || b.wpl != g.wpl || b.planes != g.planes || b.nt != g.nt ||
-                    b.split_waves != g.split_waves || b.split_parts != g.split_parts || b.split_sub != g.split_sub ||
-                    b.f.n_hash != g.f.n_hash)
-                    continue;
-                g.fused_f[g.n_fused] = b.f;
-                g.fused_col_begin[g.n_fused] = b.col_begin;
-                g.fused_col_end[g.n_fused] = b.col_end;
-                g.fused_out_offset[g.n_fused] = pending_fi[j];
-                ++g.n_fused;
-                done[j] = true;
-            }
-            g.out = maxcount;  // per-filter column offsets travel in the set
-            if ((rc = ensure_split_ws(e, g, (size_t)g.n_fused, st)) != RB_OK) return rc;
-            RB_HIP(launch_ibf_count_max(g, st));
-        }
-    }
+    if ((rc = launch_fused_groups(e, pending, pending_fi, maxcount, st)) != RB_OK) return rc;
     if (fan_out) {
         for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) {
             RB_HIP(hipEventRecord(e->join_ev[k], e->aux[k]));
