@@ -1,5 +1,7 @@
 """Seeded differential fuzzing of the HIP path against the oracle over random filter geometries (bins, blocks,
 k, h), read lengths and alphabets -- the corner cases nobody thought of listing."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,7 +12,8 @@ from readbouncer_amd import capi
 from tests import helpers as H
 
 
-@pytest.mark.parametrize("seed", range(24))
+# RB_FUZZ_SEEDS=<n> widens the sweep for an offline soak (profiles/r01/deep_parity.txt)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RB_FUZZ_SEEDS", "24"))))
 def test_random_geometry(seed):
     rng = np.random.default_rng(1000 + seed)
     n_bins = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 9000)), int(rng.integers(1, 700))]))
@@ -55,3 +58,9 @@ def test_random_geometry(seed):
         mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
         assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, split)
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, split)
+    # latency form with several workgroups per read (wide filters), on the batch and on a few reads of it (more parts)
+    eng.set_split_threshold(2048)
+    eng.set_split_parts(int(rng.choice([2, 3, 8, 16])), int(rng.choice([1, 2, 4, 8])))
+    for n_sub in (len(reads), 7, 2):
+        mc = eng.classify(buf, offs[:n_sub], lens[:n_sub], error_rate=r_err)[0]
+        assert np.array_equal(mc[:, 0], exp_max[:n_sub]), (n_bins, k, h, n_blocks, "parts", n_sub)
