@@ -34,12 +34,17 @@ struct ReadSrc {
 };
 
 constexpr unsigned kMaxFused = 8;
+constexpr int kSplitAnyWaves = 8;  // waves per workgroup of the mixed-geometry latency kernel (built for 512 threads)
 
-// by-value kernel argument of the latency kernel: up to 8 filters of equal kernel geometry served by one launch
+// by-value kernel argument: up to 8 filters served by one launch (blockIdx.y picks one).  The throughput kernel takes
+// filters of one kernel geometry; the latency kernel takes any mix and reads the geometry per filter.
 struct FilterSet {
     uint32_t n;
     uint32_t col_begin[kMaxFused], col_end[kMaxFused];
     uint32_t out_offset[kMaxFused];  // element offset of the filter's column in the output
+    uint32_t geom[kMaxFused];        // latency kernel: lg | (wpl == 2 ? 8 : 0) | (nt ? 16 : 0)
+    uint32_t parts[kMaxFused];       // latency kernel: workgroups per (read, slice) that work for this filter (<= grid parts)
+    uint32_t sub[kMaxFused];         // latency kernel: shares per macro tile
     IbfDev f[kMaxFused];
 };
 
@@ -53,7 +58,8 @@ struct CountLaunch {
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
-    uint64_t *split_ws;           // parts > 1: partial counters [filter][item][part][strand][wpl][planes][64]
+    int grid_parts;               // latency form: workgroups launched per (read, slice) = max parts of the fused filters
+    uint64_t *split_ws;           // parts > 1: partial counters [filter][item][grid part][strand][2][planes][64]
     uint32_t *split_tickets;      // parts > 1: arrival counters [filter][item], zero between launches
     uint16_t *out;
     uint32_t out_read_stride, out_slice_stride;
@@ -61,7 +67,10 @@ struct CountLaunch {
     int n_fused;
     IbfDev fused_f[kMaxFused];
     uint32_t fused_col_begin[kMaxFused], fused_col_end[kMaxFused], fused_out_offset[kMaxFused];
+    uint8_t fused_geom[kMaxFused], fused_parts[kMaxFused], fused_sub[kMaxFused];  // latency form, see FilterSet
 };
+
+inline uint8_t geom_code(int lg, int wpl, int nt) { return (uint8_t)(lg | (wpl == 2 ? 8 : 0) | (nt ? 16 : 0)); }
 
 struct DecideParams {
     uint32_t nd, nt;
@@ -74,6 +83,7 @@ struct DecideParams {
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
+int split_waves_cap(int wpl, int planes, int lg);
 int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n_items, uint32_t max_parts, uint32_t max_sub,
                      int *nw, int *sub);
 hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,

@@ -646,27 +646,51 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
 
 static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipStream_t st);
 
-// micro-batches: one launch per group of filters that share (lanes per block, words per lane, planes, NT, waves, parts)
+// micro-batches: filters of equal kernel geometry share a launch; beyond that, the filters whose latency form applies
+// share ONE launch of the mixed-geometry kernel when the batch is small or their wave counts are close (the wide deplete
+// filter then hides the narrow targets: 52 -> 41 us per call on config 4).  With many reads per call a shared workgroup
+// size wastes LDS and wave slots on the filters that need few waves, so those keep their own launches.
 static int launch_fused_groups(rb_engine *e, const std::vector<CountLaunch> &pending, const std::vector<uint32_t> &pending_fi,
                                uint16_t *maxcount, hipStream_t st)
 {
+    int lo = 1 << 30, hi = 0;
+    for (const CountLaunch &b : pending)
+        if (b.split_waves >= 2) { lo = std::min(lo, b.split_waves); hi = std::max(hi, b.split_waves); }
+    const bool mix = hi > 0 && (pending[0].n_reads <= 64 || hi <= 2 * lo);
     std::vector<bool> done(pending.size(), false);
     for (size_t i = 0; i < pending.size(); ++i) {
         if (done[i]) continue;
         CountLaunch g = pending[i];
+        const bool split = g.split_waves >= 2;
         g.n_fused = 0;
+        int want_waves = 0, grid_parts = 1;
+        bool same = true, multi = false;
         for (size_t j = i; j < pending.size() && g.n_fused < (int)kMaxFused; ++j) {
             const CountLaunch &b = pending[j];
-            if (done[j] || b.lg != g.lg || b.wpl != g.wpl || b.planes != g.planes || b.nt != g.nt ||
-                b.split_waves != g.split_waves || b.split_parts != g.split_parts || b.split_sub != g.split_sub ||
-                b.f.n_hash != g.f.n_hash)
-                continue;
+            if (done[j] || (b.split_waves >= 2) != split || b.planes != g.planes || b.f.n_hash != g.f.n_hash) continue;
+            const bool same_geometry = b.lg == g.lg && b.wpl == g.wpl && b.nt == g.nt;
+            if (!same_geometry && !(split && mix)) continue;
+            if (split && same_geometry && (b.split_waves != g.split_waves) && !mix) continue;
             g.fused_f[g.n_fused] = b.f;
             g.fused_col_begin[g.n_fused] = b.col_begin;
             g.fused_col_end[g.n_fused] = b.col_end;
             g.fused_out_offset[g.n_fused] = pending_fi[j];
+            g.fused_geom[g.n_fused] = geom_code(b.lg, b.wpl, b.nt);
+            g.fused_parts[g.n_fused] = (uint8_t)(b.split_parts > 1 ? b.split_parts : 1);
+            g.fused_sub[g.n_fused] = (uint8_t)(b.split_sub > 1 ? b.split_sub : 1);
+            same &= same_geometry;
+            multi |= b.split_parts > 1;
+            want_waves = std::max(want_waves, b.split_waves);
+            grid_parts = std::max(grid_parts, b.split_parts);
             ++g.n_fused;
             done[j] = true;
+        }
+        if (split) {
+            // a filter spread over several workgroups was planned for 2 x 4 waves (= kSplitAnyWaves); filters that
+            // keep one workgroup adapt to any even wave count
+            if (!same) g.split_waves = std::min(want_waves, kSplitAnyWaves);
+            else if (multi) g.split_waves = kSplitAnyWaves;
+            g.grid_parts = grid_parts;
         }
         g.out = maxcount;  // per-filter column offsets travel in the set
         int rc = ensure_split_ws(e, g, (size_t)g.n_fused, st);
@@ -680,10 +704,12 @@ static int launch_fused_groups(rb_engine *e, const std::vector<CountLaunch> &pen
 // or grown allocation is zeroed on the stream that will use it)
 static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipStream_t st)
 {
-    if (a.split_parts <= 1) return RB_OK;
+    if (a.split_waves < 2) return RB_OK;
+    if (a.grid_parts < 1) a.grid_parts = a.split_parts > 1 ? a.split_parts : 1;
+    if (a.grid_parts <= 1) return RB_OK;
     const size_t items = n_filters * (size_t)a.n_reads * a.n_slices;
     const size_t np = a.planes <= 10 ? 10 : 16;
-    int rc = e->d_split_ws.ensure(items * (size_t)a.split_parts * 2 * (size_t)a.wpl * np * 64 * 8);
+    int rc = e->d_split_ws.ensure(items * (size_t)a.grid_parts * 2 * 2 * np * 64 * 8);
     if (rc != RB_OK) return rc;
     const void *old = e->d_split_tickets.p;
     const size_t old_cap = e->d_split_tickets.cap;

@@ -421,25 +421,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 // workgroups leave their sums in a workspace and the last one to finish (ticket counter) adds them and takes the max.
 // A wide filter is latency bound per read -- 2088 dependent-free gathers, but only 12-24 of them in flight per wave --
 // so the way to a short kernel is more waves per read than one workgroup holds.
-// blockIdx.y selects one filter of the set: filters of equal kernel geometry share ONE launch (a micro-batch against
-// deplete + several targets would otherwise queue one short kernel per filter, ~25 us each).
+// blockIdx.y selects one filter of the set; all filters of a micro-batch share ONE launch whatever their geometry (a
+// micro-batch against deplete + several targets would otherwise queue one short kernel per filter, 10-25 us each, and
+// the short kernel of a narrow target would wait for the long one of the wide deplete filter instead of hiding in it).
+// The launch has grid_parts workgroups per (read, slice); a filter that wants fewer leaves the others idle.
 template <int LG, int WPL, int NP, int H, bool NT>
-__global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_count_max_split_kernel(
-    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
-    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t parts, uint32_t sub, uint64_t *__restrict__ ws,
-    uint32_t *__restrict__ tickets)
+__device__ __forceinline__ void split_body(const IbfDev &f, uint32_t col_begin, uint32_t col_end, uint32_t parts,
+                                           uint32_t sub, const ReadSrc &src, uint32_t n_reads, uint32_t n_slices,
+                                           uint16_t *__restrict__ out, uint32_t out_read_stride,
+                                           uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+                                           uint32_t *__restrict__ tickets, uint8_t *s_dyn)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const IbfDev &f = set.f[blockIdx.y];
-    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
-    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n_waves = blockDim.x >> 6;
     const int wps = n_waves >> 1;  // waves per strand in this workgroup
     const int strand = wave & 1, lslot = wave >> 1;
-    const uint32_t item = blockIdx.x / parts;
-    const uint32_t part = blockIdx.x - item * parts;
+    const uint32_t item = blockIdx.x / grid_parts;
+    const uint32_t part = blockIdx.x - item * grid_parts;
+    if (part >= parts) return;  // workgroup-uniform: this filter uses fewer workgroups per read than the launch has
     const uint32_t read = item / n_slices;
     const uint32_t slice = item - read * n_slices;
     const uint32_t slots = (uint32_t)wps * parts;  // per strand, over all parts
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
             const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
             if (lane == 0) s_max[strand] = m;
         } else {
-            uint64_t *dst = ws + ((gitem * parts + part) * 2 + (size_t)strand) * (WPL * NP * 64);
+            uint64_t *dst = ws + ((gitem * grid_parts + part) * 2 + (size_t)strand) * (2 * NP * 64);
 #pragma unroll
             for (int w = 0; w < WPL; ++w)
 #pragma unroll
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
 #pragma unroll
             for (int w = 0; w < WPL; ++w) pl[w].clear();
             for (uint32_t q = 0; q < parts; ++q) {
-                const uint64_t *srcp = ws + ((gitem * parts + q) * 2 + (size_t)strand) * (WPL * NP * 64);
+                const uint64_t *srcp = ws + ((gitem * grid_parts + q) * 2 + (size_t)strand) * (2 * NP * 64);
 #pragma unroll
                 for (int w = 0; w < WPL; ++w) {
                     uint64_t carry = 0;
@@ -540,6 +540,65 @@ __global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : 1024) void ibf_c
         const uint32_t a = s_max[0], b = s_max[1];
         out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)(a > b ? a : b);
     }
+}
+
+
+// filters of ONE kernel geometry (single-filter engines, several targets of equal width): the body alone, with the
+// workgroup size its register budget allows
+template <int LG, int WPL, int NP, int H, bool NT>
+__global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : (LG == 0 ? 512 : 1024)) void ibf_count_max_split_kernel(
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+    uint32_t *__restrict__ tickets)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    split_body<LG, WPL, NP, H, NT>(set.f[blockIdx.y], set.col_begin[blockIdx.y], set.col_end[blockIdx.y], set.parts[blockIdx.y],
+                                   set.sub[blockIdx.y], src, n_reads, n_slices, out_base + set.out_offset[blockIdx.y],
+                                   out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);
+}
+
+// filters of DIFFERENT geometries in one launch (deplete = human genome, targets = a few small genomes): the geometry
+// of the filter picked by blockIdx.y selects the body (workgroup-uniform branch).  Built for 512 threads: with all
+// bodies in one function the scalar state of sixteen specialisations spills into vector registers, and at 768+
+// threads that pushes the widest bodies over the budget.
+template <int NP, bool WIDE>
+__global__ __launch_bounds__(512) void ibf_count_max_split_any_kernel(
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+    uint32_t *__restrict__ tickets)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const IbfDev &f = set.f[blockIdx.y];
+    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
+    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
+    const uint32_t parts = set.parts[blockIdx.y], sub = set.sub[blockIdx.y];
+#define RB_SPLIT_CASE(LG_, WPL_)                                                                                          \
+    case (LG_) | ((WPL_) == 2 ? 8 : 0):                                                                                    \
+        split_body<LG_, WPL_, NP, 3, false>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,                \
+                                            out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);            \
+        break;                                                                                                             \
+    case (LG_) | ((WPL_) == 2 ? 8 : 0) | 16:                                                                               \
+        split_body<LG_, WPL_, NP, 3, true>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,                 \
+                                           out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);             \
+        break;
+    switch (set.geom[blockIdx.y]) {
+        RB_SPLIT_CASE(0, 1)
+        RB_SPLIT_CASE(1, 1)
+        RB_SPLIT_CASE(2, 1)
+        RB_SPLIT_CASE(3, 1)
+        RB_SPLIT_CASE(4, 1)
+        RB_SPLIT_CASE(5, 1)
+        RB_SPLIT_CASE(6, 1)
+    default:
+        if constexpr (WIDE) {
+            switch (set.geom[blockIdx.y]) {
+                RB_SPLIT_CASE(6, 2)
+            default: break;
+            }
+        }
+        break;
+    }
+#undef RB_SPLIT_CASE
 }
 
 // combine the per-slice partial maxima of one filter: part[slice][read] -> maxcount[read*nf + f]
@@ -746,35 +805,101 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
         set.col_end[0] = a.col_end;
         set.out_offset[0] = 0;
     }
-    if (a.split_waves >= 2) {
-        // latency form: one workgroup per read; dynamic LDS = plane exchange + maxima + per-wave staging
-        const int nw = a.split_waves;
-        const size_t lds = (size_t)nw * WPL * NP * 64 * 8 + 16 + (size_t)nw * kStageBytes;
-        auto kern = ibf_count_max_split_kernel<LG, WPL, NP, H, NT>;
-        // the opt-in for > 64 KiB of dynamic LDS is per function AND per device: remember it per device id
-        static std::atomic<uint64_t> attr_done{0};  // one bit per device, per instantiation
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const uint64_t bit = (dev >= 0 && dev < 64) ? (1ULL << dev) : 0;
-        if (!bit || !(attr_done.load(std::memory_order_acquire) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            attr_done.fetch_or(bit, std::memory_order_release);
-        }
-        const uint32_t parts = a.split_parts > 1 ? (uint32_t)a.split_parts : 1u;
-        const uint32_t sub = a.split_sub > 1 ? (uint32_t)a.split_sub : 1u;
-        if (parts > 1 && (!a.split_ws || !a.split_tickets)) return hipErrorInvalidValue;
-        dim3 grid(a.n_reads * a.n_slices * parts, set.n);
-        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
-                           a.out_slice_stride, parts, sub, a.split_ws, a.split_tickets);
-        return hipGetLastError();
-    }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
     dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock), set.n);
     hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, set, a.src,
                        a.n_reads, a.n_slices, a.out, a.out_read_stride, a.out_slice_stride);
     return hipGetLastError();
+}
+
+// latency form.  Dynamic LDS = plane exchange + maxima + per-wave staging; the opt-in for > 64 KiB of it is per function
+// AND per device, remembered per device id.
+template <typename K>
+static hipError_t launch_split_kernel(K kern, std::atomic<uint64_t> &done, const FilterSet &set, const CountLaunch &a, int max_wpl,
+                                      int np, uint32_t grid_parts, hipStream_t st)
+{
+    const int nw = a.split_waves;
+    const size_t lds = (size_t)nw * max_wpl * np * 64 * 8 + 16 + (size_t)nw * kStageBytes;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (1ULL << dev) : 0;
+    if (!bit || !(done.load(std::memory_order_acquire) & bit)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        done.fetch_or(bit, std::memory_order_release);
+    }
+    dim3 grid(a.n_reads * a.n_slices * grid_parts, set.n);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
+                       a.out_slice_stride, grid_parts, a.split_ws, a.split_tickets);
+    return hipGetLastError();
+}
+
+template <int LG, int WPL, int NP, bool NT>
+static hipError_t launch_split_one(const FilterSet &set, const CountLaunch &a, uint32_t grid_parts, hipStream_t st)
+{
+    static std::atomic<uint64_t> done{0};
+    return launch_split_kernel(ibf_count_max_split_kernel<LG, WPL, NP, 3, NT>, done, set, a, WPL, NP, grid_parts, st);
+}
+
+template <int NP, bool NT>
+static hipError_t launch_split_same(int lg, int wpl, const FilterSet &set, const CountLaunch &a, uint32_t grid_parts,
+                                    hipStream_t st)
+{
+    if (wpl == 2) return launch_split_one<6, 2, NP, NT>(set, a, grid_parts, st);
+    switch (lg) {
+    case 0: return launch_split_one<0, 1, NP, NT>(set, a, grid_parts, st);
+    case 1: return launch_split_one<1, 1, NP, NT>(set, a, grid_parts, st);
+    case 2: return launch_split_one<2, 1, NP, NT>(set, a, grid_parts, st);
+    case 3: return launch_split_one<3, 1, NP, NT>(set, a, grid_parts, st);
+    case 4: return launch_split_one<4, 1, NP, NT>(set, a, grid_parts, st);
+    case 5: return launch_split_one<5, 1, NP, NT>(set, a, grid_parts, st);
+    default: return launch_split_one<6, 1, NP, NT>(set, a, grid_parts, st);
+    }
+}
+
+template <int NP>
+static hipError_t launch_split(const CountLaunch &a, hipStream_t st)
+{
+    FilterSet set;
+    set.n = a.n_fused > 0 ? (uint32_t)a.n_fused : 1u;
+    if (a.n_fused > 0) {
+        for (uint32_t i = 0; i < set.n; ++i) {
+            set.f[i] = a.fused_f[i];
+            set.col_begin[i] = a.fused_col_begin[i];
+            set.col_end[i] = a.fused_col_end[i];
+            set.out_offset[i] = a.fused_out_offset[i];
+            set.geom[i] = a.fused_geom[i];
+            set.parts[i] = a.fused_parts[i];
+            set.sub[i] = a.fused_sub[i];
+        }
+    } else {
+        set.f[0] = a.f;
+        set.col_begin[0] = a.col_begin;
+        set.col_end[0] = a.col_end;
+        set.out_offset[0] = 0;
+        set.geom[0] = geom_code(a.lg, a.wpl, a.nt);
+        set.parts[0] = (uint32_t)(a.split_parts > 1 ? a.split_parts : 1);
+        set.sub[0] = (uint32_t)(a.split_sub > 1 ? a.split_sub : 1);
+    }
+    const uint32_t grid_parts = a.grid_parts > 1 ? (uint32_t)a.grid_parts : 1u;
+    bool same = true, wide = false;
+    for (uint32_t i = 0; i < set.n; ++i) {
+        if (set.parts[i] < 1 || set.parts[i] > grid_parts || set.sub[i] < 1) return hipErrorInvalidValue;
+        same &= set.geom[i] == set.geom[0];
+        wide |= (set.geom[i] & 8) != 0;
+    }
+    if (grid_parts > 1 && (!a.split_ws || !a.split_tickets)) return hipErrorInvalidValue;
+    const int nw = a.split_waves;
+    const int lg = (int)(set.geom[0] & 7), wpl = (set.geom[0] & 8) ? 2 : 1;
+    const int cap = same ? split_waves_cap(wpl, NP, lg) : kSplitAnyWaves;
+    if (nw < 2 || (nw & 1) || nw > cap) return hipErrorInvalidValue;
+    if (same)
+        return (set.geom[0] & 16) ? launch_split_same<NP, true>(lg, wpl, set, a, grid_parts, st)
+                                  : launch_split_same<NP, false>(lg, wpl, set, a, grid_parts, st);
+    static std::atomic<uint64_t> done[2];
+    if (wide) return launch_split_kernel(ibf_count_max_split_any_kernel<NP, true>, done[1], set, a, 2, NP, grid_parts, st);
+    return launch_split_kernel(ibf_count_max_split_any_kernel<NP, false>, done[0], set, a, 1, NP, grid_parts, st);
 }
 
 template <int LG, int WPL, int NP, int H>
@@ -783,18 +908,29 @@ static hipError_t launch_count(const CountLaunch &a, hipStream_t st)
     return a.nt ? launch_count_nt<LG, WPL, NP, H, true>(a, st) : launch_count_nt<LG, WPL, NP, H, false>(a, st);
 }
 
-// number of waves the split form may use per read for this geometry (0 = split form not applicable)
-int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
+// most waves a workgroup of the one-geometry latency kernel may have: the 16-byte-lane instantiations are built for
+// 768 (10 planes) / 512 (16 planes) threads, the one-lane-per-block ones for 512 (eight tiles of block numbers in
+// registers: at 1024 threads they spilled 36-49 registers; a 512-k-mer macro tile needs two waves anyway), the others
+// for 1024, and the plane exchange of every wave has to fit the 160 KiB of LDS.  The mixed-geometry kernel takes
+// kSplitAnyWaves.
+int split_waves_cap(int wpl, int planes, int lg)
 {
     const int np = planes <= 10 ? 10 : 16;
     const size_t per_wave = (size_t)wpl * np * 64 * 8 + kStageBytes;
-    int by_lds = (int)((160 * 1024 - 16) / per_wave);
+    int cap = (int)((160 * 1024 - 16) / per_wave);
+    const int by_bounds = wpl == 2 ? (np > 10 ? 8 : 12) : (lg == 0 ? 8 : 16);
+    if (cap > by_bounds) cap = by_bounds;
+    return cap & ~1;
+}
+
+// number of waves the latency form wants per read for this geometry (0 = latency form not applicable)
+int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg)
+{
     int items = 64 * (lg >= 3 ? 1 : (8 >> lg));
     int tiles = (int)((max_kmers + items - 1) / items);
     int nw = 2 * (tiles < 1 ? 1 : tiles);
-    if (nw > by_lds) nw = by_lds;
-    if (nw > 16) nw = 16;
-    if (wpl == 2 && nw > (np > 10 ? 8 : 12)) nw = np > 10 ? 8 : 12;  // those instantiations are built for 512 / 768 threads
+    const int cap = split_waves_cap(wpl, planes, lg);
+    if (nw > cap) nw = cap;
     nw &= ~1;
     return nw >= 2 ? nw : 0;  // two waves = one per strand (reads that fit one macro tile, e.g. one-word filters)
 }
@@ -811,13 +947,11 @@ int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n
     const int bpt = lg == 6 ? 8 : 4;           // TileShape<LG>::STEPS / 8
     const uint32_t tiles = (max_kmers + 63) / 64;  // J == 1 for these shapes
     if (tiles == 0) return 1;
-    const int np = planes <= 10 ? 10 : 16;
-    const int max_nw = (wpl == 2) ? (np > 10 ? 8 : 12) : 16;
-    const int wps = max_nw >= 8 ? 4 : 2;       // waves per strand and workgroup (a power of two)
+    const int wps = kSplitAnyWaves / 2;        // waves per strand and workgroup: fits every kernel of the latency form
     uint32_t cap = max_parts;
-    // measured on the 8 GiB filter: beyond ~256 workgroups per launch the extra parts only queue behind each other
-    // (64 reads: 4 parts 67 us, 6 parts 87 us, 1 part 82 us; 256 reads: 1 part is best)
-    const uint32_t by_grid = n_items ? 256u / n_items : 1u;
+    // measured on the 8 GiB filter: beyond ~200 workgroups per launch the extra parts only queue behind each other
+    // (64 reads: 3 parts 66 us, 4 parts 72 us, 6 parts 87 us, 1 part 82 us; 256 reads: 1 part is best)
+    const uint32_t by_grid = n_items ? 200u / n_items : 1u;
     if (cap > by_grid) cap = by_grid;
     if (cap <= 1) return 1;
     int s0 = 1;
@@ -854,6 +988,10 @@ static hipError_t dispatch_geometry(const CountLaunch &a, hipStream_t st)
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
 {
     if (a.n_reads == 0) return hipSuccess;
+    if (a.split_waves >= 2) {  // latency form (three hash functions only; the engine plans it for those)
+        if (a.f.n_hash != 3) return hipErrorInvalidValue;
+        return a.planes <= 10 ? launch_split<10>(a, st) : launch_split<16>(a, st);
+    }
     if (a.f.n_hash == 3) {
         if (a.planes <= 10) return dispatch_geometry<10, 3>(a, st);
         return dispatch_geometry<16, 3>(a, st);
