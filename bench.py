@@ -66,7 +66,41 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="serialise the count kernels of different filters")
     ap.add_argument("--rate", type=float, default=150000.0, help="c5: total chunk arrival rate (chunks/s) over all GPUs")
     ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default c2 run on one GPU: do not append the short runs of configs 3, 4 and 5 (`other_configs`)")
     return ap.parse_args()
+
+
+def other_configs():
+    """Short runs of the other BASELINE configs that fit one GPU, each in a child process after the main measurement
+    (the headline line stays config 2): the 8 GiB GRCh38-scale filter (c3), deplete + target check_unblock (c4) and the
+    live replay (c5).  Reported as a compact summary next to the headline; failures are reported, never raised."""
+    import subprocess
+    runs = {
+        "c3": ["--workload", "c3", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
+        "c4": ["--workload", "c4", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
+        "c5": ["--workload", "c5", "--replay-seconds", "2.0"],
+    }
+    out = {}
+    for name, argv in runs.items():
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras"] + argv, capture_output=True,
+                               text=True, timeout=300)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+            d = json.loads(line)
+            o = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"]}
+            if d.get("roofline", {}).get("frac") is not None:
+                o["roofline_frac"] = d["roofline"]["frac"]
+                o["achieved_GBps"] = d["roofline"]["achieved"]
+                o["ms_per_step"] = d["ms_per_step"]
+                o["decisions"] = d["config"].get("decisions")
+            if name == "c5":
+                o["latency"] = {k: v for k, v in d["latency"].items() if k.endswith("_ms") or k == "slo_met"}
+                o["micro_batch_reads"] = d["config"].get("micro_batch_reads")
+            out[name] = o
+        except Exception as ex:  # noqa: BLE001 -- the headline line must not depend on the extras
+            out[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+    return out
 
 
 def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
@@ -382,6 +416,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.reads and not args.no_extras:
+        result["other_configs"] = other_configs()
     if rank == 0:
         print(json.dumps(result))
         if result.get("parity", {}).get("decision_mismatches"):
