@@ -1,6 +1,7 @@
-"""Size-independent properties at BASELINE config-2 scale (0.41 GB filter, 10^5 reads), where the CPU oracle is too
-slow to check every read: strand symmetry, batch-partition invariance, order invariance, kernel-form invariance.
-A sample of the same batch is still compared with the oracle."""
+"""Size-independent properties at BASELINE scale, where the CPU oracle is too slow to check every read: strand symmetry,
+batch-partition invariance, order invariance, kernel-form invariance -- on config 2 (0.41 GB filter, 10^5 reads) and on
+config 4 (8 GiB deplete + 600-bin target filter, 10^6 reads, full check_unblock).  A sample of each batch is still
+compared with the oracle."""
 import numpy as np
 import pytest
 
@@ -66,3 +67,66 @@ def test_sample_against_oracle(c2):
     exp_max = po.batch_raw_max(o, buf, offs[idx], lens[idx], 8)
     exp_dec, _ = po.batch_check_unblock([o], [], buf, offs[idx], lens[idx], n_threads=8)
     assert np.array_equal(base[0][idx, 0], exp_max) and np.array_equal(base[2][idx], exp_dec)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs 3/4 at full filter size: 8 GiB GRCh38-scale deplete filter (8192 bins) + 600-bin target filter,
+# 10^6 reads through the whole check_unblock decision.
+@pytest.fixture(scope="module")
+def c4():
+    dep, ref_d = synth.build_device_filter(0, synth.WORKLOADS["c3"], fill_seed=4, plant_seed=40)
+    tgt, ref_t = synth.build_device_filter(0, synth.WORKLOADS["zymo"], fill_seed=6, plant_seed=60)
+    buf, offs, lens = synth.make_reads(78, 1_000_000, 360, np.concatenate([ref_d, ref_t]))
+    eng = capi.Engine(0, [dep], [tgt])
+    base = eng.classify(buf, offs, lens)
+    return dep, tgt, eng, buf, offs, lens, base
+
+
+def test_c4_strand_symmetry_and_decision_mix(c4):
+    dep, tgt, eng, buf, offs, lens, base = c4
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
+    rc = comp[buf.reshape(-1, 360)[:, ::-1]].reshape(-1).copy()
+    got = eng.classify(rc, offs, lens)
+    assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]) and np.array_equal(got[2], base[2])
+    counts = np.bincount(base[2], minlength=3)
+    assert counts.min() > 100_000  # wait / unblock / stop_receiving all occur (reads from both references + random ones)
+    assert (base[3] == capi.RB_OK).all()
+
+
+def test_c4_partition_forms_and_host_paths(c4):
+    """the same reads as one 10^6 batch (throughput kernels, sliced PCIe copies), as micro-batches (latency kernels: one
+    mixed-geometry launch, several workgroups per read on the 8 GiB filter) and with those features switched off"""
+    dep, tgt, eng, buf, offs, lens, base = c4
+    pos = 0
+    for size in (1, 5, 14, 64, 200, 2048, 2049, 70_000):
+        sl = slice(pos, pos + size)
+        g = eng.classify(buf, offs[sl], lens[sl])
+        assert np.array_equal(g[0], base[0][sl]) and np.array_equal(g[2], base[2][sl]) and np.array_equal(g[1], base[1][sl]), size
+        pos += size
+    sl = slice(500_000, 500_300)
+    for parts, split in ((1, 2048), (16, 2048), (8, 0)):
+        eng.set_split_parts(parts, 4)
+        eng.set_split_threshold(split)
+        g = eng.classify(buf, offs[sl], lens[sl])
+        assert np.array_equal(g[0], base[0][sl]) and np.array_equal(g[2], base[2][sl]), (parts, split)
+    eng.set_split_parts(8, 4)
+    eng.set_split_threshold(2048)
+    eng.set_host_slice_bytes(0)  # the whole 360 MB batch in one copy
+    g = eng.classify(buf, offs, lens)
+    eng.set_host_slice_bytes(32 << 20)
+    assert np.array_equal(g[0], base[0]) and np.array_equal(g[2], base[2])
+
+
+def test_c4_sample_against_oracle(c4):
+    dep, tgt, eng, buf, offs, lens, base = c4
+    views, keep = [], []
+    for d in (dep, tgt):
+        host = d.download()
+        keep.append(host)
+        views.append(po.OracleIBF.wrap(host.info["n_bins"], 3, 13, host.info["n_bits"], host.words()))
+    idx = np.random.default_rng(10).choice(len(lens), size=2000, replace=False)
+    exp_dec, exp_st = po.batch_check_unblock(views[:1], views[1:], buf, offs[idx], lens[idx], n_threads=8)
+    assert np.array_equal(base[2][idx], exp_dec) and np.array_equal(base[3][idx], exp_st)
+    for f, o in enumerate(views):
+        assert np.array_equal(base[0][idx, f], po.batch_raw_max(o, buf, offs[idx], lens[idx], 8))
