@@ -172,6 +172,12 @@ RB_API int rb_classify_batch_ptrs(rb_engine *e, const char *const *seq_ptrs, con
                                   double error_rate, double significance, int mode, uint16_t *out_maxcount,
                                   int32_t *out_best_target, uint8_t *out_decision, uint8_t *out_status);
 
+/* Page-locked host memory for read buffers handed to rb_classify_batch: the copy to the GPU is then a plain DMA
+ * (pageable buffers are pinned on the fly by the runtime, which costs more than the copy itself and serialises with
+ * threads that page-fault on a memory-mapped read file).  Optional: any host pointer works. */
+RB_API int rb_host_alloc(size_t bytes, void **out);
+RB_API void rb_host_free(void *p);
+
 /* Same with every buffer already resident in HBM (device pointers) and asynchronous on
  * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
  * before returning).  max_len = an upper bound of lens[] (a longer read gets status RB_ERR_INVALID_ARG).  The inputs must be complete on `stream`

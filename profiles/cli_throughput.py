@@ -34,7 +34,8 @@ open(cfg, "w").write('usage = "classify"\noutput_directory = "%s/out"\nlog_direc
                      'deplete_files = ["%s"]\nread_files = ["%s"]\nchunk_length = 360\nmax_chunks = 1\n' % (work, work, ibf, fq))
 cli = os.path.join(ROOT, "readbouncer_amd", "readbouncer_amd_cli")
 print(subprocess.run([cli, "--parse-stats", fq], capture_output=True, text=True).stdout.strip())
-for batch in (65536, 262144):
-    p = subprocess.run([cli, "--config", cfg, "--batch-reads", str(batch)], capture_output=True, text=True)
+for batch, threads in ((65536, 4), (262144, 4), (65536, 1), (65536, 8), (1048576, 8)):
+    p = subprocess.run([cli, "--config", cfg, "--batch-reads", str(batch), "--ingest-threads", str(threads)],
+                       capture_output=True, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith(("RESULT", "THROUGHPUT"))]
-    print("batch", batch, " | ".join(lines), p.stderr.strip()[-200:])
+    print("batch", batch, "threads", threads, " | ".join(lines), p.stderr.strip()[-100:])

@@ -75,6 +75,8 @@ SIGNATURES = {
     "rb_classify_batch_ptrs": (_int, [_vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_classify_batch_device_ex": (_int, [_vp, C.POINTER(BatchDesc), _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_pack_reads": (_int, [_vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rb_host_alloc": (_int, [_sz, C.POINTER(_vp)]),
+    "rb_host_free": (None, [_vp]),
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),

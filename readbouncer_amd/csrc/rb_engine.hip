@@ -742,6 +742,19 @@ static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *
 
 extern "C" {
 
+int rb_host_alloc(size_t bytes, void **out)
+{
+    if (!out) return rb::fail(RB_ERR_INVALID_ARG, "null out");
+    *out = nullptr;
+    RB_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return RB_OK;
+}
+
+void rb_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_offsets, const void *d_lens, size_t n_reads,
                              uint32_t max_len, double error_rate, double significance, int mode, void *d_maxcount,
                              void *d_best_target, void *d_decision, void *d_status, void *stream)

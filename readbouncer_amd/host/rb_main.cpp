@@ -107,17 +107,28 @@ struct ReadState
     int best = -1;
 };
 
-// one parsed batch travelling from the reader thread to the classifying thread
-struct ParsedBatch
+// host pipeline knobs (command line)
+struct IngestOptions
 {
-    seqio::Batch batch;
-    uint64_t n_records = 0;
+    size_t batch_reads = 65536;  // most reads per GPU call
+    unsigned threads = 4;        // parser threads
+    size_t segment_mb = 64;      // file bytes per parsed segment
+    size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
+    size_t bytes() const { return segment_bytes ? segment_bytes : (segment_mb << 20); }
 };
 
-// classify_reads, src/main/classify.hpp:142-380.  A reader thread parses batch i+1 from the memory-mapped read
-// file while the GPU works on batch i.
+// a classified segment on its way to the writer thread
+struct WriteJob
+{
+    std::unique_ptr<seqio::Segment> seg;
+    std::vector<ReadState> state;
+};
+
+// classify_reads, src/main/classify.hpp:142-380, as a pipeline: parser threads cut the memory-mapped read file into
+// segments and stage the first chunk of every read (seqio::ParallelReader), this thread runs the chunk loop on the
+// GPU, a writer thread formats the FASTA outputs -- in file order throughout.
 static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta> DepletionFilters,
-                           std::vector<interleave::IBFMeta> TargetFilters, size_t batch_reads,
+                           std::vector<interleave::IBFMeta> TargetFilters, const IngestOptions& opt,
                            const std::vector<int>& devices)
 {
     interleave::ClassifyConfig Conf{};
@@ -140,19 +151,14 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         const auto wall0 = std::chrono::steady_clock::now();
 
         std::vector<std::ofstream> targetFastas{};
-        std::vector<std::vector<char>> outbufs(TargetFilters.size() + 1, std::vector<char>(1 << 20));
         for (size_t i = 0; i < TargetFilters.size(); ++i) {
             std::filesystem::path outfile(config.output_dir);
             outfile /= TargetFilters[i].name + ".fasta";
-            targetFastas.emplace_back();
-            targetFastas.back().rdbuf()->pubsetbuf(outbufs[i].data(), (std::streamsize)outbufs[i].size());
-            targetFastas.back().open(outfile, std::ios::out);
+            targetFastas.emplace_back(outfile, std::ios::out | std::ios::binary);
         }
         std::filesystem::path outfile(config.output_dir);
         outfile /= "unclassified.fasta";
-        std::ofstream UnclassifiedOut;
-        UnclassifiedOut.rdbuf()->pubsetbuf(outbufs.back().data(), (std::streamsize)outbufs.back().size());
-        UnclassifiedOut.open(outfile, std::ios::out);
+        std::ofstream UnclassifiedOut(outfile, std::ios::out | std::ios::binary);
         if (!UnclassifiedOut.is_open()) {
             std::cerr << "ERROR: Unable to open the file: " << outfile.string() << std::endl;
             return;
@@ -167,113 +173,147 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         const uint32_t chunk_length = (uint32_t)config.IBF_Parsed.chunk_length;
         const uint32_t max_chunks = (uint8_t)config.IBF_Parsed.max_chunks;  // "uint8_t i" in the reference
 
-        // ---- reader thread: two batches in flight
-        std::mutex mu;
-        std::condition_variable cv_full, cv_free;
-        std::deque<std::unique_ptr<ParsedBatch>> ready;
-        bool reader_done = false;
-        std::thread reader([&] {
-            seqio::Parser parser(mapped.data(), mapped.size());
+        // ---- writer thread: outputs in read order, one buffer per file and segment, one write() each
+        std::mutex wmu;
+        std::condition_variable wcv_job, wcv_room;
+        std::deque<WriteJob> wjobs;
+        bool wdone = false;
+        std::thread writer([&] {
+            std::vector<std::string> bufs(TargetFilters.size() + 1);
             for (;;) {
-                std::unique_ptr<ParsedBatch> pb(new ParsedBatch());
-                parser.next_batch(pb->batch, batch_reads);
-                const bool last = pb->batch.eof;
+                WriteJob job;
                 {
-                    std::unique_lock<std::mutex> lock(mu);
-                    cv_free.wait(lock, [&] { return ready.size() < 2; });
-                    ready.push_back(std::move(pb));
+                    std::unique_lock<std::mutex> lock(wmu);
+                    wcv_job.wait(lock, [&] { return !wjobs.empty() || wdone; });
+                    if (wjobs.empty()) return;
+                    job = std::move(wjobs.front());
+                    wjobs.pop_front();
                 }
-                cv_full.notify_one();
-                if (last) break;
+                wcv_room.notify_one();
+                for (std::string& b : bufs) b.clear();
+                const std::vector<seqio::Record>& recs = job.seg->batch.records;
+                for (size_t i = 0; i < recs.size(); ++i) {
+                    const seqio::Record& r = recs[i];
+                    if (r.seq_len < chunk_length) continue;
+                    if (job.state[i].failed) {  // classify.hpp:306-316
+                        failed++;
+                        log_line("error", "Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
+                        continue;
+                    }
+                    std::string* out = &bufs.back();  // unclassified.fasta
+                    if (job.state[i].classified) {
+                        found++;
+                        if (!(target && job.state[i].best >= 0)) continue;
+                        TargetFilters[job.state[i].best].classified += 1;
+                        out = &bufs[job.state[i].best];
+                    }
+                    out->push_back('>');
+                    out->append(r.id, r.id_len);
+                    out->push_back('\n');
+                    out->append(r.seq, r.seq_len);
+                    out->push_back('\n');
+                }
+                for (size_t f = 0; f < TargetFilters.size(); ++f)
+                    if (!bufs[f].empty()) targetFastas[f].write(bufs[f].data(), (std::streamsize)bufs[f].size());
+                if (!bufs.back().empty()) UnclassifiedOut.write(bufs.back().data(), (std::streamsize)bufs.back().size());
             }
-            {
-                std::lock_guard<std::mutex> lock(mu);
-                reader_done = true;
-            }
-            cv_full.notify_one();
         });
 
+        // first chunks are staged in page-locked memory: the copy to the GPU is then a plain DMA (a pageable source is
+        // pinned on the fly by the runtime, under the same mm lock the parser threads' page faults need)
+        seqio::BlockAllocator pinned;
+        pinned.alloc = [](size_t bytes) -> void* { void* p = nullptr; return rb_host_alloc(bytes, &p) == RB_OK ? p : nullptr; };
+        pinned.release = [](void* p) { rb_host_free(p); };
+        seqio::ParallelReader reader(mapped.data(), mapped.size(), opt.threads, opt.bytes(), chunk_length, pinned);
         std::vector<char> flat;
         std::vector<uint64_t> offs;
         std::vector<uint32_t> lens;
+        std::vector<size_t> idx;
+        double wait_reader_s = 0.0, wait_writer_s = 0.0;
+        auto seconds_since = [](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
+        };
         for (;;) {
-            std::unique_ptr<ParsedBatch> pb;
-            {
-                std::unique_lock<std::mutex> lock(mu);
-                cv_full.wait(lock, [&] { return !ready.empty() || reader_done; });
-                if (ready.empty()) break;
-                pb = std::move(ready.front());
-                ready.pop_front();
-            }
-            cv_free.notify_one();
-            const std::vector<seqio::Record>& recs = pb->batch.records;
+            const auto tr = std::chrono::steady_clock::now();
+            std::unique_ptr<seqio::Segment> seg = reader.next();
+            wait_reader_s += seconds_since(tr);
+            if (!seg) break;
+            const std::vector<seqio::Record>& recs = seg->batch.records;
             readCounter += recs.size();
-            if (!pb->batch.error.empty()) std::cerr << "ERROR: " << pb->batch.error << std::endl;
+            if (!seg->batch.error.empty()) std::cerr << "ERROR: " << seg->batch.error << std::endl;
             std::vector<ReadState> state(recs.size());
-            std::vector<size_t> active;
-            for (size_t i = 0; i < recs.size(); ++i) {
-                if (recs[i].seq_len < chunk_length) too_short++;  // classify.hpp:247-250
-                else active.push_back(i);
-            }
-            const size_t n_candidates = active.size();
+            too_short += recs.size() - seg->prefix_idx.size();  // classify.hpp:247-250
             const auto t0 = std::chrono::steady_clock::now();
-            for (uint32_t c = 0; c < max_chunks && !active.empty(); ++c) {
-                flat.clear();
-                offs.clear();
-                lens.clear();
-                std::vector<size_t> idx;
-                for (size_t i : active) {
-                    const seqio::Record& r = recs[i];
-                    uint64_t fragend = (uint64_t)(c + 1) * chunk_length, fragstart = (uint64_t)c * chunk_length;
-                    if (fragend > r.seq_len) fragend = r.seq_len;
-                    if (fragstart > fragend) { state[i].failed = true; continue; }  // undefined infix in the reference
-                    offs.push_back(flat.size());
-                    lens.push_back((uint32_t)(fragend - fragstart));
-                    flat.insert(flat.end(), r.seq + fragstart, r.seq + fragend);
-                    idx.push_back(i);
-                }
-                std::vector<size_t> next;
-                if (!idx.empty()) {
-                    if (flat.empty()) flat.push_back('N');
-                    interleave::BatchResult res =
-                        multi ? multi->classify_flat(Conf, flat.data(), offs.data(), lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK)
-                              : interleave::classify_batch_flat(DepletionFilters, TargetFilters, Conf, flat.data(), offs.data(),
-                                                                lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK);
-                    for (size_t j = 0; j < idx.size(); ++j) {
-                        ReadState& st = state[idx[j]];
-                        if (res.status[j] != RB_OK) { st.failed = true; continue; }  // exception -> failed++ (:306-316)
-                        if (res.decision[j]) {
-                            st.classified = true;
-                            st.best = target ? res.best_target[j] : -1;
-                        } else {
-                            next.push_back(idx[j]);
+            // the reads of a segment go to the GPU in calls of at most batch_reads; chunk 0 comes ready-made from the
+            // parser threads, later chunks are gathered here for the reads that are still unclassified
+            for (size_t b0 = 0; b0 < seg->prefix_idx.size(); b0 += opt.batch_reads) {
+                const size_t b1 = std::min(seg->prefix_idx.size(), b0 + opt.batch_reads);
+                std::vector<size_t> active(b1 - b0);
+                for (size_t j = b0; j < b1; ++j) active[j - b0] = seg->prefix_idx[j];
+                for (uint32_t c = 0; c < max_chunks && !active.empty(); ++c) {
+                    const char* base = nullptr;
+                    offs.clear();
+                    lens.clear();
+                    idx.clear();
+                    if (c == 0) {
+                        base = seg->prefix + b0 * (size_t)chunk_length;
+                        for (size_t j = 0; j < active.size(); ++j) {
+                            offs.push_back(j * (uint64_t)chunk_length);
+                            lens.push_back(chunk_length);
+                        }
+                        idx = active;
+                    } else {
+                        flat.clear();
+                        for (size_t i : active) {
+                            const seqio::Record& r = recs[i];
+                            uint64_t fragend = (uint64_t)(c + 1) * chunk_length, fragstart = (uint64_t)c * chunk_length;
+                            if (fragend > r.seq_len) fragend = r.seq_len;
+                            if (fragstart > fragend) { state[i].failed = true; continue; }  // undefined infix in the reference
+                            offs.push_back(flat.size());
+                            lens.push_back((uint32_t)(fragend - fragstart));
+                            flat.insert(flat.end(), r.seq + fragstart, r.seq + fragend);
+                            idx.push_back(i);
+                        }
+                        if (flat.empty()) flat.push_back('N');
+                        base = flat.data();
+                    }
+                    std::vector<size_t> next;
+                    if (!idx.empty()) {
+                        interleave::BatchResult res =
+                            multi ? multi->classify_flat(Conf, base, offs.data(), lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK)
+                                  : interleave::classify_batch_flat(DepletionFilters, TargetFilters, Conf, base, offs.data(),
+                                                                    lens.data(), idx.size(), RB_MODE_CLASSIFY_CHUNK);
+                        for (size_t j = 0; j < idx.size(); ++j) {
+                            ReadState& st = state[idx[j]];
+                            if (res.status[j] != RB_OK) { st.failed = true; continue; }  // exception -> failed++ (:306-316)
+                            if (res.decision[j]) {
+                                st.classified = true;
+                                st.best = target ? res.best_target[j] : -1;
+                            } else {
+                                next.push_back(idx[j]);
+                            }
                         }
                     }
+                    active.swap(next);
                 }
-                active.swap(next);
             }
             classify_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            classify_reads_n += n_candidates;
-            for (size_t i = 0; i < recs.size(); ++i) {  // outputs in read order
-                const seqio::Record& r = recs[i];
-                if (r.seq_len < chunk_length) continue;
-                if (state[i].failed) {  // classify.hpp:306-316
-                    failed++;
-                    log_line("error", "Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
-                    continue;
-                }
-                if (state[i].classified) {
-                    found++;
-                    if (target && state[i].best >= 0) {
-                        TargetFilters[state[i].best].classified += 1;
-                        seqio::write_fasta(targetFastas[state[i].best], r.id, r.id_len, r.seq, r.seq_len);
-                    }
-                } else {
-                    seqio::write_fasta(UnclassifiedOut, r.id, r.id_len, r.seq, r.seq_len);
-                }
+            classify_reads_n += seg->prefix_idx.size();
+            {
+                const auto tw = std::chrono::steady_clock::now();
+                std::unique_lock<std::mutex> lock(wmu);
+                wcv_room.wait(lock, [&] { return wjobs.size() < 4; });
+                wjobs.push_back(WriteJob{std::move(seg), std::move(state)});
+                wait_writer_s += seconds_since(tw);
             }
+            wcv_job.notify_one();
         }
-        reader.join();
+        {
+            std::lock_guard<std::mutex> lock(wmu);
+            wdone = true;
+        }
+        wcv_job.notify_one();
+        writer.join();
         for (auto& f : targetFastas) f.close();
         UnclassifiedOut.close();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
@@ -291,7 +331,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         std::cout << "RESULT found=" << found << " failed=" << failed << " too_short=" << too_short
                   << " readCounter=" << readCounter << std::endl;
         std::cout << "THROUGHPUT reads_per_s=" << (wall > 0 ? (double)readCounter / wall : 0.0) << " wall_s=" << wall
-                  << " classify_s=" << classify_seconds << std::endl;
+                  << " classify_s=" << classify_seconds << " wait_reader_s=" << wait_reader_s
+                  << " wait_writer_s=" << wait_writer_s << std::endl;
         ClassificationResults_.found = found;
         ClassificationResults_.failed = failed;
         ClassificationResults_.too_short = too_short;
@@ -300,7 +341,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
     }
 }
 
-static int run_program(ConfigReader& config, size_t batch_reads, const std::vector<int>& devices)
+static int run_program(ConfigReader& config, const IngestOptions& opt, const std::vector<int>& devices)
 {
     config.parse();
     config.createLog(config.usage);  // main.cpp:283
@@ -320,7 +361,7 @@ static int run_program(ConfigReader& config, size_t batch_reads, const std::vect
     if (config.usage == "classify") {  // main.cpp:346-376
         std::vector<interleave::IBFMeta> DepletionFilters = getIBF(config, true, false);
         std::vector<interleave::IBFMeta> TargetFilters = getIBF(config, false, true);
-        classify_reads(config, DepletionFilters, TargetFilters, batch_reads, devices);
+        classify_reads(config, DepletionFilters, TargetFilters, opt, devices);
         return 0;
     }
     std::cerr << "usage \"" << config.usage << "\" is outside this engine's scope (supported: build, classify)" << std::endl;
@@ -331,7 +372,8 @@ int main(int argc, char const* argv[])
 {
     std::string config_path;
     bool dump_only = false;
-    size_t batch_reads = 65536;
+    IngestOptions opt;
+    bool no_digest = false;
     std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {  // e.g. --devices 0,1,2,3,4,5,6,7
@@ -350,31 +392,37 @@ int main(int argc, char const* argv[])
         }
         if ((!std::strcmp(argv[i], "--config") || !std::strcmp(argv[i], "-c")) && i + 1 < argc) config_path = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-config")) dump_only = true;
-        else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) batch_reads = (size_t)std::stoull(argv[++i]);
+        else if (!std::strcmp(argv[i], "--no-digest")) no_digest = true;
+        else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
+        else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
+        else if (!std::strcmp(argv[i], "--segment-bytes") && i + 1 < argc) opt.segment_bytes = (size_t)std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--parse-stats") && i + 1 < argc) {
             // ingest self-check (no GPU): records, bases and an FNV-1a digest over "id\tseq\n" of every record
             seqio::MappedFile mf(argv[++i]);
             if (!mf.is_open()) { std::cerr << "ERROR: Unable to open the file: " << argv[i] << std::endl; return 1; }
-            seqio::Parser parser(mf.data(), mf.size());
-            seqio::Batch b;
+            // through the parallel reader (--ingest-threads / --segment-bytes given BEFORE --parse-stats apply): the digest is
+            // over the records in file order, so it is the same for every thread count and segment size
             uint64_t n = 0, bases = 0, h = 1469598103934665603ull;
             auto mix = [&](const char* d, size_t len) { for (size_t k = 0; k < len; ++k) { h ^= (unsigned char)d[k]; h *= 1099511628211ull; } };
             const auto t0 = std::chrono::steady_clock::now();
-            do {
-                parser.next_batch(b, batch_reads);
-                for (const seqio::Record& r : b.records) {
+            seqio::ParallelReader reader(mf.data(), mf.size(), opt.threads, opt.bytes(), 0);
+            const size_t n_segments = reader.segments();
+            while (std::unique_ptr<seqio::Segment> seg = reader.next()) {
+                for (const seqio::Record& r : seg->batch.records) {
                     ++n; bases += r.seq_len;
-                    mix(r.id, r.id_len); mix("\t", 1); mix(r.seq, r.seq_len); mix("\n", 1);
+                    if (!no_digest) { mix(r.id, r.id_len); mix("\t", 1); mix(r.seq, r.seq_len); mix("\n", 1); }
                 }
-                if (!b.error.empty()) { std::cerr << "ERROR: " << b.error << std::endl; return 1; }
-            } while (!b.eof);
+                if (!seg->batch.error.empty()) { std::cerr << "ERROR: " << seg->batch.error << std::endl; return 1; }
+            }
             const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             std::cout << "records=" << n << " bases=" << bases << " fnv=" << h << " seconds=" << secs
-                      << " MB_per_s=" << (secs > 0 ? mf.size() / 1e6 / secs : 0.0) << std::endl;
+                      << " MB_per_s=" << (secs > 0 ? mf.size() / 1e6 / secs : 0.0) << " segments=" << n_segments << std::endl;
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--devices 0,1,...] [--parse-stats file]" << std::endl;
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--segment-mb N] "
+                         "[--devices 0,1,...] [--parse-stats file]" << std::endl;
             return 0;
         }
     }
@@ -392,7 +440,7 @@ int main(int argc, char const* argv[])
         }
         // end-of-run report of main.cpp:438-444 (getrusage on Linux, main.cpp:140-152)
         const auto t_begin = std::chrono::steady_clock::now();
-        const int rc = run_program(config, batch_reads, devices);
+        const int rc = run_program(config, opt, devices);
         struct rusage ru;
         getrusage(RUSAGE_SELF, &ru);
         const double cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);

@@ -10,11 +10,17 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace seqio
@@ -155,6 +161,237 @@ public:
             out.error = ex.what();
             out.eof = true;
         }
+    }
+};
+
+// ---- parallel ingest ------------------------------------------------------------------------------------------------
+// The mapping is cut into segments that start at record boundaries; worker threads parse whole segments (and copy the
+// first `prefix_len` bases of every long-enough read into one flat buffer: the classifier's first chunk), the consumer
+// takes them in file order.  One parser thread does 6 GB/s of FASTQ; the GPU wants more than that.
+// where the prefix buffers live: plain heap by default; the GPU driver passes page-locked memory so that the copy to
+// the device is a plain DMA.  Blocks are pooled by the reader (page-locking is slow).
+struct BlockAllocator
+{
+    void* (*alloc)(size_t bytes) = nullptr;
+    void (*release)(void* p) = nullptr;
+};
+
+class BlockPool
+{
+    BlockAllocator a_;
+    std::mutex mu_;
+    std::vector<std::pair<char*, size_t>> idle_;
+public:
+    explicit BlockPool(BlockAllocator a) : a_(a) {}
+    ~BlockPool()
+    {
+        for (auto& b : idle_) free_block(b.first);
+    }
+    BlockPool(const BlockPool&) = delete;
+    BlockPool& operator=(const BlockPool&) = delete;
+    char* raw_alloc(size_t bytes) { return (char*)(a_.alloc ? a_.alloc(bytes) : std::malloc(bytes)); }
+    void free_block(char* p) { if (a_.release) a_.release(p); else std::free(p); }
+    // a block of at least `bytes` (capacity returned through cap); throws std::bad_alloc
+    char* get(size_t bytes, size_t* cap)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            for (size_t i = 0; i < idle_.size(); ++i) {
+                if (idle_[i].second >= bytes) {
+                    std::pair<char*, size_t> b = idle_[i];
+                    idle_.erase(idle_.begin() + (ptrdiff_t)i);
+                    *cap = b.second;
+                    return b.first;
+                }
+            }
+        }
+        const size_t want = bytes + bytes / 8 + 4096;
+        char* p = raw_alloc(want);
+        if (!p) throw std::bad_alloc();
+        *cap = want;
+        return p;
+    }
+    void put(char* p, size_t cap)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        idle_.emplace_back(p, cap);
+    }
+};
+
+struct Segment
+{
+    Batch batch;                       // every record of the segment (views into the mapping / the arena)
+    char* prefix = nullptr;            // prefix_len bases of each record with seq_len >= prefix_len, back to back
+    size_t prefix_cap = 0;
+    std::vector<uint32_t> prefix_idx;  // record index of each prefix row
+    BlockPool* pool = nullptr;
+    Segment() = default;
+    Segment(const Segment&) = delete;
+    Segment& operator=(const Segment&) = delete;
+    ~Segment()
+    {
+        if (prefix && pool) pool->put(prefix, prefix_cap);
+    }
+};
+
+namespace detail
+{
+inline size_t line_end(const char* d, size_t n, size_t pos)  // index of the '\n' that ends the line at pos, or n
+{
+    const char* nl = (const char*)memchr(d + pos, '\n', n - pos);
+    return nl ? (size_t)(nl - d) : n;
+}
+inline size_t trimmed_len(const char* d, size_t b, size_t e) { return (e > b && d[e - 1] == '\r') ? e - b - 1 : e - b; }
+
+// a four-line FASTQ record starts at line start L: '@' line, sequence, '+' line, quality of the sequence's length
+inline bool fastq_record_at(const char* d, size_t n, size_t L, size_t* next)
+{
+    if (L >= n || d[L] != '@') return false;
+    const size_t e0 = line_end(d, n, L);
+    if (e0 >= n) return false;
+    const size_t s1 = e0 + 1, e1 = line_end(d, n, s1);
+    if (e1 >= n) return false;
+    const size_t s2 = e1 + 1, e2 = line_end(d, n, s2);
+    if (s2 >= n || d[s2] != '+' || e2 >= n) return false;
+    const size_t s3 = e2 + 1, e3 = line_end(d, n, s3);
+    if (trimmed_len(d, s1, e1) != trimmed_len(d, s3, e3)) return false;
+    *next = e3 < n ? e3 + 1 : n;
+    return true;
+}
+
+// first record boundary at or after pos ('>' line for FASTA; for FASTQ a line that starts two well-formed records in a
+// row or the last one -- a quality line may begin with '@', its successors do not fit the pattern)
+inline size_t find_record_start(const char* d, size_t n, size_t pos, char fmt)
+{
+    if (pos == 0) return 0;
+    if (pos >= n) return n;
+    size_t L = line_end(d, n, pos - 1);
+    L = L < n ? L + 1 : n;
+    while (L < n) {
+        if (fmt == '>') {
+            if (d[L] == '>') return L;
+        } else {
+            size_t nx = 0, nx2 = 0;
+            if (fastq_record_at(d, n, L, &nx)) {
+                size_t R = nx;
+                while (R < n && (d[R] == '\n' || d[R] == '\r')) ++R;  // blank lines between records
+                if (R >= n || fastq_record_at(d, n, R, &nx2)) return L;
+            }
+        }
+        const size_t e = line_end(d, n, L);
+        L = e < n ? e + 1 : n;
+    }
+    return n;
+}
+}  // namespace detail
+
+class ParallelReader
+{
+    const char* data_;
+    size_t size_;
+    uint32_t prefix_len_;
+    BlockPool pool_;              // declared before the slots: segments hand their blocks back on destruction
+    std::vector<size_t> starts_;  // segment s = [starts_[s], starts_[s + 1])
+    std::vector<std::unique_ptr<Segment>> slots_;
+    std::vector<std::thread> workers_;
+    std::atomic<size_t> next_seg_{0};
+    size_t consumed_ = 0, window_;
+    bool stop_ = false;
+    std::mutex mu_;
+    std::condition_variable cv_ready_, cv_room_;
+
+    void work()
+    {
+        for (;;) {
+            const size_t s = next_seg_.fetch_add(1);
+            if (s + 1 >= starts_.size()) return;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_room_.wait(lock, [&] { return stop_ || s < consumed_ + window_; });
+                if (stop_) return;
+            }
+            std::unique_ptr<Segment> seg(new Segment());
+            Parser parser(data_ + starts_[s], starts_[s + 1] - starts_[s]);
+            parser.next_batch(seg->batch, (size_t)-1);
+            seg->batch.eof = seg->batch.eof && (!seg->batch.error.empty() || s + 2 == starts_.size());
+            if (prefix_len_) {
+                size_t rows = 0;
+                for (const Record& r : seg->batch.records) rows += r.seq_len >= prefix_len_;
+                seg->pool = &pool_;
+                seg->prefix = pool_.get(rows * (size_t)prefix_len_ + 1, &seg->prefix_cap);
+                seg->prefix_idx.reserve(rows);
+                char* out = seg->prefix;
+                for (size_t i = 0; i < seg->batch.records.size(); ++i) {
+                    const Record& r = seg->batch.records[i];
+                    if (r.seq_len < prefix_len_) continue;
+                    std::memcpy(out, r.seq, prefix_len_);
+                    out += prefix_len_;
+                    seg->prefix_idx.push_back((uint32_t)i);
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu_);
+                slots_[s] = std::move(seg);
+            }
+            cv_ready_.notify_all();
+        }
+    }
+
+public:
+    // prefix_len = 0: no prefix buffers.  segment_bytes ~ one classifier batch worth of file.
+    ParallelReader(const char* data, size_t size, unsigned threads, size_t segment_bytes, uint32_t prefix_len,
+                   BlockAllocator allocator = BlockAllocator())
+        : data_(data), size_(size), prefix_len_(prefix_len), pool_(allocator)
+    {
+        if (threads == 0) threads = 1;
+        if (segment_bytes < 4096) segment_bytes = 4096;
+        size_t first = 0;
+        while (first < size && (data[first] == '\n' || data[first] == '\r')) ++first;
+        const char fmt = first < size ? data[first] : '>';
+        starts_.push_back(0);
+        if (fmt == '>' || fmt == '@') {  // anything else: one segment, the parser reports the malformed record
+            for (size_t pos = segment_bytes; pos < size; pos += segment_bytes) {
+                const size_t b = detail::find_record_start(data, size, pos, fmt);
+                if (b >= size) break;
+                if (b > starts_.back()) starts_.push_back(b);
+                if (b > pos) pos = b;
+            }
+        }
+        starts_.push_back(size);
+        slots_.resize(starts_.size() - 1);
+        window_ = 2 * (size_t)threads + 2;
+        const size_t n_workers = std::min<size_t>(threads, slots_.size());
+        for (size_t i = 0; i < n_workers; ++i) workers_.emplace_back([this] { work(); });
+    }
+    ~ParallelReader()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_room_.notify_all();
+        for (std::thread& t : workers_) t.join();
+    }
+    ParallelReader(const ParallelReader&) = delete;
+    ParallelReader& operator=(const ParallelReader&) = delete;
+
+    size_t segments() const { return slots_.size(); }
+
+    // the next segment in file order; nullptr after the last one.  A segment whose batch.error is set is the last.
+    std::unique_ptr<Segment> next()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        if (consumed_ >= slots_.size()) return nullptr;
+        cv_ready_.wait(lock, [&] { return slots_[consumed_] != nullptr; });
+        std::unique_ptr<Segment> seg = std::move(slots_[consumed_]);
+        ++consumed_;
+        if (!seg->batch.error.empty()) {
+            consumed_ = slots_.size();
+            stop_ = true;
+        }
+        lock.unlock();
+        cv_room_.notify_all();
+        return seg;
     }
 };
 

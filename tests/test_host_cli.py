@@ -142,16 +142,41 @@ def test_ingest_parser_matches_python_reader(tmp_path, refdata):
     mixed = tmp_path / "m.fq"
     mixed.write_bytes(b"@r1 x\nACGTN\n+\n!!!!!\n@r2\nAC\n+r2\n@@\n")  # quality line starting with '@'
     cases.append((str(mixed), H.read_fastq))
+    # a FASTQ whose quality lines love '@' and '>' and '+': every line start is a tempting record boundary
+    rng = np.random.default_rng(8)
+    tricky = tmp_path / "tricky.fq"
+    with open(tricky, "wb") as fh:
+        for i in range(400):
+            L = int(rng.integers(1, 90))
+            seq = H.random_dna(rng, L, with_n=0.05).encode()
+            qual = bytes(rng.choice(np.frombuffer(b"@>+I!", dtype=np.uint8), size=L))
+            fh.write(b"@r%d extra\n%s\n+%s\n%s\n" % (i, seq, b"" if i % 3 else b"r%d" % i, qual))
+    cases.append((str(tricky), H.read_fastq))
+    long_fa = tmp_path / "long.fa"
+    with open(long_fa, "w") as fh:
+        for i in range(120):
+            seq = H.random_dna(rng, int(rng.integers(0, 400)))
+            fh.write(">s%d\n" % i + "\n".join(seq[j:j + 60] for j in range(0, len(seq), 60)) + "\n")
+    cases.append((str(long_fa), H.read_fasta))
     for path, reader in cases:
         recs = reader(path)
-        out = run_cli("--parse-stats", path).stdout.split()
-        kv = dict(x.split("=") for x in out)
-        assert int(kv["records"]) == len(recs), path
-        assert int(kv["bases"]) == sum(len(s) for _, s in recs), path
-        assert int(kv["fnv"]) == _fnv(recs), path
+        # serial-equivalent (one segment) and cut into many small segments parsed by several threads: same records in
+        # the same order
+        for extra in ((), ("--ingest-threads", "3", "--segment-bytes", "64"), ("--ingest-threads", "2", "--segment-bytes", "1000"),
+                      ("--ingest-threads", "5", "--segment-bytes", "4096")):
+            out = run_cli(*extra, "--parse-stats", path).stdout.split()
+            kv = dict(x.split("=") for x in out)
+            assert int(kv["records"]) == len(recs), (path, extra)
+            assert int(kv["bases"]) == sum(len(s) for _, s in recs), (path, extra)
+            assert int(kv["fnv"]) == _fnv(recs), (path, extra)
+    kv = dict(x.split("=") for x in run_cli("--ingest-threads", "3", "--segment-bytes", "4096", "--parse-stats", str(tricky)).stdout.split())
+    assert int(kv["segments"]) > 3  # the file really was cut
     bad = tmp_path / "bad.fq"
     bad.write_bytes(b"@r1\nACGT\nIIII\n")
     assert run_cli("--parse-stats", str(bad), check=False).returncode == 1
+    bad2 = tmp_path / "bad2.fq"  # malformed record deep inside a multi-segment file: reported, not skipped
+    bad2.write_bytes(open(tricky, "rb").read() + b"@broken\nACGT\nIIII\n" + open(tricky, "rb").read())
+    assert run_cli("--ingest-threads", "4", "--segment-bytes", "4096", "--parse-stats", str(bad2), check=False).returncode == 1
 
 
 def synth_genome(seed, n, plant=None, at=0):
