@@ -14,4 +14,16 @@ touch $R/oracle/libibf_oracle.so
 (cd $R/readbouncer_amd/host && g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer rb_main.cpp \
     -o ../readbouncer_amd_cli -L.. -lreadbouncer_amd -Wl,-rpath,'$ORIGIN' -lpthread)
 (cd $R && ASAN_OPTIONS=detect_leaks=0 python -m pytest tests/test_host_cli.py -x -q -m "not gpu")
+# ThreadSanitizer on the parallel ingest (parser threads, ordered hand-over, block pool): 60 segments, 4 threads
+python3 - "$T/tsan.fq" <<'PY'
+import sys, random
+random.seed(1)
+with open(sys.argv[1], "w") as fh:
+    for i in range(30000):
+        n = random.randint(1, 900)
+        fh.write("@r%d\n%s\n+\n%s\n" % (i, "".join(random.choice("ACGTN") for _ in range(n)), "".join(random.choice("@>+I") for _ in range(n))))
+PY
+(cd $R/readbouncer_amd/host && g++ -O1 -g -std=c++17 -fsanitize=thread rb_main.cpp -o $T/cli_tsan -L.. -lreadbouncer_amd \
+    -Wl,-rpath,$R/readbouncer_amd -lpthread)
+TSAN_OPTIONS="halt_on_error=1" $T/cli_tsan --ingest-threads 4 --segment-bytes 250000 --parse-stats $T/tsan.fq
 echo "sanitizers: clean"
