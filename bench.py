@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", help="c2 (default, BASELINE configs[1]), c3, c3np2, c1, c4")
+    ap.add_argument("--workload", default="c2", help="c2 (default, BASELINE configs[1]), c3, c3np2, c1, c4, c5, readme, grch38_f100k, zymo, zymo16")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
@@ -226,6 +226,18 @@ def main():
         wname = "config4: deplete=GRCh38-scale IBF (8192 bins, 8 GiB) + target=Zymo-mock-like IBF (600 bins), check_unblock"
         n_reads = args.reads or 2_000_000
         read_len = 360
+    elif args.workload == "readme":
+        # the reference's own (only) published benchmark shape: README.md:254-262, 250 bp prefixes, 1 deplete + 3 targets
+        deplete, target, refs = [], [], []
+        for i, key in enumerate(("mock_deplete", "mock_t1", "mock_t2", "mock_t3")):
+            f, r = synth.build_device_filter(dev_index, synth.WORKLOADS[key], fill_seed=11 + i, plant_seed=110 + i, n_segments=512)
+            (deplete if i == 0 else target).append(f)
+            refs.append(r)
+        ref = np.concatenate(refs)
+        wname = ("README benchmark shape: 250bp prefixes vs 1 deplete (122 bins) + 3 target (43/29/49 bins) IBFs, k=13, "
+                 "F=100000, check_unblock")
+        n_reads = args.reads or 1_000_000
+        read_len = 250
     else:
         w = synth.WORKLOADS[args.workload]
         seeds = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60),

@@ -31,6 +31,13 @@ WORKLOADS = {
     # mock-community target of config 4: ~600 bins at F=100000
     "zymo": dict(name="Zymo-mock-like target IBF (600 bins, F=100000)",
                  n_bins=600, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=360),
+    # the shape of the reference's only published benchmark (README.md:254-262): 3 target + 1 deplete filters built from
+    # single mock-community genomes at k=13, F=100000 -- all of them narrow (1-2 word columns, 5-20 MB)
+    "mock_deplete": dict(name="12.1 Mbp genome (122 bins, F=100000)", n_bins=122, k=13, h=3, fragment=100000, n_bits=None,
+                         reads=1_000_000, read_len=250),
+    "mock_t1": dict(name="4.2 Mbp genome (43 bins)", n_bins=43, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
+    "mock_t2": dict(name="2.8 Mbp genome (29 bins)", n_bins=29, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
+    "mock_t3": dict(name="4.8 Mbp genome (49 bins)", n_bins=49, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
 }
 
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
