@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="serialise the count kernels of different filters")
     ap.add_argument("--rate", type=float, default=150000.0, help="c5: total chunk arrival rate (chunks/s) over all GPUs")
     ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
+    ap.add_argument("--read-len", type=int, default=0, help="override the read length of the workload (e.g. 1500: 16 counter planes)")
     ap.add_argument("--no-extras", action="store_true",
                     help="default c2 run on one GPU: do not append the short runs of configs 3, 4 and 5 (`other_configs`)")
     return ap.parse_args()
@@ -247,6 +248,8 @@ def main():
         wname = w["name"]
         n_reads = args.reads or w["reads"]
         read_len = w["read_len"]
+    if args.read_len:
+        read_len = args.read_len
     filters = deplete + target
     geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in filters]
     bytes_per_read = synth.algorithmic_bytes_per_read(read_len, geo)
@@ -428,7 +431,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and args.workload == "c2" and not args.reads and not args.no_extras:
+    if rank == 0 and world == 1 and args.workload == "c2" and not args.reads and not args.read_len and not args.no_extras:
         result["other_configs"] = other_configs()
     if rank == 0:
         print(json.dumps(result))
