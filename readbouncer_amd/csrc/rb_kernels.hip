@@ -21,8 +21,9 @@
 //     10 or 16 planes (16 planes wrap at 65536 exactly like the reference's uint16_t counters);
 //   * the max over bins is taken on the bit-sliced form with 64-wide ballots, MSB plane first.
 // Two forms share that body (count_strand): the throughput form (one wave per read and column slice, both strands in
-// sequence; slices of a read sit side by side in a workgroup) and the latency form for micro-batches (one workgroup
-// per read; its waves split strands and k-mer tiles and add their bit-sliced counters through LDS).  Gathers are
+// sequence; slices of a read sit side by side in a workgroup) and the latency form for micro-batches (one or several
+// workgroups per read; their waves split strands and k-mer tiles, add their bit-sliced counters through LDS and -- across
+// workgroups -- through a workspace and an arrival counter; one launch serves filters of different geometries).  Gathers are
 // issued in batches of 12-24 per wave with no control flow around them and a schedule fence before the first use;
 // filters beyond the Infinity Cache are read with non-temporal loads.  Inputs may be ASCII or 2-bit packed reads, whole
 // or chunked on the device (BaseSrc / ReadSrc).
