@@ -289,3 +289,71 @@ def test_cpp_mirror_reads_like_the_reference_tests(tmp_path, refdata):
     p = subprocess.run([exe, refdata, str(tmp_path / "work")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "failures: 0" in p.stdout
+
+
+@pytest.mark.gpu
+def test_pipeline_settings_do_not_change_the_outputs(tmp_path):
+    """parser threads, segment size and GPU batch size only change the schedule: RESULT line and every output file are
+    byte-identical, in read order, and equal to the oracle's chunk driver -- with reads that are only classified on their
+    second or third chunk (the chunks the main thread gathers itself) and reads too short for one chunk"""
+    rng = np.random.default_rng(33)
+    dep_seq, tgt_seq = H.random_dna(rng, 40000), H.random_dna(rng, 30000)
+    (tmp_path / "dep.fasta").write_text(">dep\n" + dep_seq + "\n")
+    (tmp_path / "tgt.fasta").write_text(">tgt\n" + tgt_seq + "\n")
+    reads = []
+    for i in range(3000):
+        kind = i % 6
+        L = int(rng.integers(300, 1100))
+        if kind == 0:
+            s = H.random_dna(rng, L)                                             # unclassified
+        elif kind == 1:
+            p = int(rng.integers(0, len(dep_seq) - L)); s = H.mutate(rng, dep_seq[p:p + L], 0.05)   # deplete, chunk 0
+        elif kind == 2:
+            p = int(rng.integers(0, len(tgt_seq) - L)); s = H.mutate(rng, tgt_seq[p:p + L], 0.05)   # target, chunk 0
+        elif kind == 3:
+            p = int(rng.integers(0, len(dep_seq) - 600)); s = H.random_dna(rng, 250) + dep_seq[p:p + 600]   # chunk 1
+        elif kind == 4:
+            p = int(rng.integers(0, len(tgt_seq) - 400)); s = H.random_dna(rng, 500) + tgt_seq[p:p + 400]   # chunk 2
+        else:
+            s = H.random_dna(rng, int(rng.integers(1, 250)))                     # too short
+        reads.append(("read%d some description" % i, s))
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "w") as fh:
+        for n, s in reads:
+            fh.write("@%s\n%s\n+\n%s\n" % (n, s, "".join(rng.choice(list("@>+I5"), size=len(s)))))
+    outputs = []
+    for tag, extra in (("a", ("--ingest-threads", "1", "--batch-reads", "1000000")),
+                       ("b", ("--ingest-threads", "4", "--segment-bytes", "150000", "--batch-reads", "777")),
+                       ("c", ("--ingest-threads", "3", "--segment-bytes", "20000", "--batch-reads", "64"))):
+        out = tmp_path / ("out_" + tag)
+        cfg = tmp_path / (tag + ".toml")
+        write_config(cfg, "classify", out, kmer_size=13, fragment_size=1000, deplete_files=[tmp_path / "dep.fasta"],
+                     target_files=[tmp_path / "tgt.fasta"], read_files=[fq], chunk_length=250, max_chunks=3)
+        stdout = run_cli("--config", str(cfg), *extra).stdout
+        line = [l for l in stdout.splitlines() if l.startswith("RESULT")][0]
+        files = {p.name: p.read_bytes() for p in sorted(out.glob("*.fasta"))}
+        outputs.append((line, files))
+    assert outputs[0] == outputs[1] == outputs[2]
+    line, files = outputs[0]
+    # the oracle's chunk driver on filters built like the reference builds them
+    od = H.build_filter_like_reference([dep_seq], k=13, fragment_length=1000)
+    ot = H.build_filter_like_reference([tgt_seq], k=13, fragment_length=1000)
+    exp_un, exp_t, found, short, failed = [], [], 0, 0, 0
+    for n, s in reads:
+        r = po.classify_read_chunks([od], [ot], s, 250, 3)
+        short += r["too_short"]
+        failed += r["status"] != po.OK
+        found += r["classified"]
+        if r["too_short"] or r["status"] != po.OK:
+            continue
+        if not r["classified"]:
+            exp_un.append((n.split(" ")[0], s))
+        elif r["best_target"] >= 0:
+            exp_t.append((n.split(" ")[0], s))
+    assert line == "RESULT found=%d failed=%d too_short=%d readCounter=%d" % (found, failed, short, len(reads))
+    got_un = [(n.split(" ")[0], s) for n, s in H.read_fasta(str(tmp_path / "out_a" / "unclassified.fasta"))]
+    got_t = [(n.split(" ")[0], s) for n, s in H.read_fasta(str(tmp_path / "out_a" / "tgt.fasta"))]
+    assert got_un == exp_un and got_t == exp_t
+    # with both filter sets only target reads count as classified (classify.hpp:58-111): kinds 2 and 4
+    assert 950 < found < 1100 and len(exp_t) == found and short == 500 and len(exp_un) > 1000
+    assert failed > 50  # a last chunk shorter than k throws in the reference (classify.hpp:306-316): counted, not written
