@@ -18,12 +18,23 @@ __device__ __forceinline__ uint64_t mix(uint64_t z)
     return z ^ (z >> 31);
 }
 
+// U independent 16-byte loads in flight per lane; consecutive waves read consecutive 1 KiB pieces
+template <int U, bool NT>
 __global__ void stream_read(const u64x2 *__restrict__ p, size_t n, uint64_t *out)
 {
     uint64_t acc = 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const u64x2 v = __builtin_nontemporal_load(p + i);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n; i += U * stride) {
+        u64x2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(p + i + u * stride) : p[i + u * stride];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc ^= v[u].x ^ v[u].y;
+    }
+    for (; i < n; i += stride) {
+        const u64x2 v = p[i];
         acc ^= v.x ^ v.y;
     }
     if (acc == 0x123456789ULL) out[0] = acc;
@@ -71,18 +82,35 @@ static void run_gather(const uint8_t *d, size_t bytes, uint64_t *out, const char
     const uint32_t iters = 64;
     const int waves = 256 * 16 * 8;  // 32 k waves
     hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
     for (int rep = 0; rep < 2; ++rep) {
-        hipEventRecord(a);
+        (void)hipEventRecord(a);
         hipLaunchKernelGGL((gather_rows<ROW, NT>), dim3(waves / 4), dim3(256), 0, 0, d, n_rows, iters, out);
-        hipEventRecord(b);
-        hipEventSynchronize(b);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
     }
     float ms = 0;
-    hipEventElapsedTime(&ms, a, b);
+    (void)hipEventElapsedTime(&ms, a, b);
     const double moved = (double)waves * iters * BATCH * (64 / LANES) * (double)ROW;
     printf("gather %4d-B rows %s over %.1f GiB: %7.0f GB/s\n", ROW, label, bytes / 1073741824.0, moved / ms / 1e6);
+}
+
+template <int U, bool NT>
+static void run_stream(const uint8_t *d, size_t bytes, uint64_t *out, int blocks, const char *label)
+{
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((stream_read<U, NT>), dim3(blocks), dim3(256), 0, 0, (const u64x2 *)d, bytes / 16, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    printf("stream read of 8 GiB (%s): %7.0f GB/s\n", label, bytes / ms / 1e6);
 }
 
 int main()
@@ -91,19 +119,11 @@ int main()
     uint8_t *d;
     uint64_t *out;
     if (hipMalloc(&d, bytes) != hipSuccess || hipMalloc(&out, 8) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    hipMemset(d, 0x5a, bytes);
-    hipEvent_t a, b;
-    hipEventCreate(&a);
-    hipEventCreate(&b);
-    for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(a);
-        hipLaunchKernelGGL(stream_read, dim3(256 * 16), dim3(256), 0, 0, (const u64x2 *)d, bytes / 16, out);
-        hipEventRecord(b);
-        hipEventSynchronize(b);
-    }
-    float ms = 0;
-    hipEventElapsedTime(&ms, a, b);
-    printf("stream read of 8 GiB: %7.0f GB/s\n", bytes / ms / 1e6);
+    (void)hipMemset(d, 0x5a, bytes);
+    run_stream<1, true>(d, bytes, out, 256 * 16, "1 load in flight per lane, nt");
+    run_stream<8, true>(d, bytes, out, 256 * 16, "8 loads in flight per lane, nt");
+    run_stream<8, false>(d, bytes, out, 256 * 16, "8 loads in flight per lane, default");
+    run_stream<16, true>(d, bytes, out, 256 * 8, "16 loads in flight per lane, nt");
     run_gather<128, false>(d, bytes, out, "(default)");
     run_gather<128, true>(d, bytes, out, "(nt)     ");
     run_gather<128, false>(d, (size_t)390 << 20, out, "(default)");  // config 2's table size: Infinity Cache helps
