@@ -24,6 +24,8 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- python3 $R/bench.py --workload c5 --replay-seconds 1.0 > $OUT/stats_c5.log 2>&1
 bash $R/profiles/collect_pmc.sh c2 1000000 $OUT/pmc_c2 > /dev/null 2>&1
 bash $R/profiles/collect_pmc.sh c3 1000000 $OUT/pmc_c3 > /dev/null 2>&1
+bash $R/profiles/collect_pmc.sh c4 1000000 $OUT/pmc_c4 > /dev/null 2>&1
+bash $R/profiles/collect_pmc.sh grch38_f100k 500000 $OUT/pmc_grch38_f100k > /dev/null 2>&1
 hipcc -O3 --offload-arch=gfx950 $R/profiles/hbm_peak.hip -o /tmp/hbm_peak 2>/dev/null && /tmp/hbm_peak > $OUT/hbm_peak.txt 2>&1; cat $OUT/hbm_peak.txt
 for w in c2 c3 c4 c5; do f=$(find $OUT/stats_$w -name "*kernel_stats.csv" | head -1); echo "== $w"; grep -E "rb::ibf_count" $f | sed -e 's/(rb::IbfDev[^"]*"/"/' | head -4; done
 for f in $OUT/bench_*.json; do python3 - "$f" <<'PY'

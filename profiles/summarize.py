@@ -27,23 +27,32 @@ for w in ("c2", "c3", "c4", "c5"):
 
 
 def counter_means(path):
-    """{counter: (dispatches, mean value, mean kernel ms)} over the dispatches of the throughput count kernel"""
+    """{counter: (dispatches, value per step, kernel ms per step)} of the throughput count kernels.  A step launches one
+    count kernel per filter (different template instantiations): the per-step figure is the sum over the kernels of
+    their per-dispatch means."""
     acc = {}
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
             if "ibf_count_max_kernel" not in r["Kernel_Name"]:
                 continue
-            a = acc.setdefault(r["Counter_Name"], [0, 0.0, 0.0])
+            a = acc.setdefault((r["Counter_Name"], r["Kernel_Name"]), [0, 0.0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
             a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    return {k: (n, v / n, ms / n) for k, (n, v, ms) in acc.items()}
+    out = {}
+    for (name, _kernel), (n, v, ms) in acc.items():
+        o = out.setdefault(name, [0, 0.0, 0.0])
+        o[0] += n
+        o[1] += v / n
+        o[2] += ms / n
+    return {k: tuple(v) for k, v in out.items()}
 
 
 from readbouncer_amd import synth  # noqa: E402
 
 rows, traffic = [], {}
-for w in ("c2", "c3"):
+FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"]}
+for w in ("c2", "c3", "c4", "grch38_f100k"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):
         continue
@@ -57,9 +66,9 @@ for w in ("c2", "c3"):
             m[name] = v
     if "FETCH_SIZE" not in m:
         continue
-    reads = 1_000_000
-    wl = synth.WORKLOADS[w]
-    alg = synth.algorithmic_bytes_per_read(wl["read_len"], [(wl["n_bins"], wl["k"], wl["h"])])
+    reads = 500_000 if w == "grch38_f100k" else 1_000_000
+    wls = [synth.WORKLOADS[k] for k in FILTERS[w]]
+    alg = synth.algorithmic_bytes_per_read(360, [(x["n_bins"], x["k"], x["h"]) for x in wls])
     hbm = m["FETCH_SIZE"] * 1024 * 2
     traffic[w] = {
         "reads_per_launch": reads,
