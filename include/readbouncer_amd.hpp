@@ -305,21 +305,31 @@ public:
 // ---- engines are cached per (deplete set, target set) -----------------------------------------
 namespace detail
 {
+// One engine per (calling thread, filter set).  Engines only borrow the filters (no copy in HBM) and own their streams
+// and workspaces, so the N classification threads of the reference (src/main/adaptive_sampling.hpp:745-751) overlap on
+// the GPU instead of queueing behind one engine's staging buffers.  The key carries the geometry next to the handles: a
+// filter freed and another one allocated at the same address must not inherit threshold tables made for another k.
 struct EngineKey
 {
     std::vector<rb_dibf*> d, t;
-    bool operator<(const EngineKey& o) const { return d != o.d ? d < o.d : t < o.t; }
+    std::vector<uint64_t> geo;
+    bool operator<(const EngineKey& o) const { return d != o.d ? d < o.d : (t != o.t ? t < o.t : geo < o.geo); }
 };
 inline rb_engine* engine_for(const std::vector<IBFMeta>& dep, const std::vector<IBFMeta>& tgt)
 {
-    static std::mutex mu;
-    static std::map<EngineKey, std::shared_ptr<rb_engine>> cache;
+    thread_local std::map<EngineKey, std::shared_ptr<rb_engine>> cache;
     EngineKey k;
     for (const IBFMeta& m : dep) k.d.push_back(m.filter.handle());
     for (const IBFMeta& m : tgt) k.t.push_back(m.filter.handle());
-    std::lock_guard<std::mutex> lock(mu);
+    for (const std::vector<rb_dibf*>* set : {&k.d, &k.t})
+        for (rb_dibf* f : *set) {
+            rb_ibf_info g{};
+            if (f) rb_dibf_get_info(f, &g);
+            k.geo.insert(k.geo.end(), {g.n_bins, g.n_hash, g.kmer_size, g.n_bits});
+        }
     auto it = cache.find(k);
     if (it != cache.end()) return it->second.get();
+    if (cache.size() >= 16) cache.clear();  // filter sets come and go (tests, rebuilt filters): do not hoard engines
     rb_engine* e = nullptr;
     const int dev = !k.d.empty() ? rb_dibf_device(k.d[0]) : (!k.t.empty() ? rb_dibf_device(k.t[0]) : 0);
     throw_status(rb_engine_create(dev, k.d.data(), k.d.size(), k.t.data(), k.t.size(), &e), "engine");

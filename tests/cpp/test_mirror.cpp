@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <filesystem>
 #include <iostream>
+#include <thread>
+#include <vector>
 
 #include "../../include/readbouncer_amd.hpp"
 #include "../../readbouncer_amd/host/seqio.hpp"
@@ -179,6 +181,35 @@ int main(int argc, char** argv)
         IBFConfig cg{};
         cg.input_filter_file = tmp + "/upd.ibf";
         EXPECT_EQ(g.load_filter(cg).totalBinsFile, 3u);
+    }
+
+    // ---- the reference's threading model (adaptive_sampling.hpp:745-751): N classification threads share the filters
+    // read-only and call check_unblock one read at a time; every thread gets its own engine (streams, workspaces)
+    {
+        const int n_threads = 6, per_thread = 300;
+        std::vector<int> bad(n_threads, 0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) {
+            pool.emplace_back([&, t] {
+                ClassifyConfig c = cconf;  // the reference shares one mutable config between its threads: a data race there
+                for (int i = 0; i < per_thread; ++i) {
+                    try {
+                        if ((int)check_unblock(read, c, v1, v2) != 0) ++bad[t];
+                        if ((int)check_unblock(read, c, v1, emptyVectorMeta) != 1) ++bad[t];
+                        if ((int)check_unblock(other, c, emptyVectorMeta, v2) != 1) ++bad[t];
+                        std::pair<int, int> q = read.classify(v1, v2, c);
+                        if (q.first != 282 || q.second != 182) ++bad[t];
+                        if (read.classify(filters, c) != 0) ++bad[t];
+                    } catch (...) {
+                        ++bad[t];
+                    }
+                }
+            });
+        }
+        for (std::thread& th : pool) th.join();
+        int total_bad = 0;
+        for (int b : bad) total_bad += b;
+        EXPECT_EQ(total_bad, 0);
     }
 
     std::cout << "mirror checks: " << checks << ", failures: " << failures << std::endl;
