@@ -50,6 +50,16 @@ def test_no_gpu_means_loud_failure():
     with pytest.raises(capi.RBError) as ei:
         capi.DeviceIBF.create(0, 64, 3, 13, 64 * 1024)
     assert ei.value.status == capi.RB_ERR_NO_DEVICE
+    # every entry point that needs the GPU says so -- there is no CPU fallback anywhere in the product
+    import ctypes as C
+    p = C.c_void_p()
+    assert capi.lib().rb_host_alloc(1024, C.byref(p)) == capi.RB_ERR_NO_DEVICE and not p.value
+    capi.lib().rb_host_free(None)
+    host = capi.HostIBF.create(64, 3, 13, 64 * 1024)
+    with pytest.raises(capi.RBError) as ei:
+        capi.DeviceIBF.upload(0, host)
+    assert ei.value.status == capi.RB_ERR_NO_DEVICE
+    assert capi.device_count() <= 0
 
 
 def test_threshold_table_matches_oracle_and_golden(golden_dir):
