@@ -34,8 +34,9 @@ open(cfg, "w").write('usage = "classify"\noutput_directory = "%s/out"\nlog_direc
                      'deplete_files = ["%s"]\nread_files = ["%s"]\nchunk_length = 360\nmax_chunks = 1\n' % (work, work, ibf, fq))
 cli = os.path.join(ROOT, "readbouncer_amd", "readbouncer_amd_cli")
 print(subprocess.run([cli, "--parse-stats", fq], capture_output=True, text=True).stdout.strip())
-for batch, threads in ((65536, 4), (262144, 4), (65536, 1), (65536, 8), (1048576, 8)):
-    p = subprocess.run([cli, "--config", cfg, "--batch-reads", str(batch), "--ingest-threads", str(threads)],
-                       capture_output=True, text=True)
+for batch, threads, cthreads in ((65536, 4, 2), (65536, 4, 2), (65536, 4, 1), (65536, 4, 3), (65536, 6, 2), (262144, 4, 2), (65536, 1, 1)):
+    subprocess.run(["rm", "-rf", os.path.join(work, "out")])  # truncating last run's GB-sized outputs would be timed otherwise
+    p = subprocess.run([cli, "--config", cfg, "--batch-reads", str(batch), "--ingest-threads", str(threads),
+                        "--classify-threads", str(cthreads)], capture_output=True, text=True)
     lines = [l for l in p.stdout.splitlines() if l.startswith(("RESULT", "THROUGHPUT"))]
-    print("batch", batch, "threads", threads, " | ".join(lines), p.stderr.strip()[-100:])
+    print("batch", batch, "parsers", threads, "classifiers", cthreads, " | ".join(lines), p.stderr.strip()[-100:])

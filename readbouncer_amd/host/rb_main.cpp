@@ -112,21 +112,25 @@ struct IngestOptions
 {
     size_t batch_reads = 65536;  // most reads per GPU call
     unsigned threads = 4;        // parser threads
+    unsigned classify_threads = 2;  // threads running the chunk loop on the GPU (one engine each)
     size_t segment_mb = 64;      // file bytes per parsed segment
     size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
     size_t bytes() const { return segment_bytes ? segment_bytes : (segment_mb << 20); }
 };
 
-// a classified segment on its way to the writer thread
+// a classified segment on its way to the writer thread: the FASTA text of every output file (formatted by the
+// classifier thread, in read order) and the tallies of the segment
 struct WriteJob
 {
-    std::unique_ptr<seqio::Segment> seg;
-    std::vector<ReadState> state;
+    std::vector<std::string> bufs;       // one per target file, unclassified.fasta last
+    std::vector<uint64_t> per_target;    // IBFMeta.classified increments (classify.hpp:80,288)
+    std::vector<std::string> error_lines;
+    uint64_t found = 0, failed = 0;
 };
 
 // classify_reads, src/main/classify.hpp:142-380, as a pipeline: parser threads cut the memory-mapped read file into
-// segments and stage the first chunk of every read (seqio::ParallelReader), this thread runs the chunk loop on the
-// GPU, a writer thread formats the FASTA outputs -- in file order throughout.
+// segments and stage the first chunk of every read (seqio::ParallelReader), classifier threads run the chunk loop on
+// the GPU, a writer thread formats the FASTA outputs -- in file order throughout.
 static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta> DepletionFilters,
                            std::vector<interleave::IBFMeta> TargetFilters, const IngestOptions& opt,
                            const std::vector<int>& devices)
@@ -173,13 +177,12 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         const uint32_t chunk_length = (uint32_t)config.IBF_Parsed.chunk_length;
         const uint32_t max_chunks = (uint8_t)config.IBF_Parsed.max_chunks;  // "uint8_t i" in the reference
 
-        // ---- writer thread: outputs in read order, one buffer per file and segment, one write() each
+        // ---- writer thread: outputs in read order, one write() per file and segment
         std::mutex wmu;
         std::condition_variable wcv_job, wcv_room;
         std::deque<WriteJob> wjobs;
         bool wdone = false;
         std::thread writer([&] {
-            std::vector<std::string> bufs(TargetFilters.size() + 1);
             for (;;) {
                 WriteJob job;
                 {
@@ -190,34 +193,51 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     wjobs.pop_front();
                 }
                 wcv_room.notify_one();
-                for (std::string& b : bufs) b.clear();
-                const std::vector<seqio::Record>& recs = job.seg->batch.records;
-                for (size_t i = 0; i < recs.size(); ++i) {
-                    const seqio::Record& r = recs[i];
-                    if (r.seq_len < chunk_length) continue;
-                    if (job.state[i].failed) {  // classify.hpp:306-316
-                        failed++;
-                        log_line("error", "Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
-                        continue;
-                    }
-                    std::string* out = &bufs.back();  // unclassified.fasta
-                    if (job.state[i].classified) {
-                        found++;
-                        if (!(target && job.state[i].best >= 0)) continue;
-                        TargetFilters[job.state[i].best].classified += 1;
-                        out = &bufs[job.state[i].best];
-                    }
-                    out->push_back('>');
-                    out->append(r.id, r.id_len);
-                    out->push_back('\n');
-                    out->append(r.seq, r.seq_len);
-                    out->push_back('\n');
+                found += job.found;
+                failed += (uint16_t)job.failed;
+                for (const std::string& l : job.error_lines) log_line("error", l);
+                for (size_t f = 0; f < TargetFilters.size(); ++f) {
+                    TargetFilters[f].classified += job.per_target[f];
+                    if (!job.bufs[f].empty()) targetFastas[f].write(job.bufs[f].data(), (std::streamsize)job.bufs[f].size());
                 }
-                for (size_t f = 0; f < TargetFilters.size(); ++f)
-                    if (!bufs[f].empty()) targetFastas[f].write(bufs[f].data(), (std::streamsize)bufs[f].size());
-                if (!bufs.back().empty()) UnclassifiedOut.write(bufs.back().data(), (std::streamsize)bufs.back().size());
+                if (!job.bufs.back().empty())
+                    UnclassifiedOut.write(job.bufs.back().data(), (std::streamsize)job.bufs.back().size());
             }
         });
+        // the outputs of one classified segment, in read order (classify.hpp:289-316)
+        auto format_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state) {
+            WriteJob job;
+            job.bufs.resize(TargetFilters.size() + 1);
+            job.per_target.assign(TargetFilters.size(), 0);
+            size_t unclassified_bytes = 0;
+            const std::vector<seqio::Record>& recs = seg.batch.records;
+            for (size_t i = 0; i < recs.size(); ++i)
+                if (recs[i].seq_len >= chunk_length && !state[i].failed && !state[i].classified)
+                    unclassified_bytes += recs[i].id_len + recs[i].seq_len + 3;
+            job.bufs.back().reserve(unclassified_bytes);
+            for (size_t i = 0; i < recs.size(); ++i) {
+                const seqio::Record& r = recs[i];
+                if (r.seq_len < chunk_length) continue;
+                if (state[i].failed) {  // classify.hpp:306-316
+                    job.failed++;
+                    job.error_lines.push_back("Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
+                    continue;
+                }
+                std::string* out = &job.bufs.back();  // unclassified.fasta
+                if (state[i].classified) {
+                    job.found++;
+                    if (!(target && state[i].best >= 0)) continue;
+                    job.per_target[state[i].best] += 1;
+                    out = &job.bufs[state[i].best];
+                }
+                out->push_back('>');
+                out->append(r.id, r.id_len);
+                out->push_back('\n');
+                out->append(r.seq, r.seq_len);
+                out->push_back('\n');
+            }
+            return job;
+        };
 
         // first chunks are staged in page-locked memory: the copy to the GPU is then a plain DMA (a pageable source is
         // pinned on the fly by the runtime, under the same mm lock the parser threads' page faults need)
@@ -225,38 +245,30 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         pinned.alloc = [](size_t bytes) -> void* { void* p = nullptr; return rb_host_alloc(bytes, &p) == RB_OK ? p : nullptr; };
         pinned.release = [](void* p) { rb_host_free(p); };
         seqio::ParallelReader reader(mapped.data(), mapped.size(), opt.threads, opt.bytes(), chunk_length, pinned);
-        std::vector<char> flat;
-        std::vector<uint64_t> offs;
-        std::vector<uint32_t> lens;
-        std::vector<size_t> idx;
         double wait_reader_s = 0.0, wait_writer_s = 0.0;
         auto seconds_since = [](std::chrono::steady_clock::time_point t) {
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
         };
-        for (;;) {
-            const auto tr = std::chrono::steady_clock::now();
-            std::unique_ptr<seqio::Segment> seg = reader.next();
-            wait_reader_s += seconds_since(tr);
-            if (!seg) break;
-            const std::vector<seqio::Record>& recs = seg->batch.records;
-            readCounter += recs.size();
-            if (!seg->batch.error.empty()) std::cerr << "ERROR: " << seg->batch.error << std::endl;
-            std::vector<ReadState> state(recs.size());
-            too_short += recs.size() - seg->prefix_idx.size();  // classify.hpp:247-250
-            const auto t0 = std::chrono::steady_clock::now();
-            // the reads of a segment go to the GPU in calls of at most batch_reads; chunk 0 comes ready-made from the
-            // parser threads, later chunks are gathered here for the reads that are still unclassified
-            for (size_t b0 = 0; b0 < seg->prefix_idx.size(); b0 += opt.batch_reads) {
-                const size_t b1 = std::min(seg->prefix_idx.size(), b0 + opt.batch_reads);
+        // the chunk loop of one segment (classify.hpp:262-299, batch-wise): the reads go to the GPU in calls of at most
+        // batch_reads; chunk 0 comes ready-made from the parser threads, later chunks are gathered here for the reads that
+        // are still unclassified
+        auto classify_segment = [&](const seqio::Segment& seg, std::vector<ReadState>& state) {
+            const std::vector<seqio::Record>& recs = seg.batch.records;
+            std::vector<char> flat;
+            std::vector<uint64_t> offs;
+            std::vector<uint32_t> lens;
+            std::vector<size_t> idx;
+            for (size_t b0 = 0; b0 < seg.prefix_idx.size(); b0 += opt.batch_reads) {
+                const size_t b1 = std::min(seg.prefix_idx.size(), b0 + opt.batch_reads);
                 std::vector<size_t> active(b1 - b0);
-                for (size_t j = b0; j < b1; ++j) active[j - b0] = seg->prefix_idx[j];
+                for (size_t j = b0; j < b1; ++j) active[j - b0] = seg.prefix_idx[j];
                 for (uint32_t c = 0; c < max_chunks && !active.empty(); ++c) {
                     const char* base = nullptr;
                     offs.clear();
                     lens.clear();
                     idx.clear();
                     if (c == 0) {
-                        base = seg->prefix + b0 * (size_t)chunk_length;
+                        base = seg.prefix + b0 * (size_t)chunk_length;
                         for (size_t j = 0; j < active.size(); ++j) {
                             offs.push_back(j * (uint64_t)chunk_length);
                             lens.push_back(chunk_length);
@@ -297,16 +309,70 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     active.swap(next);
                 }
             }
-            classify_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            classify_reads_n += seg->prefix_idx.size();
-            {
-                const auto tw = std::chrono::steady_clock::now();
-                std::unique_lock<std::mutex> lock(wmu);
-                wcv_room.wait(lock, [&] { return wjobs.size() < 4; });
-                wjobs.push_back(WriteJob{std::move(seg), std::move(state)});
-                wait_writer_s += seconds_since(tw);
+        };
+        // classifier threads: each takes the next segment in file order, runs its chunk loop on an engine of its own (the
+        // mirror keeps one engine per calling thread) and hands the result to the writer when its turn has come -- while
+        // one thread waits for the GPU, the other prepares and post-processes its segment
+        std::mutex rmu, omu;
+        std::condition_variable ocv;
+        uint64_t next_seq = 0, write_seq = 0;
+        std::string worker_error;
+        auto classifier = [&] {
+            try {
+                for (;;) {
+                    std::unique_ptr<seqio::Segment> seg;
+                    uint64_t seq = 0;
+                    {
+                        std::lock_guard<std::mutex> lock(rmu);
+                        const auto tr = std::chrono::steady_clock::now();
+                        seg = reader.next();
+                        wait_reader_s += seconds_since(tr);
+                        if (!seg) return;
+                        seq = next_seq++;
+                        readCounter += seg->batch.records.size();
+                        too_short += seg->batch.records.size() - seg->prefix_idx.size();  // classify.hpp:247-250
+                        classify_reads_n += seg->prefix_idx.size();
+                        if (!seg->batch.error.empty()) std::cerr << "ERROR: " << seg->batch.error << std::endl;
+                    }
+                    std::vector<ReadState> state(seg->batch.records.size());
+                    const auto t0 = std::chrono::steady_clock::now();
+                    classify_segment(*seg, state);
+                    const double secs = seconds_since(t0);
+                    WriteJob job = format_segment(*seg, state);
+                    seg.reset();  // the staged chunks go back to the pool before the hand-over wait
+                    {
+                        std::unique_lock<std::mutex> lock(omu);
+                        ocv.wait(lock, [&] { return write_seq == seq || write_seq == ~0ULL; });
+                        if (write_seq == ~0ULL) return;  // another worker failed
+                        classify_seconds += secs;
+                    }
+                    {
+                        const auto tw = std::chrono::steady_clock::now();
+                        std::unique_lock<std::mutex> lock(wmu);
+                        wcv_room.wait(lock, [&] { return wjobs.size() < 4; });
+                        wjobs.push_back(std::move(job));
+                        wait_writer_s += seconds_since(tw);
+                    }
+                    wcv_job.notify_one();
+                    {
+                        std::lock_guard<std::mutex> lock(omu);
+                        if (write_seq != ~0ULL) ++write_seq;
+                    }
+                    ocv.notify_all();
+                }
+            } catch (const std::exception& ex) {
+                std::lock_guard<std::mutex> lock(omu);
+                if (worker_error.empty()) worker_error = ex.what();
+                write_seq = ~0ULL;  // nobody's turn any more: the other workers stop at their hand-over
+                ocv.notify_all();
             }
-            wcv_job.notify_one();
+        };
+        {
+            const unsigned n_classifiers = multi ? 1u : std::max(1u, opt.classify_threads);
+            std::vector<std::thread> workers;
+            for (unsigned i = 1; i < n_classifiers; ++i) workers.emplace_back(classifier);
+            classifier();
+            for (std::thread& t : workers) t.join();
         }
         {
             std::lock_guard<std::mutex> lock(wmu);
@@ -314,6 +380,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         }
         wcv_job.notify_one();
         writer.join();
+        if (!worker_error.empty()) throw std::runtime_error(worker_error);
         for (auto& f : targetFastas) f.close();
         UnclassifiedOut.close();
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
@@ -395,6 +462,7 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--no-digest")) no_digest = true;
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-bytes") && i + 1 < argc) opt.segment_bytes = (size_t)std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--parse-stats") && i + 1 < argc) {
@@ -421,7 +489,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--segment-mb N] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] "
                          "[--devices 0,1,...] [--parse-stats file]" << std::endl;
             return 0;
         }
