@@ -74,13 +74,15 @@ def parse():
 
 def other_configs():
     """Short runs of the other BASELINE configs that fit one GPU, each in a child process after the main measurement
-    (the headline line stays config 2): the 8 GiB GRCh38-scale filter (c3), deplete + target check_unblock (c4) and the
-    live replay (c5).  Reported as a compact summary next to the headline; failures are reported, never raised."""
+    (the headline line stays config 2): the 8 GiB GRCh38-scale filter (c3), deplete + target check_unblock (c4), the
+    live replay (c5) and the four narrow filters of the reference's README benchmark (readme).  Reported as a compact summary next to the headline; failures are reported, never raised."""
     import subprocess
     runs = {
         "c3": ["--workload", "c3", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
         "c4": ["--workload", "c4", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
         "c5": ["--workload", "c5", "--replay-seconds", "2.0"],
+        # the shape of the reference's only published benchmark (README.md:254-262; ~506 reads/s there, hardware unstated)
+        "readme": ["--workload", "readme", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
     }
     out = {}
     for name, argv in runs.items():
