@@ -3,9 +3,11 @@
 
 A step = one pass of the hot path (K1 count/max for every filter + K2 decision) over one batch of
 synthetic 360 bp read prefixes that is already resident in HBM, against IBF(s) resident in HBM.
-N=1 workload = BASELINE.json configs[1] ("c2"); other configs via --workload.  With N>1 (torchrun)
-every rank holds a replica of the IBF and its own shard of reads (weak scaling, no data-path
-collective); time = max over ranks, value = all reads / that time.
+N=1 workload = BASELINE.json configs[1] ("c2"); other configs via --workload.  With N>1 every rank
+(one process per GPU) holds a replica of the IBF and its own shard of reads (weak scaling, no data-path
+collective); time = max over ranks, value = all reads / that time.  `python bench.py --gpus N` starts
+the N ranks itself (fresh child processes, started before this process touches the GPU); under
+torchrun (WORLD_SIZE set) it is one of the ranks.
 
 Prints ONE JSON line with the driver contract fields plus "roofline" and "cpu_baseline".
 The CPU oracle is used here only as the checker / cpu_baseline leg, never in the timed path.
@@ -49,6 +51,58 @@ def host_cores():
     return n
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (rank i -> GPU i, RCCL
+    rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  This process never initialises the GPU (no HIP call,
+    no torch.cuda.is_available(): children started by a process that holds the device are refused on this pool) and it
+    never execs: it waits for the children and exits with the worst of their codes.  The reference's scaling model is N
+    classification workers behind one queue (src/main/adaptive_sampling.hpp:745-751); here a worker is a GPU."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   RB_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = None
+    while True:
+        alive = [p for p in procs if p.poll() is None]
+        if not alive:
+            break
+        failed = any(p.returncode for p in procs if p.returncode is not None)
+        if failed and deadline is None:
+            deadline = time.time() + 15.0  # a rank died: the others would wait in a collective for ever
+        if deadline is not None and time.time() > deadline:
+            for p in alive:
+                p.terminate()  # exact children of this process, by handle
+            deadline = float("inf")
+        time.sleep(0.2)
+    reader.join(10)
+    for line in "".join(out0).splitlines():  # the contract is ONE JSON line on stdout; library chatter goes to stderr
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    rc = 0
+    for p in procs:
+        rc = rc or (p.returncode or 0)
+    sys.exit(rc if rc >= 0 else 1)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,25 +126,33 @@ def parse():
     return ap.parse_args()
 
 
-def other_configs():
-    """Short runs of the other BASELINE configs that fit one GPU, each in a child process after the main measurement
-    (the headline line stays config 2): the 8 GiB GRCh38-scale filter (c3), deplete + target check_unblock (c4), the
-    live replay (c5) and the four narrow filters of the reference's README benchmark (readme).  Reported as a compact summary next to the headline; failures are reported, never raised."""
+def other_configs(args):
+    """Runs of the other BASELINE configs that fit one GPU, each in a child process after the main measurement (the
+    headline line stays config 2, the configuration BASELINE.json's metric is quoted on).  Config 3 -- the 8 GiB
+    GRCh38-scale filter, the HBM-bound case -- is a FULL run: same steps and warm-up as the headline, its own roofline
+    (live hipEvent kernel time), CPU baseline and parity leg; it comes back as `hbm_bound_config`.  Short runs: deplete +
+    target check_unblock (c4), the live replay (c5), the four narrow filters of the reference's README benchmark
+    (readme).  Failures are reported, never raised."""
     import subprocess
+    st, wu = str(args.steps), str(args.warmup)
     runs = {
-        "c3": ["--workload", "c3", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
+        "c3": ["--workload", "c3", "--steps", st, "--warmup", wu, "--cpu-seconds", "8", "--no-latency"],
         "c4": ["--workload", "c4", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
         "c5": ["--workload", "c5", "--replay-seconds", "2.0"],
         # the shape of the reference's only published benchmark (README.md:254-262; ~506 reads/s there, hardware unstated)
         "readme": ["--workload", "readme", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
     }
-    out = {}
+    out, hb = {}, None
     for name, argv in runs.items():
         try:
             p = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras"] + argv, capture_output=True,
-                               text=True, timeout=300)
+                               text=True, timeout=420)
             line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
             d = json.loads(line)
+            if name == "c3":
+                hb = {k: d.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
+                                            "cpu_baseline", "parity")}
+                continue
             o = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"]}
             if d.get("roofline", {}).get("frac") is not None:
                 o["roofline_frac"] = d["roofline"]["frac"]
@@ -100,10 +162,15 @@ def other_configs():
             if name == "c5":
                 o["latency"] = {k: v for k, v in d["latency"].items() if k.endswith("_ms") or k == "slo_met"}
                 o["micro_batch_reads"] = d["config"].get("micro_batch_reads")
+                o["dispatcher"] = d["config"].get("dispatcher")
             out[name] = o
         except Exception as ex:  # noqa: BLE001 -- the headline line must not depend on the extras
-            out[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
-    return out
+            err = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+            if name == "c3":
+                hb = err
+            else:
+                out[name] = err
+    return hb, out
 
 
 def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
@@ -189,37 +256,108 @@ def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
         dist.destroy_process_group()
 
 
+def null_engine_run(args, torch, dist, world, rank, backend):
+    """Control-flow test hook (RB_BENCH_ENGINE=none, set only by tests/): the rank flow of this script -- rendezvous,
+    barriers, max-over-ranks timing, the per-rank gather, the all-gather + max of the bin-sharded layout and the JSON
+    line -- with NO classification behind it, so that `bench.py --gpus 2` can be exercised on a box without a GPU.
+    There is no CPU implementation of the hot path: the line says so and its value means nothing."""
+    n_reads = args.reads or 1000
+    nf = 2
+
+    def partial(r):  # what rank r "counted": deterministic, different per rank
+        i = np.arange(n_reads * nf, dtype=np.uint64)
+        return ((i * np.uint64(2654435761) + np.uint64(r) * np.uint64(40503)) % np.uint64(65536)).astype(np.uint16).reshape(n_reads, nf)
+
+    reduce_ok = None
+    if dist is not None:
+        dist.barrier()
+    if os.environ.get("RB_BENCH_TEST_DIE_RANK") == str(rank):  # tests: the launcher must not hang on a dead rank
+        os._exit(7)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if args.bin_sharded and dist is not None:
+            mine = torch.from_numpy(partial(rank).view(np.uint8).copy())  # bytes: an all-gather does no arithmetic
+            gathered = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8)
+            dist.all_gather_into_tensor(gathered, mine)
+            got = gathered.numpy().view(np.uint16).reshape(world, n_reads, nf).max(axis=0)
+            exp = np.maximum.reduce([partial(r) for r in range(world)])
+            reduce_ok = bool(np.array_equal(got, exp)) and (reduce_ok is not False)
+        time.sleep(0.002)
+    t_local = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [t_local]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g = torch.zeros(world, dtype=torch.float64)
+        dist.all_gather_into_tensor(g, torch.tensor([t_local], dtype=torch.float64))
+        per_rank = g.tolist()
+    if rank == 0:
+        total = n_reads * (1 if args.bin_sharded else world) * args.steps
+        print(json.dumps({
+            "metric": "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)", "value": total / elapsed,
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.bin_sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "engine": "none (control-flow test hook RB_BENCH_ENGINE=none: no classification ran, the value is meaningless)",
+            "config": {"workload": "rank-flow test", "reads_per_gpu_per_step": n_reads},
+            "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "self_launched":
+                      os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
+                      "per_rank_reads_per_s": [n_reads * args.steps / x for x in per_rank]},
+            "bin_sharded_reduce_ok": reduce_ok, "roofline": None, "cpu_baseline": None}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)  # before anything touches the GPU
     import torch
-    from readbouncer_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     # test hooks (never set by the driver): RB_BENCH_BACKEND=gloo + RB_BENCH_SAME_GPU=1 run several ranks on ONE GPU,
-    # which exercises the multi-rank control flow of this script on a one-GPU box (RCCL refuses duplicate GPUs)
+    # which exercises the multi-rank control flow of this script on a one-GPU box (RCCL refuses duplicate GPUs);
+    # RB_BENCH_ENGINE=none runs that control flow with no GPU at all (null_engine_run)
     backend = os.environ.get("RB_BENCH_BACKEND", "nccl")
     same_gpu = os.environ.get("RB_BENCH_SAME_GPU") == "1"
+    no_engine = os.environ.get("RB_BENCH_ENGINE") == "none"
     dev_index = 0 if (same_gpu or world == 1) else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(dev_index)
         if backend == "nccl":
+            torch.cuda.set_device(dev_index)
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if no_engine:
+        return null_engine_run(args, torch, dist, world, rank, backend)
+    from readbouncer_amd import capi, synth
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
 
     # ---------------------------------------------------------------- workload (untimed set-up)
     t_setup = time.time()
     if args.workload == "c5":
-        return replay(args, torch, capi, synth, world, rank, dev_index, dev if backend == "nccl" else "cpu", dist)
+        return replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist)
     if args.workload == "c4":
         wd, wt = synth.WORKLOADS["c3"], synth.WORKLOADS["zymo"]
         dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
@@ -249,10 +387,13 @@ def main():
         deplete, target = [dep], []
         wname = w["name"]
         n_reads = args.reads or w["reads"]
+        if args.workload in ("c3", "c3np2") and not args.reads:
+            n_reads = 2_000_000  # per step; BASELINE's 10 M reads are five such steps (3.6 GB of read bytes per 10 M)
         read_len = w["read_len"]
     if args.read_len:
         read_len = args.read_len
     filters = deplete + target
+    nf = len(filters)
     geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in filters]
     bytes_per_read = synth.algorithmic_bytes_per_read(read_len, geo)
 
@@ -260,7 +401,7 @@ def main():
     t_seq, t_off, t_len = synth.make_reads_device(1000 + rank, n_reads, read_len, ref, dev)
     lens = np.full(n_reads, read_len, dtype=np.uint32)
     offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(read_len)
-    t_max = torch.zeros((n_reads, len(filters)), dtype=torch.int16, device=dev)
+    t_max = torch.zeros((n_reads, nf), dtype=torch.int16, device=dev)
     t_best = torch.zeros(n_reads, dtype=torch.int32, device=dev)
     t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
     t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
@@ -277,7 +418,10 @@ def main():
         # every rank classifies the SAME reads (seed of rank 0) against its column slice of every filter
         t_seq, t_off, t_len = synth.make_reads_device(1000, n_reads, read_len, ref, dev)
         eng.set_column_shard(rank, world)
-        t_red = torch.zeros((n_reads, len(filters)), dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        # the u16 partial maxima of all ranks, all-gathered as they are (byte view: an all-gather does no arithmetic, so
+        # there is no widening for the collective and half the bytes of an int32 all-reduce); the max over the ranks is
+        # taken inside the decision kernel
+        t_all = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8, device=red_dev)  # rank-major
 
     def step():
         if not bin_sharded:
@@ -285,16 +429,23 @@ def main():
                                 capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), t_best.data_ptr(), t_dec.data_ptr(),
                                 t_st.data_ptr(), stream)
             return
-        # partial maxima of this rank's columns -> all_reduce(max) over xGMI (u16 carried as i32) -> decision
+        # partial maxima of this rank's columns -> all_gather over xGMI -> decision over the gathered tables.
+        # Everything is ordered on `side` (the collective is enqueued with `side` current: RCCL's own stream waits for
+        # it and `side` waits for the collective); the host never waits inside a step.
         eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
                             capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), None, None, None, stream)
-        side.synchronize()
-        t_red.copy_(t_max.to(torch.int32) & 0xFFFF)
-        dist.all_reduce(t_red, op=dist.ReduceOp.MAX)
-        t_max.copy_(t_red.to(torch.int16))
-        torch.cuda.synchronize()
-        eng.decide_device(t_max.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95, capi.RB_MODE_CHECK_UNBLOCK,
-                          t_best.data_ptr(), t_dec.data_ptr(), t_st.data_ptr(), stream)
+        with torch.cuda.stream(side):
+            if backend == "nccl":
+                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8))
+                parts = t_all
+            else:  # gloo test hook: through the host
+                side.synchronize()
+                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8).cpu())
+                parts = t_all.to(dev, non_blocking=False)
+        eng.decide_device_parts(parts.data_ptr(), world, n_reads * nf, t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
+                                capi.RB_MODE_CHECK_UNBLOCK, t_best.data_ptr(), t_dec.data_ptr(), t_st.data_ptr(), stream)
+        if backend != "nccl":
+            side.synchronize()  # `parts` is a temporary of this step
 
     def barrier():
         torch.cuda.synchronize()
@@ -313,14 +464,20 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0  # this rank's own time for its K steps
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms, n_calls = eng.kernel_time()
     eng.set_timing(False)
+    per_rank_s = [t_local]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        g = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        dist.all_gather_into_tensor(g, torch.tensor([t_local], dtype=torch.float64, device=red_dev))
+        per_rank_s = g.tolist()
     total_reads = n_reads * (1 if bin_sharded else world) * args.steps
     value = total_reads / elapsed
 
@@ -328,15 +485,30 @@ def main():
     if rank == 0:
         avg_kernel_s = (kernel_ms / max(1, n_calls)) / 1e3
         achieved = bytes_per_read * n_reads / avg_kernel_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                per_read = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_read")
-                traffic = per_read * n_reads if per_read else None  # PMC passes of profiles/collect_pmc.sh
-            except Exception:
-                traffic = None
+        # fabric-side traffic of one launch: NOT measured in this run -- rocprofv3 --pmc passes of an earlier run of the
+        # same workload (profiles/collect_pmc.sh), kept in profiles/traffic.json and replayed here per read
+        traffic, traffic_source = None, None
+        tj = load_json("traffic.json").get(args.workload, {})
+        if tj.get("hbm_bytes_per_read") and not bin_sharded:
+            traffic = tj["hbm_bytes_per_read"] * n_reads
+            traffic_source = "profiles/traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc, separate passes, round 1")
+        ceil = load_json("ceilings.json").get(args.workload, {})
         decisions = t_dec.cpu().numpy()
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": "ibf_count_max_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_read": bytes_per_read,
+                "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
+        if ceil.get("GBps"):
+            # the same access pattern with no compute attached (profiles/hbm_peak.hip): what this chip delivers for it
+            roof["measured_ceiling"] = ceil["GBps"]
+            roof["frac_of_measured_ceiling"] = achieved / ceil["GBps"]
+            roof["measured_ceiling_source"] = ceil.get("source")
+        table_bytes = sum(f.info["n_words"] * 8 for f in filters)
+        if table_bytes < (256 << 20) * 4:
+            roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
+                            "`traffic` counts L2->fabric requests, Infinity-Cache hits included, so this is a fabric "
+                            "figure -- the HBM-bound case is config 3 (`hbm_bound_config`)" % (table_bytes / 1e9))
         result = {
             "metric": "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)",
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -346,16 +518,20 @@ def main():
             "config": {"workload": wname, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                        "filters": [{"n_bins": g[0], "k": g[1], "h": g[2], "bytes": f.info["n_words"] * 8}
                                    for g, f in zip(geo, filters)],
-                       "parallelism": ("bin-sharded x%d, all_reduce(max) of partial maxima" % world) if bin_sharded
+                       "parallelism": ("bin-sharded x%d, all_gather of u16 partial maxima, max taken in the decision "
+                                       "kernel" % world) if bin_sharded
                        else "read-sharded x%d, IBF replicated" % world,
                        "decisions": np.bincount(decisions, minlength=3).tolist()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ibf_count_max_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_read": bytes_per_read,
-                         "algorithmic_bytes_per_launch": bytes_per_read * n_reads},
+            "ranks": {"backend": backend, "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,
+                      "self_launched": os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
+                      "same_gpu_test_hook": same_gpu,
+                      "per_rank_reads_per_s": [n_reads * args.steps / x for x in per_rank_s]},
+            "roofline": roof,
             "setup_s": setup_s,
         }
+        if os.environ.get("RB_BENCH_DUMP_DECISIONS"):  # tests compare the N-rank decisions with the 1-rank run
+            import hashlib
+            result["config"]["decisions_sha1"] = hashlib.sha1(decisions.tobytes()).hexdigest()
 
     # ---------------------------------------------------------------- parity check + CPU baseline (rank 0, N=1)
     buf = None
@@ -400,7 +576,7 @@ def main():
         result["cpu_baseline"] = None
 
     # ---------------------------------------------------------------- per-read classify latency (small batches)
-    if rank == 0 and not args.no_latency:
+    if rank == 0 and not args.no_latency and not bin_sharded:
         lat = {}
         for mb in (64, 256, 1024):
             m = min(mb, len(buf) // read_len)
@@ -434,7 +610,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and world == 1 and args.workload == "c2" and not args.reads and not args.read_len and not args.no_extras:
-        result["other_configs"] = other_configs()
+        # free this process's filters and reads first: the children need the HBM (config 3 alone is 8 GiB + reads)
+        del eng, t_seq, t_off, t_len, t_max, t_best, t_dec, t_st
+        for f in filters:
+            f.free()
+        torch.cuda.empty_cache()
+        hb, others = other_configs(args)
+        result["hbm_bound_config"] = hb
+        result["other_configs"] = others
     if rank == 0:
         print(json.dumps(result))
         if result.get("parity", {}).get("decision_mismatches"):

@@ -147,7 +147,12 @@ enum rb_mode {
     /* check_unblock (src/main/adaptive_sampling.hpp:35-113): decision 0 wait / 1 unblock / 2 stop_receiving */
     RB_MODE_CHECK_UNBLOCK = 0,
     /* one chunk of classify_reads (src/main/classify.hpp:275-292, 58-111): decision 1 = classified */
-    RB_MODE_CLASSIFY_CHUNK = 1
+    RB_MODE_CLASSIFY_CHUNK = 1,
+    /* Read::classify(std::vector<TIbf>&) -> find_matches / select_matches (src/IBF/IBFClassify.cpp:181-226, 81-128,
+     * 16-38): decision 1 = some filter of the list (deplete entries first, then target entries) holds a bin whose
+     * forward or reverse count is >= the uint16_t threshold -- with a threshold of 0 that is every read, matches or
+     * not; status RB_ERR_SHORT_READ when the read is shorter than the first filter's k */
+    RB_MODE_CLASSIFY_ANY = 2
 };
 
 /* Batch form of Read::classify x3 + the decision, inputs and outputs in HOST memory.
@@ -229,6 +234,14 @@ RB_API int rb_engine_set_column_shard(rb_engine *e, int rank, int world);
 RB_API int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads,
                             uint32_t max_len, double error_rate, double significance, int mode,
                             void *d_best_target, void *d_decision, void *d_status, void *stream);
+
+/* Same for a bin-sharded node: d_maxcount holds n_parts partial tables (the all-gathered outputs of the ranks, each
+ * [n_reads x filters] u16, part_stride elements apart); the raw maximum of a (read, filter) is the max over them, taken
+ * inside the decision kernel -- no separate reduction pass and no widening of the u16 values for a collective. */
+RB_API int rb_decide_device_parts(rb_engine *e, const void *d_maxcount, uint32_t n_parts, uint64_t part_stride,
+                                  const void *d_lens, size_t n_reads, uint32_t max_len, double error_rate,
+                                  double significance, int mode, void *d_best_target, void *d_decision, void *d_status,
+                                  void *stream);
 
 /* ---- single-process multi-GPU pool -----------------------------------------------------------
  * One engine + one host thread per entry of devices[] (an entry may repeat), every filter replicated into each

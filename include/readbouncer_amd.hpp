@@ -448,7 +448,13 @@ public:
         if (filters.empty()) throw NullFilterException("No IBF provided to classify the read!");
         std::vector<IBFMeta> metas;
         for (TIbf& f : filters) metas.push_back(IBFMeta{f, "", 0});
-        return classify(metas, config) > -1;
+        // select_matches semantics (any bin >= threshold, so a threshold of 0 is a hit even without a match) live in the
+        // decision kernel as their own mode; this is NOT `classify(metas) > -1`
+        static const std::vector<IBFMeta> none;
+        BatchResult r = classify_batch(none, metas, config, {sequence}, RB_MODE_CLASSIFY_ANY);
+        if (r.status[0] == RB_ERR_SHORT_READ) throw ShortReadException("Read " + id + " shorter than kmer size");
+        throw_status(r.status[0], "classify");
+        return r.decision[0] != 0;
     }
 
     // IBFClassify.cpp:239-297: index of the best matching filter or -1

@@ -1,0 +1,240 @@
+// gather_probe.hip -- what limits random 8-byte gathers from a 10-20 MB table (the narrow-filter geometry: one- and
+// two-word IBF blocks) on this MI355X, and what the candidate ways around it would deliver.  No compute attached.
+//   full   : every lane gathers from the whole table (the round-1 kernel's pattern; L2 holds 4 MiB / table of it)
+//   xcd    : every lane gathers only from the eighth of the table that belongs to ITS XCD (HW_REG_XCC_ID): the ceiling
+//            of a scheme that routes each lookup to the XCD whose L2 owns the slice
+//   lds    : every workgroup copies a 128 KiB slice into LDS and gathers from there (ds_read_b64): the ceiling of a
+//            table-in-LDS scheme
+//   stream : coalesced 4-byte read + 8-byte write per item (the routing traffic such schemes pay per lookup)
+// Variants: element 8 or 16 bytes; load policy plain / nt / sc1 (agent scope) / sc0 sc1 (system scope); allocation
+// hipMalloc / hipDeviceMallocUncached / hipDeviceMallocFinegrained.
+// build+run on the GPU box:  hipcc -O3 --offload-arch=gfx950 profiles/gather_probe.hip -o /tmp/gather_probe && /tmp/gather_probe all
+// single case for a counter pass: /tmp/gather_probe one <mode> <table MiB> <esz> <policy> <alloc>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+__device__ __forceinline__ uint64_t mix(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+template <int POLICY>
+__device__ __forceinline__ uint64_t ld8(const uint64_t *p)
+{
+    if constexpr (POLICY == 1) return __builtin_nontemporal_load(p);
+    else if constexpr (POLICY == 2) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if constexpr (POLICY == 3) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else return *p;
+}
+
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID (20), offset 0, size 4)
+    return (uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+}
+
+// 24 gathers in flight per lane (8 steps x 3 "hash functions"), like the count kernel's one-lane-per-block form
+template <int ESZ, int POLICY, bool XCD>
+__global__ __launch_bounds__(256) void gather(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                              uint64_t *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t lo = 0, span = n_elems;
+    if constexpr (XCD) {
+        span = n_elems / 8;
+        lo = xcc_id() * span;
+    }
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint64_t v[8][3][ESZ / 8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+                const uint32_t idx = lo + (uint32_t)(((s >> 32) * (uint64_t)span) >> 32);
+                const uint64_t *p = table + (size_t)idx * (ESZ / 8);
+                if constexpr (ESZ == 8) {
+                    v[u][h][0] = ld8<POLICY>(p);
+                } else {
+                    u64x2 q;
+                    if constexpr (POLICY == 1) q = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p));
+                    else q = *reinterpret_cast<const u64x2 *>(p);
+                    v[u][h][0] = q.x;
+                    v[u][h][1] = q.y;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int e = 0; e < ESZ / 8; ++e) acc += v[u][0][e] & v[u][1][e] & v[u][2][e];
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+__global__ __launch_bounds__(1024) void gather_lds(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                    uint64_t *out)
+{
+    extern __shared__ uint64_t s_tab[];  // 16384 words = 128 KiB
+    const uint32_t slice = (blockIdx.x * 16384u) % (n_elems - 16384u);
+    for (uint32_t i = threadIdx.x; i < 16384u; i += blockDim.x) s_tab[i] = table[slice + i];
+    __syncthreads();
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint64_t a = ~0ULL;
+#pragma unroll
+            for (int h = 0; h < 3; ++h) {
+                s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+                a &= s_tab[(uint32_t)(s >> 50)];
+            }
+            acc += a;
+        }
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+// routing traffic: read a 4-byte query, write an 8-byte answer, both coalesced
+__global__ __launch_bounds__(256) void stream_qa(const uint32_t *__restrict__ q, uint64_t *__restrict__ a, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = (uint64_t)q[i] * 0x9E3779B97F4A7C15ULL;
+}
+
+static void *alloc_kind(size_t bytes, int kind)
+{
+    void *p = nullptr;
+    hipError_t e;
+    if (kind == 1) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    else if (kind == 2) e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    else e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { printf("alloc kind %d failed: %s\n", kind, hipGetErrorString(e)); return nullptr; }
+    (void)hipMemset(p, 0x5a, bytes);
+    (void)hipDeviceSynchronize();
+    return p;
+}
+
+static const char *kPolicy[] = {"plain", "nt", "sc1", "sc0sc1"};
+static const char *kAlloc[] = {"hipMalloc", "uncached", "finegrained"};
+
+template <int ESZ, int POLICY, bool XCD>
+static double run_gather(const uint64_t *t, size_t bytes, uint64_t *out)
+{
+    const uint32_t n = (uint32_t)(bytes / ESZ);
+    const uint32_t iters = 16;
+    const int blocks = 256 * 64;  // 16 waves per CU x 16 rounds
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather<ESZ, POLICY, XCD>), dim3(blocks), dim3(256), 0, 0, t, n, iters, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * 24;
+    return gathers / best / 1e6;  // G gathers/s
+}
+
+static double dispatch(const char *mode, const uint64_t *t, size_t bytes, int esz, int policy, uint64_t *out)
+{
+    const bool xcd = !strcmp(mode, "xcd");
+#define CASE(E, P)                                                                                   \
+    if (esz == E && policy == P) return xcd ? run_gather<E, P, true>(t, bytes, out) : run_gather<E, P, false>(t, bytes, out);
+    CASE(8, 0) CASE(8, 1) CASE(8, 2) CASE(8, 3) CASE(16, 0) CASE(16, 1)
+#undef CASE
+    return -1.0;
+}
+
+static void one(const char *mode, int mib, int esz, int policy, int kind, uint64_t *out)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, kind);
+    if (!t) return;
+    const double g = dispatch(mode, t, bytes, esz, policy, out);
+    printf("%-5s table %4d MiB  elem %2d B  %-6s %-11s : %7.1f G gathers/s  (%7.0f GB/s useful, %7.0f GB/s at 128 B/req)\n", mode, mib,
+           esz, kPolicy[policy], kAlloc[kind], g, g * esz, g * 128);
+    fflush(stdout);
+    (void)hipFree(t);
+}
+
+int main(int argc, char **argv)
+{
+    uint64_t *out;
+    (void)hipMalloc(&out, 8);
+    if (argc >= 7 && !strcmp(argv[1], "one")) {
+        one(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), out);
+        return 0;
+    }
+    // --- the wall: whole-table gathers by table size
+    for (int mib : {2, 10, 20, 64, 400}) one("full", mib, 8, 0, 0, out);
+    // --- request size / policy / allocation on the 20 MiB table
+    for (int p = 1; p < 4; ++p) one("full", 20, 8, p, 0, out);
+    for (int k = 1; k < 3; ++k)
+        for (int p : {0, 3}) one("full", 20, 8, p, k, out);
+    one("full", 20, 16, 0, 0, out);
+    one("full", 20, 16, 1, 0, out);
+    // --- slice per XCD: L2-resident gathers
+    for (int mib : {10, 20, 32}) one("xcd", mib, 8, 0, 0, out);
+    one("xcd", 20, 16, 0, 0, out);
+    one("xcd", 20, 8, 2, 0, out);
+    // --- table slice in LDS
+    {
+        const size_t bytes = (size_t)20 << 20;
+        uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gather_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        const uint32_t iters = 256;
+        const int blocks = 256 * 4;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(gather_lds, dim3(blocks), dim3(1024), 128 * 1024, 0, t, (uint32_t)(bytes / 8), iters, out);
+            (void)hipEventRecord(b);
+            (void)hipEventSynchronize(b);
+            (void)hipEventElapsedTime(&ms, a, b);
+        }
+        printf("lds   128 KiB slice per workgroup, ds_read_b64 : %7.1f G gathers/s (incl. the slice load)\n",
+               (double)blocks * 1024 * iters * 24 / ms / 1e6);
+        (void)hipFree(t);
+    }
+    // --- routing traffic
+    {
+        const size_t n = (size_t)1 << 28;
+        uint32_t *q = (uint32_t *)alloc_kind(n * 4, 0);
+        uint64_t *a8 = (uint64_t *)alloc_kind(n * 8, 0);
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(stream_qa, dim3(256 * 16), dim3(256), 0, 0, q, a8, n);
+            (void)hipEventRecord(b);
+            (void)hipEventSynchronize(b);
+            (void)hipEventElapsedTime(&ms, a, b);
+        }
+        printf("stream 4 B in + 8 B out per item, 2^28 items : %7.1f G items/s (%7.0f GB/s)\n", n / ms / 1e6, n * 12.0 / ms / 1e6);
+    }
+    return 0;
+}

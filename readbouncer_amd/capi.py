@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libreadbouncer_amd.so")
 (RB_OK, RB_ERR_NULL_FILTER, RB_ERR_SHORT_READ, RB_ERR_COUNT_KMER, RB_ERR_MISSING_FILE, RB_ERR_PARSE_IBF,
  RB_ERR_BAD_CHUNK, RB_ERR_STORE, RB_ERR_INVALID_ARG, RB_ERR_UNSUPPORTED, RB_ERR_NO_DEVICE, RB_ERR_HIP,
  RB_ERR_NOMEM) = range(13)
-RB_MODE_CHECK_UNBLOCK, RB_MODE_CLASSIFY_CHUNK = 0, 1
+RB_MODE_CHECK_UNBLOCK, RB_MODE_CLASSIFY_CHUNK, RB_MODE_CLASSIFY_ANY = 0, 1, 2
 
 
 class BatchDesc(C.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     "rb_classify_batch_device": (_int, [_vp, _vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp, _vp]),
     "rb_engine_set_column_shard": (_int, [_vp, _int, _int]),
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
+    "rb_decide_device_parts": (_int, [_vp, _vp, _u32, _u64, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_pool_create": (_int, [C.POINTER(_int), _sz, _pp, _sz, _pp, _sz, _pp]),
     "rb_pool_destroy": (None, [_vp]),
     "rb_pool_size": (_sz, [_vp]),
@@ -341,6 +342,14 @@ class Engine:
                       mode=RB_MODE_CHECK_UNBLOCK, d_best=None, d_decision=None, d_status=None, stream=None):
         _check(lib().rb_decide_device(self.h, d_maxcount, d_lens, n_reads, max_len, error_rate, significance, mode,
                                       d_best, d_decision, d_status, stream), "rb_decide_device")
+
+    def decide_device_parts(self, d_maxcount, n_parts, part_stride, d_lens, n_reads, max_len, error_rate=0.1,
+                            significance=0.95, mode=RB_MODE_CHECK_UNBLOCK, d_best=None, d_decision=None, d_status=None,
+                            stream=None):
+        """decision over n_parts all-gathered partial maxcount tables (bin-sharded ranks), part_stride elements apart"""
+        _check(lib().rb_decide_device_parts(self.h, d_maxcount, n_parts, part_stride, d_lens, n_reads, max_len, error_rate,
+                                            significance, mode, d_best, d_decision, d_status, stream),
+               "rb_decide_device_parts")
 
     def set_column_shard(self, rank, world):
         _check(lib().rb_engine_set_column_shard(self.h, rank, world), "rb_engine_set_column_shard")

@@ -75,10 +75,14 @@ inline uint8_t geom_code(int lg, int wpl, int nt) { return (uint8_t)(lg | (wpl =
 struct DecideParams {
     uint32_t nd, nt;
     uint32_t k[kMaxFilters];
-    const uint16_t *thr;  // [nf][2][thr_len]: thresholds at r and at r-0.02 by read length
+    const uint16_t *thr;  // [thr_len][nf][2]: thresholds at r and at r-0.02 by read length
     uint32_t thr_len;
     uint32_t max_len;  // declared upper bound of the read lengths of this batch
     uint16_t *maxcount_copy;  // optional second destination of the maxcount rows (pinned host memory of the micro-batch path)
+    // bin-sharded operation: maxcount holds n_parts partial tables (one per rank, all-gathered), part_stride elements apart;
+    // the raw maximum of a (read, filter) is the max over them.  1 = a plain table.
+    uint32_t n_parts;
+    uint64_t part_stride;
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);

@@ -96,10 +96,20 @@ struct rb_engine {
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
-    // threshold tables
-    DevBuf d_thr;
-    uint32_t thr_len = 0;
-    double thr_r = -1.0, thr_conf = -1.0;
+    // threshold tables u16[len][filter][{r, r-0.02}], one per (error rate, significance) pair; the two most recently used
+    // pairs stay resident so that a caller alternating two error rates never rebuilds (or waits for) a table.  A table
+    // that is replaced or outgrown may still be read by queued kernels: its device block is parked in thr_retired.
+    struct ThrTable {
+        void *d = nullptr;       // device copy
+        PinnedBuf host;          // page-locked host copy (source of the asynchronous upload; rows are appended on growth)
+        uint32_t len = 0;        // rows
+        double r = -1.0, conf = -1.0;
+        uint64_t last_use = 0;
+    };
+    ThrTable thr[2];
+    uint64_t thr_clock = 0;
+    std::vector<std::pair<void *, size_t>> thr_retired;
+    size_t thr_retired_bytes = 0;
     // workspaces
     DevBuf d_maxcount;
     std::vector<DevBuf> d_parts;  // per filter: partial maxima of the column slices
@@ -489,7 +499,12 @@ void rb_engine_destroy(rb_engine *e)
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     for (hipEvent_t ev : e->copy_ev) (void)hipEventDestroy(ev);
     for (DevBuf &b : e->d_parts) b.release();
-    for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_efflens, &e->d_prestatus, &e->d_thr, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+    for (auto &t : e->thr) {
+        if (t.d) (void)hipFree(t.d);
+        t.host.release();
+    }
+    for (auto &r : e->thr_retired) (void)hipFree(r.first);
+    for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_efflens, &e->d_prestatus, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
     e->h_in.release();
@@ -577,34 +592,76 @@ int rb_engine_kernel_time(rb_engine *e, double *total_ms, uint64_t *n_calls)
 
 }  // extern "C"
 
-// thresholds by read length for every filter at r and r-0.02 (host doubles, device table)
-static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st)
+// thresholds by read length for every filter at r and r-0.02 (host doubles -> device table); *tab_out / *len_out = the
+// table to hand to the decision kernel.  Nothing here waits for the GPU: a new or longer table gets a fresh device block
+// and is uploaded asynchronously on `st` from page-locked memory, the block it replaces is parked until the engine
+// goes away (or 64 MiB of parked blocks have piled up, which costs one device synchronisation).
+static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st, const uint16_t **tab_out,
+                             uint32_t *len_out)
 {
     // one table row per read length: 16 Mbp is far beyond any read the callers classify whole (chunk prefixes, 1.5 kbp
     // live cut-off) and keeps the table (4 bytes x filters x length) small
     if (max_len > (1u << 24)) return rb::fail(RB_ERR_UNSUPPORTED, "reads longer than 2^24 bases");
+    // NormalCDFInverse(1 - alpha/2) throws std::invalid_argument outside (0,1) (IBF.hpp:284-308): no thresholds, no decisions
+    {
+        const double p = 1.0 - (1.0 - conf) / 2.0;
+        if (!(p > 0.0 && p < 1.0)) return rb::fail(RB_ERR_INVALID_ARG, "significance outside the range NormalCDFInverse accepts");
+    }
     const uint32_t need = max_len + 1;
-    if (e->thr_len >= need && e->thr_r == r && e->thr_conf == conf) return RB_OK;
+    rb_engine::ThrTable *t = nullptr;
+    for (auto &c : e->thr)
+        if (c.d && c.r == r && c.conf == conf) t = &c;
+    if (!t) {  // take the empty or the least recently used slot
+        t = &e->thr[0];
+        if (e->thr[1].last_use < t->last_use || (!e->thr[1].d && t->d)) t = &e->thr[1];
+        t->len = 0;
+        t->r = r;
+        t->conf = conf;
+    }
+    t->last_use = ++e->thr_clock;
+    if (t->d && t->len >= need) {
+        *tab_out = (const uint16_t *)t->d;
+        *len_out = t->len;
+        return RB_OK;
+    }
     uint32_t cap = 1024;
     while (cap < need) cap <<= 1;
     const size_t nf = e->filters.size();
-    std::vector<uint16_t> tab(nf * 2 * (size_t)cap);
+    const size_t row = nf * 2;
+    // grow the host copy in place (rows [0, t->len) stay valid), then compute the new rows only
+    {
+        PinnedBuf bigger;
+        int rc = bigger.ensure((size_t)cap * row * 2);
+        if (rc != RB_OK) return rc;
+        if (t->len) std::memcpy(bigger.p, t->host.p, (size_t)t->len * row * 2);
+        t->host.release();
+        t->host = bigger;
+    }
+    uint16_t *tab = (uint16_t *)t->host.p;
     const double r2 = r - 0.02;  // "conf.error_rate -= 0.02" (adaptive_sampling.hpp:55, classify.hpp:67)
-    for (size_t fi = 0; fi < nf; ++fi) {
-        const uint64_t k = e->filters[fi]->geo.kmer_size;
-        for (uint32_t len = 0; len < cap; ++len) {
-            tab[(fi * 2 + 0) * cap + len] = threshold_u16(len, k, r, conf);
-            tab[(fi * 2 + 1) * cap + len] = threshold_u16(len, k, r2, conf);
+    for (uint32_t len = t->len; len < cap; ++len) {
+        for (size_t fi = 0; fi < nf; ++fi) {
+            const uint64_t k = e->filters[fi]->geo.kmer_size;
+            tab[((size_t)len * nf + fi) * 2 + 0] = threshold_u16(len, k, r, conf);
+            tab[((size_t)len * nf + fi) * 2 + 1] = threshold_u16(len, k, r2, conf);
         }
     }
-    // the previous table may still be in use by work queued on the stream
-    RB_HIP(hipStreamSynchronize(st));
-    int rc = e->d_thr.ensure(tab.size() * 2);
-    if (rc != RB_OK) return rc;
-    RB_HIP(hipMemcpy(e->d_thr.p, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
-    e->thr_len = cap;
-    e->thr_r = r;
-    e->thr_conf = conf;
+    if (t->d) {  // may still be read by kernels in flight
+        e->thr_retired.emplace_back(t->d, (size_t)t->len * row * 2);
+        e->thr_retired_bytes += (size_t)t->len * row * 2;
+        t->d = nullptr;
+        if (e->thr_retired_bytes > ((size_t)64 << 20)) {
+            RB_HIP(hipDeviceSynchronize());
+            for (auto &x : e->thr_retired) (void)hipFree(x.first);
+            e->thr_retired.clear();
+            e->thr_retired_bytes = 0;
+        }
+    }
+    RB_HIP(hipMalloc(&t->d, (size_t)cap * row * 2));
+    RB_HIP(hipMemcpyAsync(t->d, tab, (size_t)cap * row * 2, hipMemcpyHostToDevice, st));
+    t->len = cap;
+    *tab_out = (const uint16_t *)t->d;
+    *len_out = cap;
     return RB_OK;
 }
 
@@ -724,18 +781,19 @@ static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipSt
 
 static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
                       size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
-                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr)
+                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr,
+                      uint32_t n_parts = 1, uint64_t part_stride = 0)
 {
-    int rc = ensure_thresholds(e, max_len, r, conf, st);
-    if (rc != RB_OK) return rc;
     DecideParams P{};
+    int rc = ensure_thresholds(e, max_len, r, conf, st, &P.thr, &P.thr_len);
+    if (rc != RB_OK) return rc;
     P.nd = e->nd;
     P.nt = e->nt;
     for (size_t i = 0; i < e->filters.size(); ++i) P.k[i] = (uint32_t)e->filters[i]->geo.kmer_size;
-    P.thr = (const uint16_t *)e->d_thr.p;
-    P.thr_len = e->thr_len;
     P.max_len = max_len;
     P.maxcount_copy = maxcount_copy;
+    P.n_parts = n_parts ? n_parts : 1;
+    P.part_stride = part_stride;
     RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
 }
@@ -778,7 +836,8 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
                                 uint16_t *host_maxcount)
 {
     if (!e || !desc) return rb::fail(RB_ERR_INVALID_ARG, "null engine or descriptor");
-    if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK) return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
+    if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK && mode != RB_MODE_CLASSIFY_ANY)
+        return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
     const size_t n_reads = desc->n_items;
     if (n_reads >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "batch too large");
     if (n_reads == 0) return RB_OK;
@@ -900,21 +959,34 @@ int rb_classify_batch_device_ex(rb_engine *e, const rb_batch_desc *desc, double 
                                 stream, nullptr);
 }
 
-int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads, uint32_t max_len,
-                     double error_rate, double significance, int mode, void *d_best_target, void *d_decision,
-                     void *d_status, void *stream)
+int rb_decide_device_parts(rb_engine *e, const void *d_maxcount, uint32_t n_parts, uint64_t part_stride, const void *d_lens,
+                           size_t n_reads, uint32_t max_len, double error_rate, double significance, int mode,
+                           void *d_best_target, void *d_decision, void *d_status, void *stream)
 {
     if (!e || !d_maxcount || !d_lens) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (n_parts == 0 || (n_parts > 1 && part_stride < n_reads * e->filters.size()))
+        return rb::fail(RB_ERR_INVALID_ARG, "partial tables overlap");
+    if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK && mode != RB_MODE_CLASSIFY_ANY)
+        return rb::fail(RB_ERR_INVALID_ARG, "unknown mode");
     if (n_reads == 0) return RB_OK;
     std::lock_guard<std::mutex> lock(e->mu);
     int rc = check_device(e->device);
     if (rc != RB_OK) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     rc = run_decide(e, (const uint16_t *)d_maxcount, (const uint32_t *)d_lens, nullptr, n_reads, max_len, error_rate,
-                    significance, mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st);
+                    significance, mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st, nullptr,
+                    n_parts, part_stride);
     if (rc != RB_OK) return rc;
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     return RB_OK;
+}
+
+int rb_decide_device(rb_engine *e, const void *d_maxcount, const void *d_lens, size_t n_reads, uint32_t max_len,
+                     double error_rate, double significance, int mode, void *d_best_target, void *d_decision,
+                     void *d_status, void *stream)
+{
+    return rb_decide_device_parts(e, d_maxcount, 1, 0, d_lens, n_reads, max_len, error_rate, significance, mode, d_best_target,
+                                  d_decision, d_status, stream);
 }
 
 int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, const uint32_t *lens, size_t n_reads,

@@ -640,9 +640,18 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_reads) return;
+    const uint32_t nf = P.nd + P.nt;
+    // raw maximum of (this read, filter fi): the max over the partial tables of the ranks (bin-sharded), or the one table
+    auto raw_max = [&](uint32_t fi) -> uint32_t {
+        uint16_t m = maxcount[(size_t)i * nf + fi];
+        for (uint32_t q = 1; q < P.n_parts; ++q) {
+            const uint16_t v = maxcount[(size_t)q * P.part_stride + (size_t)i * nf + fi];
+            m = v > m ? v : m;
+        }
+        return m;
+    };
     if (P.maxcount_copy) {
-        for (uint32_t fi = 0; fi < P.nd + P.nt; ++fi)
-            P.maxcount_copy[(size_t)i * (P.nd + P.nt) + fi] = maxcount[(size_t)i * (P.nd + P.nt) + fi];
+        for (uint32_t fi = 0; fi < nf; ++fi) P.maxcount_copy[(size_t)i * nf + fi] = (uint16_t)raw_max(fi);
     }
     if (pre_status && pre_status[i] != RB_OK) {  // e.g. a chunk beyond the end of the read: no decision
         if (out_best_target) out_best_target[i] = -1;
@@ -657,17 +666,16 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
         if (out_status) out_status[i] = RB_ERR_INVALID_ARG;
         return;
     }
-    const uint32_t nf = P.nd + P.nt;
     const uint32_t tl = len < P.thr_len ? len : P.thr_len - 1;  // len <= max_len < thr_len
     // group maxima at r (1) and at r - 0.02 (2), strictly-greater argmax at r (first wins ties)
     uint32_t D1 = 0, T1 = 0, D2 = 0, T2 = 0;
     int best_d = -1, best_t = -1;
     for (uint32_t fi = 0; fi < nf; ++fi) {
-        const uint32_t M = maxcount[(size_t)i * nf + fi];
+        const uint32_t M = raw_max(fi);
         uint32_t c1 = 0, c2 = 0;
         if (len >= P.k[fi]) {  // pair overload skips filters with k > len; others count 0 there anyway
-            const uint16_t t1 = P.thr[((size_t)fi * 2 + 0) * P.thr_len + tl];
-            const uint16_t t2 = P.thr[((size_t)fi * 2 + 1) * P.thr_len + tl];
+            const uint16_t t1 = P.thr[((size_t)tl * nf + fi) * 2 + 0];
+            const uint16_t t2 = P.thr[((size_t)tl * nf + fi) * 2 + 1];
             c1 = (M >= t1) ? M : 0;  // max_matches with the uint16_t threshold
             c2 = (M >= t2) ? M : 0;
         }
@@ -682,7 +690,20 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
     uint8_t decision = 0, status = RB_OK;
     const bool short_d = P.nd && len < P.k[0];
     const bool short_t = P.nt && len < P.k[P.nd];
-    if (mode == RB_MODE_CHECK_UNBLOCK) {
+    if (mode == RB_MODE_CLASSIFY_ANY) {
+        // Read::classify(std::vector<TIbf>&) -> find_matches -> select_matches (IBFClassify.cpp:181-226, 81-128, 16-38):
+        // true iff some filter of the list (deplete entries first, then target) holds a bin with fwd >= t or rev >= t,
+        // i.e. raw max >= t with the uint16_t threshold -- a threshold of 0 makes every read a hit, 0 matches included
+        // (unlike max_matches, whose result is then 0 and reads as "no match").  No k > len skip here: find_matches
+        // evaluates every filter; only filters[0].kmerSize is checked (ShortReadException).
+        if (nf == 0) status = RB_ERR_NULL_FILTER;
+        else if (len < P.k[0]) status = RB_ERR_SHORT_READ;
+        else {
+            bool found = false;
+            for (uint32_t fi = 0; fi < nf; ++fi) found |= raw_max(fi) >= P.thr[((size_t)tl * nf + fi) * 2 + 0];
+            decision = found ? 1 : 0;
+        }
+    } else if (mode == RB_MODE_CHECK_UNBLOCK) {
         if (P.nd && P.nt) {
             if (D1 > 0) {
                 if (T1 > 0) decision = (D2 > 0 && T2 == 0) ? 1 : 0;

@@ -138,6 +138,20 @@ int main(int argc, char** argv)
     Read mer("35mer", "AAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAG");
     EXPECT_EQ(mer.classify(filters, cconf), -1);
 
+    // select_matches with a threshold of 0 (IBFClassify.cpp:16-38): at k = 13, r = 0.1 the CI upper bound equals the k-mer
+    // count for 123..130 bp, the uint16_t threshold is 0 and `count >= 0` holds for every bin -- the bool overload says
+    // true for a read without a single match, the argmax overload (max_matches -> 0) says -1
+    {
+        std::string nohit;  // fixed pseudo-random 126 bp sharing no 13-mer with the fixtures
+        for (uint32_t i = 0, x = 777u; i < 126; ++i) { x = x * 1664525u + 1013904223u; nohit += "ACGT"[(x >> 24) & 3]; }
+        EXPECT_EQ((int)rb_threshold(126, 13, 0.1, 0.95), 0);
+        Read quirk("quirk", nohit);
+        EXPECT_EQ(quirk.classify(filters, cconf), -1);
+        EXPECT_EQ(quirk.classify(IBFs, cconf), true);
+        Read longer("longer", nohit + nohit);  // 252 bp: threshold 18, no match -> false
+        EXPECT_EQ(longer.classify(IBFs, cconf), false);
+    }
+
     // ---- check_unblock (adaptive_sampling.hpp:35-113) on the same objects
     EXPECT_EQ((int)check_unblock(read, cconf, v1, v2), 0);            // hits both, also at r-0.02 -> keep sequencing
     EXPECT_EQ((int)check_unblock(read, cconf, v1, emptyVectorMeta), 1);   // deplete only, match -> unblock

@@ -1,0 +1,92 @@
+"""The N>1 path of bench.py: `python bench.py --gpus N` starts N ranks itself (children created before the parent touches
+the GPU), the ranks meet in a torch.distributed group, time = max over ranks, rank 0 prints ONE JSON line.
+
+CPU tests (world size 2, gloo): the rank flow runs with RB_BENCH_ENGINE=none -- a control-flow hook with NO classification
+behind it (there is no CPU implementation of the hot path to fall back to), so what is under test is the launcher, the
+rendezvous, the barriers, the timing reduction, the per-rank gather and the all-gather + max of the bin-sharded layout.
+GPU tests (`-m gpu`): the same command with the real engine, two ranks on the one GPU of the box (RCCL refuses duplicate
+devices, so the collectives go through gloo there), decisions equal to the 1-rank run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(argv, env_extra, timeout=240, launcher=None):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra)
+    cmd = (launcher or [sys.executable]) + [BENCH] + argv
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+CPU_HOOKS = {"RB_BENCH_ENGINE": "none", "RB_BENCH_BACKEND": "gloo"}
+
+
+def test_gpus2_self_launch_read_sharded_cpu():
+    p, d = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--reads", "400"], CPU_HOOKS)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["ranks"]["self_launched"] is True and d["ranks"]["backend"] == "gloo"
+    assert len(d["ranks"]["per_rank_reads_per_s"]) == 2 and all(x > 0 for x in d["ranks"]["per_rank_reads_per_s"])
+    assert "no classification ran" in d["engine"]  # the hook can never be mistaken for a measurement
+    # exactly one JSON line on stdout
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1
+    # whole-job aggregate: both ranks' reads over the max time
+    assert abs(d["value"] - 2 * 400 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
+
+
+def test_gpus2_self_launch_bin_sharded_cpu():
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300", "--bin-sharded"], CPU_HOOKS)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["bin_sharded_reduce_ok"] is True  # all-gather of the u16 partial tables + max == max of what every rank made
+
+
+def test_under_torchrun_cpu():
+    """the driver's own launch line: python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(port)]
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200"], CPU_HOOKS, launcher=launcher)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["ranks"]["self_launched"] is False
+
+
+def test_dead_rank_does_not_hang_the_launcher():
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200"],
+                dict(CPU_HOOKS, RB_BENCH_TEST_DIE_RANK="1"), timeout=120)
+    assert p.returncode != 0
+
+
+GPU_HOOKS = {"RB_BENCH_BACKEND": "gloo", "RB_BENCH_SAME_GPU": "1", "RB_BENCH_DUMP_DECISIONS": "1"}
+SMALL = ["--workload", "zymo", "--reads", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-latency"]
+
+
+@pytest.mark.gpu
+def test_gpus2_real_engine_decisions_equal_one_rank():
+    p1, d1 = _run(["--gpus", "1"] + SMALL, {"RB_BENCH_DUMP_DECISIONS": "1"}, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2, d2 = _run(["--gpus", "2"] + SMALL, GPU_HOOKS, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    assert d2["n_gpus"] == 2 and d2["ranks"]["self_launched"] is True and len(d2["ranks"]["per_rank_reads_per_s"]) == 2
+    # rank 0 of the read-sharded run holds the same shard (seed) as the single rank
+    assert d2["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
+    assert d2["config"]["decisions"] == d1["config"]["decisions"] and min(d1["config"]["decisions"][:2]) > 0
+    p3, d3 = _run(["--gpus", "2", "--bin-sharded"] + SMALL, GPU_HOOKS, timeout=600)
+    assert p3.returncode == 0, p3.stderr[-2000:]
+    assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"
+    # every rank counts its word columns of every block; all-gather + max in the decision kernel == the unsharded run
+    assert d3["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]

@@ -654,3 +654,41 @@ def test_engine_is_thread_safe():
     for th in threads:
         th.join()
     assert errors == []
+
+
+@pytest.mark.parametrize("nd,nt", [(0, 1), (0, 3), (2, 1)])
+def test_classify_any_matches_oracle(nd, nt):
+    """Read::classify(std::vector<TIbf>&) (IBFClassify.cpp:181-226 -> find_matches :81-128 -> select_matches :16-38):
+    any bin >= the uint16_t threshold in any filter of the list.  Differs from `classify(metas) > -1` where the
+    threshold is 0 (123..130 bp at k=13, r=0.1): every such read is a hit there, with or without a match."""
+    rng = np.random.default_rng(900 + 10 * nd + nt)
+    ref = H.random_dna(rng, 30000)
+    filters, views, keep = [], [], []
+    geos = [(90, 13), (200, 15), (64, 13)]
+    for i in range(nd + nt):
+        n_bins, k = geos[i % len(geos)]
+        W = (n_bins + 63) // 64
+        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 2003)
+        d.add_sequence(ref[i * 5000: i * 5000 + 9000], 1000)
+        o, kp = oracle_view(d)
+        filters.append(d); views.append(o); keep.append(kp)
+    zero_thr = [L for L in range(100, 160) if capi.threshold(L, 13, 0.1, 0.95) == 0]
+    assert zero_thr and min(zero_thr) >= 120 and max(zero_thr) <= 135  # the window the reference's quirk lives in
+    reads = make_reads(rng, ref, 300, lo=10, hi=450, err=0.12)
+    reads += [H.random_dna(rng, L) for L in range(118, 136)]            # no hit, threshold 0 inside the window
+    reads += [H.mutate(rng, ref[100:100 + L], 0.3) for L in range(118, 136)]
+    reads += ["", "ACGTACGTACGT", "ACGTACGTACGTA", "ACGTACGTACGTAC", "ACGTACGTACGTACG"]
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, filters[:nd], filters[nd:])
+    for r in (0.1, 0.07, 0.14):
+        _, _, found, status = eng.classify(buf, offs, lens, error_rate=r, mode=capi.RB_MODE_CLASSIFY_ANY)
+        n_quirk = 0
+        for i, rd in enumerate(reads):
+            st, exp = po.classify_any(views, po.encode(rd), r=r)
+            assert status[i] == st, (i, len(rd), r)
+            if st == 0:
+                assert bool(found[i]) == exp, (i, len(rd), r)
+                best_st, best = po.classify_best(views, po.encode(rd), r=r)
+                n_quirk += int(exp and best == -1)
+        if r == 0.1:
+            assert n_quirk >= 8  # reads that the bool overload accepts and the argmax overload does not
