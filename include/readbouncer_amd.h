@@ -114,6 +114,9 @@ RB_API int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out);
 /* load_filter straight into HBM, streamed through pinned staging (no full host copy) */
 RB_API int rb_dibf_open(int device, const char *path, rb_dibf **out);
 RB_API int rb_dibf_download(const rb_dibf *f, rb_ibf **out);
+/* replica of a resident filter on another GPU (or the same one), copied device to device -- over xGMI when the pair
+ * has peer access -- in its HBM layout: no host image, no conversion */
+RB_API int rb_dibf_clone_to(const rb_dibf *src, int device, rb_dibf **out);
 RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
 RB_API void *rb_dibf_device_words(rb_dibf *f);
 /* words between consecutive blocks of the device image (see above) */
@@ -132,6 +135,26 @@ RB_API int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_
 /* one reference sequence through the reference fragmenter; *next_bin = first_bin + #fragments */
 RB_API int rb_dibf_add_sequence(rb_dibf *f, const char *seq, size_t len, uint64_t fragment_length,
                                 uint64_t overlap_length, uint64_t first_bin, uint64_t *next_bin);
+
+/* First-contact check for a filter that came from somewhere else (a .ibf written by the reference).  The hash constants
+ * and the bit layout of the IBF live in a dependency that is not part of the reference tree (ibf_spec.h), so a filter
+ * file is the first place where a wrong constant would show: re-insert the reference sequences the file was built from
+ * (the reference fragmenter + insertKmer, src/IBF/IBFBuild.cpp:165-204,190) into an EMPTY filter of the same geometry
+ * and compare.  With matching constants the rebuilt bits are a subset of the file's bits: new_bits == 0 (SURVEY 7:
+ * "re-inserting a known reference must set no new bits") and rebuilt_bits / file_bits says how much of the file the
+ * given sequences explain; under a different seed, shift, k-mer encoding or block order about (1 - load) of the
+ * rebuilt bits land on clear positions. */
+typedef struct rb_ibf_compare {
+    uint64_t file_bits;     /* bits set in the block payload of the filter under test */
+    uint64_t rebuilt_bits;  /* bits the re-insertion sets */
+    uint64_t new_bits;      /* of those, bits that are clear in the filter under test -- must be 0 */
+    uint64_t payload_bits;  /* noOfBlocks * noOfBins: the positions insertKmer can reach */
+} rb_ibf_compare;
+RB_API int rb_dibf_compare(const rb_dibf *file_filter, const rb_dibf *rebuilt, rb_ibf_compare *out);
+/* Text of what the last rb_ibf_open / rb_dibf_open / rb_is_ibf_file on this thread found odd about a file that still
+ * parsed (non-zero spare metadata word, a hash-function count or k-mer size the reference never writes, tail bits set
+ * beyond the last block); empty string when there was nothing. */
+RB_API const char *rb_last_warning(void);
 
 /* ---- classification engine --------------------------------------------------------------
  * One engine per GPU.  It borrows the filters (like the reference's
@@ -251,6 +274,16 @@ RB_API int rb_decide_device_parts(rb_engine *e, const void *d_maxcount, uint32_t
 typedef struct rb_pool rb_pool;
 RB_API int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *deplete, size_t n_deplete,
                           const rb_ibf *const *target, size_t n_target, rb_pool **out);
+/* The same pool from .ibf FILES, without a host image of any filter (rb_pool_create needs rb_ibf images: 8 GiB on the host
+ * and one PCIe upload per device for a GRCh38 filter): every file is streamed once into the HBM of devices[0]
+ * (rb_dibf_open) and replicated from there to all other devices AT ONCE, device to device -- xGMI is point to point,
+ * devices[0] has a link of its own to each peer, so the N-1 copies run side by side at link speed (no ring, no tree:
+ * a tree would only add hops on a fully connected node).  A device that refuses peer access gets its copy by the
+ * runtime's staged path; if that fails too it streams the file itself.  replication_seconds (may be NULL): wall time
+ * of all device-to-device copies. */
+RB_API int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *const *deplete_paths, size_t n_deplete,
+                                     const char *const *target_paths, size_t n_target, rb_pool **out,
+                                     double *replication_seconds);
 RB_API void rb_pool_destroy(rb_pool *p);
 RB_API size_t rb_pool_size(const rb_pool *p);
 RB_API int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device);

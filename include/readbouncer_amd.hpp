@@ -265,6 +265,40 @@ public:
         return stats;
     }
 
+    // Not in the reference: first-contact check of a filter file against the reference sequences it was built from.
+    // Loads input_filter_file, re-runs parse_ref_seqs' per-record logic + the fragmenter + insertKmer (IBFBuild.cpp:66-92,
+    // 165-204, 190) over `records` into an EMPTY filter of the file's geometry and compares (rb_dibf_compare).  With the
+    // right layout/hash constants report.new_bits == 0.  bins_expected = the bin count create_filter would have chosen.
+    struct VerifyReport
+    {
+        rb_ibf_compare bits{};
+        uint64_t bins_file = 0, bins_expected = 0;
+        std::string warning;  // rb_last_warning() of the load
+        bool ok() const { return bits.new_bits == 0 && bins_file == bins_expected && bits.rebuilt_bits > 0; }
+    };
+    VerifyReport verify_filter(IBFConfig& config, const std::vector<RefSeq>& records)
+    {
+        VerifyReport rep;
+        load_filter(config);  // sets config.kmer_size
+        rep.warning = rb_last_warning();
+        TIbf file = filter;
+        std::vector<std::string> cleaned;
+        for (const RefSeq& r : records) {
+            if (r.seq.size() < config.kmer_size) continue;
+            std::string c(r.seq.size(), '\0');
+            c.resize(rb_cut_out_nnns(r.seq.data(), r.seq.size(), &c[0]));
+            rep.bins_expected += (uint32_t)(c.size() / config.fragment_length) + 1;
+            cleaned.push_back(std::move(c));
+        }
+        rep.bins_file = file.noOfBins;
+        // bins beyond the file's count cannot be inserted; such fragments are the mismatch bins_expected already reports
+        filter = TIbf(file.noOfBins, file.noOfHashFunc, file.kmerSize, file.noOfBits, config.device);
+        if (rep.bins_expected <= rep.bins_file) insert_all(cleaned, config, 0);
+        throw_status(rb_dibf_compare(file.handle(), filter.handle(), &rep.bits), "rb_dibf_compare");
+        filter = file;
+        return rep;
+    }
+
     // IBF::update_filter, IBFBuild.cpp:223-321: load update_filter_file, resizeBins(old + new), add the new
     // sequences starting at bin id totalBinsFile, store back to update_filter_file
     FilterStats update_filter(IBFConfig& config, const std::vector<RefSeq>& records)

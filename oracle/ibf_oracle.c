@@ -91,6 +91,13 @@ orc_ibf *orc_ibf_wrap(uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint
     return f;
 }
 
+/* TEST HOOK, not part of the restatement: re-derive the per-hash multipliers from another seedValue, to make filter files
+ * "written under different constants" for the first-contact check of the product (rb_dibf_compare / --verify-ibf). */
+void orc_ibf_set_seed_for_tests(orc_ibf *f, uint64_t seed)
+{
+    for (uint64_t i = 0; i < f->n_hash && i < ORC_MAX_HASH; ++i) f->precalc[i] = i ^ (f->kmer_size * seed);
+}
+
 void orc_ibf_free(orc_ibf *f)
 {
     if (!f) return;

@@ -76,6 +76,8 @@ orc_ibf *orc_ibf_new(uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint6
 orc_ibf *orc_ibf_wrap(uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits,
                       uint64_t *words);
 void orc_ibf_free(orc_ibf *f);
+/* test hook: hash with another seedValue (files "written under different constants") */
+void orc_ibf_set_seed_for_tests(orc_ibf *f, uint64_t seed);
 uint64_t *orc_ibf_words(orc_ibf *f);
 uint64_t orc_ibf_n_words(const orc_ibf *f);
 void orc_ibf_info(const orc_ibf *f, uint64_t *n_bins, uint64_t *n_hash, uint64_t *kmer_size,

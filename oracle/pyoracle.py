@@ -193,6 +193,12 @@ class OracleIBF:
             raise ValueError("resize_bins: cannot shrink")
         return OracleIBF(_handle=h)
 
+    def set_seed_for_tests(self, seed):
+        """test hook: hash with another seedValue"""
+        lib().orc_ibf_set_seed_for_tests.argtypes = [C.c_void_p, C.c_uint64]
+        lib().orc_ibf_set_seed_for_tests.restype = None
+        lib().orc_ibf_set_seed_for_tests(self.h, seed)
+
     def fill_synth(self, seed):
         lib().orc_ibf_fill_synth(self.h, seed)
 

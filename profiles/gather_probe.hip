@@ -83,6 +83,106 @@ __global__ __launch_bounds__(256) void gather(const uint64_t *__restrict__ table
     if (acc == 0x123456789ULL) out[0] = acc;
 }
 
+// "phased": the table is cut into S slices and the whole chip walks them in step with the 100 MHz wall clock -- during
+// window w (dt ticks long) every wave gathers only those of its 24 buffered lookups that fall into slice w % S, so each
+// XCD's L2 only has to hold one slice (plus stragglers) at a time.  A wave that is ahead of the clock sleeps until its
+// next window opens, a wave that is behind never waits.  No data moves anywhere new: block numbers and the AND
+// accumulators stay in registers, exactly like the one-lane-per-block count kernel holds them.
+// PF > 0: on entering a window every wave also touches PF x 64 lines of the NEXT slice (one dword per lane, 128 bytes
+// apart), a different piece per wave of the XCD, so that the slice is already in L2 when its window opens and the fabric
+// streams the table in the background instead of serving demand misses.
+template <int S, int NBUF, int PF>
+__global__ __launch_bounds__(256) void gather_phased(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                     uint32_t dt, uint64_t *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_slice = (n_elems + S - 1) / S;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t idx[NBUF];
+        uint32_t sl[NBUF];
+        uint64_t a[NBUF / 3];
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            idx[u] = (uint32_t)(((s >> 32) * (uint64_t)n_elems) >> 32);
+            sl[u] = idx[u] / per_slice;
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) a[u] = ~0ULL;
+        const uint64_t w0 = wall_clock64() / dt;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)S; ++q) {
+            const uint64_t w = w0 + q;
+            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            const uint32_t p = (uint32_t)(w % S);
+            uint32_t pf[PF > 0 ? PF : 1];
+            if constexpr (PF > 0) {
+                const uint32_t lines = per_slice / 16;              // 128-byte lines per slice
+                const uint32_t pieces = (lines + 63) / 64;
+                const uint32_t me = (blockIdx.x / 8) * 4 + (threadIdx.x >> 6);  // wave number within "its" XCD (round-robin placement)
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const uint32_t piece = (me * PF + k + (uint32_t)w * 7u) % pieces;
+                    uint32_t line = piece * 64 + (threadIdx.x & 63);
+                    line = line < lines ? line : lines - 1;
+                    const uint64_t e = (uint64_t)((p + 1) % S) * per_slice + (uint64_t)line * 16;
+                    pf[k] = reinterpret_cast<const uint32_t *>(table + (e < n_elems ? e : 0))[0];
+                }
+            }
+            uint64_t v[NBUF];
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) {
+                v[u] = ~0ULL;
+                if (sl[u] == p) v[u] = table[idx[u]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) a[u / 3] &= v[u];
+            if constexpr (PF > 0) {
+#pragma unroll
+                for (int k = 0; k < PF; ++k) acc ^= pf[k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) acc += a[u];
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+static void *alloc_kind(size_t bytes, int kind);
+static void one(const char *mode, int mib, int esz, int policy, int kind, uint64_t *out);
+
+template <int S, int NBUF, int PF = 0>
+static void run_phased(int mib, uint32_t dt, uint64_t *out)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+    if (!t) return;
+    const uint32_t n = (uint32_t)(bytes / 8);
+    const uint32_t iters = 16 * 24 / NBUF;
+    const int blocks = 256 * 64;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather_phased<S, NBUF, PF>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * NBUF;
+    printf("phased table %4d MiB  S=%2d  %2d lookups buffered per lane  prefetch %d  window %5.2f us : %7.1f G gathers/s\n", mib, S,
+           NBUF, PF, dt / 100.0, gathers / best / 1e6);
+    fflush(stdout);
+    (void)hipFree(t);
+}
+
 __global__ __launch_bounds__(1024) void gather_lds(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
                                                     uint64_t *out)
 {
@@ -180,6 +280,34 @@ int main(int argc, char **argv)
 {
     uint64_t *out;
     (void)hipMalloc(&out, 8);
+    if (argc >= 2 && !strcmp(argv[1], "phased")) {
+        for (int mib : {20, 10}) {
+            for (uint32_t dt : {100u, 200u, 300u, 400u, 600u, 1000u}) run_phased<8, 24>(mib, dt, out);
+            for (uint32_t dt : {100u, 200u, 400u}) run_phased<16, 24>(mib, dt, out);
+            for (uint32_t dt : {200u, 400u, 600u, 1000u}) run_phased<8, 48>(mib, dt, out);
+            for (uint32_t dt : {100u, 200u, 400u}) run_phased<16, 48>(mib, dt, out);
+        }
+        for (uint32_t dt : {200u, 400u}) run_phased<4, 24>(10, dt, out);
+        for (uint32_t dt : {400u, 800u}) run_phased<16, 48>(40, dt, out);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_pf")) {
+        for (int mib : {20, 10}) {
+            for (uint32_t dt : {150u, 200u, 300u, 400u, 600u}) run_phased<8, 24, 1>(mib, dt, out);
+            for (uint32_t dt : {200u, 300u, 400u}) run_phased<8, 24, 2>(mib, dt, out);
+            for (uint32_t dt : {200u, 300u, 400u, 600u}) run_phased<8, 48, 1>(mib, dt, out);
+            for (uint32_t dt : {200u, 300u, 400u, 600u}) run_phased<8, 48, 2>(mib, dt, out);
+            for (uint32_t dt : {100u, 150u, 200u, 300u}) run_phased<16, 24, 1>(mib, dt, out);
+            for (uint32_t dt : {100u, 150u, 200u, 300u}) run_phased<16, 48, 1>(mib, dt, out);
+        }
+        for (uint32_t dt : {200u, 300u, 400u}) run_phased<8, 24, 1>(5, dt, out);
+        for (uint32_t dt : {200u, 300u, 400u}) run_phased<8, 24, 0>(5, dt, out);
+        one("full", 5, 8, 0, 0, out);
+        for (uint32_t dt : {300u, 400u, 600u}) run_phased<16, 48, 2>(40, dt, out);
+        for (uint32_t dt : {300u, 400u, 600u}) run_phased<16, 48, 1>(40, dt, out);
+        one("full", 40, 8, 0, 0, out);
+        return 0;
+    }
     if (argc >= 7 && !strcmp(argv[1], "one")) {
         one(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), out);
         return 0;

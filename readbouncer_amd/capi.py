@@ -24,6 +24,10 @@ class BatchDesc(C.Structure):
                 ("chunk_start", C.c_uint32), ("chunk_length", C.c_uint32), ("d_read_ids", C.c_void_p)]
 
 
+class IbfCompare(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("file_bits", "rebuilt_bits", "new_bits", "payload_bits")]
+
+
 class IbfInfo(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("n_bins", "n_hash", "kmer_size", "n_bits", "bin_width", "n_blocks", "n_words")]
@@ -82,7 +86,12 @@ SIGNATURES = {
     "rb_decide_device": (_int, [_vp, _vp, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_decide_device_parts": (_int, [_vp, _vp, _u32, _u64, _vp, _sz, _u32, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_pool_create": (_int, [C.POINTER(_int), _sz, _pp, _sz, _pp, _sz, _pp]),
+    "rb_pool_create_from_files": (_int, [C.POINTER(_int), _sz, C.POINTER(C.c_char_p), _sz, C.POINTER(C.c_char_p), _sz, _pp,
+                                         C.POINTER(_dbl)]),
     "rb_pool_destroy": (None, [_vp]),
+    "rb_dibf_clone_to": (_int, [_vp, _int, _pp]),
+    "rb_dibf_compare": (_int, [_vp, _vp, C.POINTER(IbfCompare)]),
+    "rb_last_warning": (C.c_char_p, []),
     "rb_pool_size": (_sz, [_vp]),
     "rb_pool_set_min_split": (_int, [_vp, _sz]),
     "rb_pool_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
@@ -226,6 +235,18 @@ class DeviceIBF:
         h = C.c_void_p()
         _check(lib().rb_dibf_download(self.h, C.byref(h)), "rb_dibf_download")
         return HostIBF(h)
+
+    def clone_to(self, device):
+        """device-to-device replica (xGMI between peers) in the HBM layout"""
+        h = C.c_void_p()
+        _check(lib().rb_dibf_clone_to(self.h, device, C.byref(h)), "rb_dibf_clone_to")
+        return DeviceIBF(h)
+
+    def compare(self, rebuilt):
+        """bit statistics against a filter of the same geometry re-inserted from the reference sequences"""
+        c = IbfCompare()
+        _check(lib().rb_dibf_compare(self.h, rebuilt.h, C.byref(c)), "rb_dibf_compare")
+        return {k: getattr(c, k) for k, _ in IbfCompare._fields_}
 
     def device_words(self):
         return lib().rb_dibf_device_words(self.h)
@@ -402,6 +423,23 @@ class Pool:
                                     _handle_array(target_images), self.nt, C.byref(h)), "rb_pool_create")
         self.h = h
 
+    @classmethod
+    def from_files(cls, devices, deplete_paths, target_paths):
+        """filters streamed once into devices[0] and replicated device to device; no host images"""
+        self = cls.__new__(cls)
+        self.nd, self.nt = len(deplete_paths), len(target_paths)
+        self._keep = ()
+        devs = (C.c_int * len(devices))(*devices)
+        dp = (C.c_char_p * max(1, self.nd))(*[os.fsencode(x) for x in deplete_paths])
+        tp = (C.c_char_p * max(1, self.nt))(*[os.fsencode(x) for x in target_paths])
+        h = C.c_void_p()
+        secs = C.c_double(0)
+        _check(lib().rb_pool_create_from_files(devs, len(devices), dp, self.nd, tp, self.nt, C.byref(h), C.byref(secs)),
+               "rb_pool_create_from_files")
+        self.h = h
+        self.replication_seconds = secs.value
+        return self
+
     def size(self):
         return lib().rb_pool_size(self.h)
 
@@ -535,6 +573,10 @@ def fragment_bounds(length, fragment_length, k, overlap=1500):
 
 def is_ibf_file(path):
     return bool(lib().rb_is_ibf_file(os.fsencode(path)))
+
+
+def last_warning():
+    return lib().rb_last_warning().decode(errors="replace")
 
 
 def device_count():

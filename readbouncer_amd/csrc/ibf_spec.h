@@ -8,6 +8,27 @@
 //   seqan::count      src/IBF/IBFClassify.cpp:97-98,149-150
 //   seqan::insertKmer src/IBF/IBFBuild.cpp:190
 //   seqan::store      src/IBF/IBFBuild.cpp:505      seqan::retrieve  src/IBF/IBFBuild.cpp:343,360
+//
+// Where each constant was recalled from (upstream seqan/seqan, branch develop at the time the binning directory was
+// added, 2017-2018; the fork's branch is not pinned to a commit, so these are names to look for, not line numbers):
+//   include/seqan/binning_directory/binning_directory_interleaved_bloom_filter.h
+//     struct BinningDirectory<InterleavedBloomFilter, TConfig>: members noOfBins, noOfHashFunc, kmerSize, noOfBits,
+//     noOfBlocks, binWidth, blockBitSize, preCalcValues, `shiftValue = 27`, `seedValue = 0x90b45d39fb6da1fa`,
+//     `intSize = 0x40`, `filterMetadataSize{256}`;  init(): binWidth = ceil(noOfBins / intSize), blockBitSize =
+//     binWidth * intSize, noOfBlocks = noOfBits / blockBitSize, preCalcValues[i] = i ^ (kmerSize * seedValue);
+//     hashToIndex(): `hash ^= hash >> shiftValue; hash %= noOfBlocks; hash *= blockBitSize`;
+//     insertKmer(): vecIndex = preCalcValues[i] * kmerHash; hashToIndex; `vecIndex += binNo; set_pos(vecIndex)`;
+//     select()/count(): for every 64-bit batch of a block AND the words at the h positions, then ++counts[binNo] per set bit;
+//     getMetadata()/setMetadata(): noOfBins at bit noOfBits, noOfHashFunc at +64, kmerSize at +128 (64-bit fields).
+//   include/seqan/binning_directory/bitvector_uncompressed.h -- Bitvector<Uncompressed>: an sdsl::bit_vector of
+//     noOfBits + filterMetadataSize bits; store()/retrieve() = sdsl::store_to_file / load_from_file, i.e. the
+//     int_vector<1> serialisation of sdsl-lite v2.1.1 (u64 bit count, then the 64-bit words, LSB first).
+//   include/seqan/index/shape_base.h -- Shape<Dna5, SimpleShape>: hash()/hashNext() = base-|alphabet| polynomial of the
+//     ordinal values, most significant base first (the k-mer value fed to hashToIndex).
+//   include/seqan/basic/alphabet_residue.h + alphabet_residue_tabs.h -- Dna5 ordinals A0 C1 G2 T3 N4, the char ->
+//     Dna5 translation table (everything but ACGTacgt[Uu] -> N).
+// `rb_dibf_compare` / `readbouncer_amd_cli --verify-ibf` check all of them at once against a filter file and the FASTA
+// it was built from.
 #pragma once
 #include <stdint.h>
 

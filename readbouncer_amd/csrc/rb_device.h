@@ -102,6 +102,7 @@ hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, c
                          uint32_t n_fragments, uint64_t total_kmers, hipStream_t st);
 hipError_t launch_restride_blocks(const uint64_t *src, uint32_t s_src, uint64_t *dst, uint32_t s_dst, uint32_t w_copy,
                                   uint64_t n_blocks, hipStream_t st);
+hipError_t launch_compare_bits(const uint64_t *a, const uint64_t *b, uint64_t n_words, uint64_t *out3, hipStream_t st);
 hipError_t launch_fill_synth(uint64_t *words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
                              uint64_t last_mask, uint64_t seed, hipStream_t st);
 

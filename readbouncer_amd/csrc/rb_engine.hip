@@ -93,6 +93,7 @@ struct rb_engine {
     std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
+    uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
@@ -316,6 +317,71 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     return RB_OK;
 }
 
+// Replica of a device-resident filter on another GPU (or a second copy on the same one), device to device: over xGMI
+// when the two devices can reach each other (peer access is switched on for the pair), else staged by the runtime.  The
+// padded HBM image travels as it lies -- no host image, no layout conversion.  `stream_out`: NULL = wait for the copy;
+// otherwise the copy is left running on a new stream returned there (the caller synchronises and destroys it), so that
+// one source can feed several destinations at once, one xGMI link each.
+int rb_dibf_clone_to_impl(const rb_dibf *src, int device, rb_dibf **out, hipStream_t *stream_out, int *used_peer)
+{
+    if (!src || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    rb_dibf *f = nullptr;
+    int st = dibf_alloc(device, src->geo, false, &f);
+    if (st != RB_OK) return st;
+    const size_t bytes = dibf_device_words(src) * 8;
+    hipError_t e = hipSuccess;
+    int peer = 0;
+    if (device != src->device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, src->device) == hipSuccess && can) {
+            e = hipDeviceEnablePeerAccess(src->device, 0);  // current device (= destination, set by dibf_alloc) maps the source
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            peer = e == hipSuccess;
+            e = hipSuccess;  // without the mapping hipMemcpyPeer stages through the host: slower, still correct
+        }
+    }
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        e = device == src->device ? hipMemcpyAsync(f->d_words, src->d_words, bytes, hipMemcpyDeviceToDevice, s)
+                                  : hipMemcpyPeerAsync(f->d_words, device, src->d_words, src->device, bytes, s);
+    }
+    if (e == hipSuccess && !stream_out) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        if (s) (void)hipStreamDestroy(s);
+        rb_dibf_free(f);
+        return rb::fail(RB_ERR_HIP, std::string("device-to-device replication: ") + hipGetErrorString(e));
+    }
+    if (stream_out) *stream_out = s;
+    else (void)hipStreamDestroy(s);
+    if (used_peer) *used_peer = peer;
+    *out = f;
+    return RB_OK;
+}
+
+int rb_dibf_clone_to(const rb_dibf *src, int device, rb_dibf **out)
+{
+    return rb_dibf_clone_to_impl(src, device, out, nullptr, nullptr);
+}
+
+// wait for a clone started with a stream_out (rb_pool.cpp is a host translation unit: it does not see HIP types)
+int rb_dibf_clone_finish(void *stream)
+{
+    if (!stream) return RB_OK;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) return rb::fail(RB_ERR_HIP, std::string("device-to-device replication: ") + hipGetErrorString(e));
+    return RB_OK;
+}
+
+int rb_dibf_clone_start(const rb_dibf *src, int device, rb_dibf **out, void **stream, int *used_peer)
+{
+    hipStream_t s = nullptr;
+    const int rc = rb_dibf_clone_to_impl(src, device, out, &s, used_peer);
+    if (stream) *stream = (void *)s;
+    return rc;
+}
+
 int rb_dibf_download(const rb_dibf *f, rb_ibf **out)
 {
     if (!f || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
@@ -393,6 +459,31 @@ int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
     RB_HIP(hipMemset(f->d_words, 0, dibf_device_words(f) * 8));
     RB_HIP(launch_fill_synth(f->d_words, used, (uint32_t)f->geo.bin_width, (uint32_t)f->stride, last_mask, seed, nullptr));
     RB_HIP(hipDeviceSynchronize());
+    return RB_OK;
+}
+
+int rb_dibf_compare(const rb_dibf *file_filter, const rb_dibf *rebuilt, rb_ibf_compare *out)
+{
+    if (!file_filter || !rebuilt || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    const rb_ibf_info &a = file_filter->geo, &b = rebuilt->geo;
+    if (a.n_bins != b.n_bins || a.n_hash != b.n_hash || a.kmer_size != b.kmer_size || a.n_bits != b.n_bits ||
+        file_filter->device != rebuilt->device)
+        return rb::fail(RB_ERR_INVALID_ARG, "filters of different geometry (or on different devices) cannot be compared");
+    int st = check_device(file_filter->device);
+    if (st != RB_OK) return st;
+    uint64_t *d_out = nullptr;
+    RB_HIP(hipMalloc((void **)&d_out, 24));
+    hipError_t e = hipMemset(d_out, 0, 24);
+    // padding words and padding bits are zero in both images, so the padded HBM form can be compared as it lies
+    if (e == hipSuccess) e = launch_compare_bits(file_filter->d_words, rebuilt->d_words, a.n_blocks * file_filter->stride, d_out, nullptr);
+    uint64_t h[3] = {0, 0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, d_out, 24, hipMemcpyDeviceToHost);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return rb::fail(RB_ERR_HIP, std::string("compare: ") + hipGetErrorString(e));
+    out->file_bits = h[0];
+    out->rebuilt_bits = h[1];
+    out->new_bits = h[2];
+    out->payload_bits = a.n_blocks * a.n_bins;
     return RB_OK;
 }
 
@@ -889,13 +980,26 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     const bool fan_out = e->overlap && nf > 1 && !e->aux.empty() && n_reads > e->split_threshold;
     if (fan_out) {
         RB_HIP(hipEventRecord(e->fork_ev, st));
-        for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) RB_HIP(hipStreamWaitEvent(e->aux[k], e->fork_ev, 0));
+        for (size_t k = 0; k < e->aux.size(); ++k) RB_HIP(hipStreamWaitEvent(e->aux[k], e->fork_ev, 0));
     }
     std::vector<CountLaunch> pending;
     std::vector<uint32_t> pending_fi;
+    // Which filters may run side by side?  A table of a few tens of MB lives partly in the 4 MiB L2 of each XCD (hit rate
+    // about 4 MiB / table); two such tables gathered at once halve each other's share, so narrow filters take turns on the
+    // call's stream (measured on the README shape, four filters of 10-20 MB: 13.3 -> 16.5 M reads/s).  Tables far beyond
+    // that have no L2 share to lose and overlap on the auxiliary streams as before.
+    auto l2_sensitive = [&](const rb_dibf *f) { return f->geo.n_blocks * f->stride * 8 <= e->serial_table_bytes; };
+    size_t n_big = 0, n_small = 0;
+    for (const rb_dibf *f : e->filters) (l2_sensitive(f) ? n_small : n_big) += 1;
+    size_t next_aux = 0;
+    bool big_on_main = false;
     for (size_t fi = 0; fi < nf; ++fi) {
         const rb_dibf *f = e->filters[fi];
-        hipStream_t fs = (fan_out && fi > 0) ? e->aux[(fi - 1) % e->aux.size()] : st;
+        hipStream_t fs = st;
+        if (fan_out && !l2_sensitive(f)) {
+            if (n_small == 0 && !big_on_main) big_on_main = true;  // no narrow filter wants the main stream: the first big one takes it
+            else fs = e->aux[next_aux++ % e->aux.size()];
+        }
         CountLaunch a{};
         a.f = f->dev;
         a.src.seqs = (const uint8_t *)d_seqs;
@@ -935,7 +1039,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     }
     if ((rc = launch_fused_groups(e, pending, pending_fi, maxcount, st)) != RB_OK) return rc;
     if (fan_out) {
-        for (size_t k = 0; k < std::min(e->aux.size(), nf - 1); ++k) {
+        for (size_t k = 0; k < std::min(e->aux.size(), next_aux); ++k) {
             RB_HIP(hipEventRecord(e->join_ev[k], e->aux[k]));
             RB_HIP(hipStreamWaitEvent(st, e->join_ev[k], 0));
         }

@@ -14,6 +14,9 @@
 namespace rb {
 
 static thread_local std::string g_last_error;
+static thread_local std::string g_last_warning;
+void set_warning(const std::string &msg) { g_last_warning = msg; }
+const std::string &last_warning() { return g_last_warning; }
 
 void set_error(const std::string &msg) { g_last_error = msg; }
 int fail(int status, const std::string &msg)
@@ -96,6 +99,18 @@ int open_ibf_stream(const char *path, FILE **fp_out, rb_ibf_info *geo)
     if (!metadata_plausible(meta, n_bits) || !geometry_from(meta[0], meta[1], meta[2], n_bits, geo) || geo->n_blocks == 0) {
         std::fclose(fp);
         return fail(RB_ERR_PARSE_IBF, std::string(path) + ": metadata block does not describe an IBF");
+    }
+    // The file parsed; say what is odd about it all the same.  The metadata order {noOfBins, noOfHashFunc, kmerSize, spare}
+    // is recalled from SeqAn, not read from the reference tree (ibf_spec.h): values the reference never writes are the
+    // first hint that a file contradicts that recollection.
+    {
+        std::string w;
+        if (meta[3] != 0) w += "spare metadata word is " + std::to_string(meta[3]) + ", expected 0; ";
+        if (meta[1] != 3) w += "noOfHashFunc = " + std::to_string(meta[1]) + ", the reference always builds with 3 (IBFConfig.hpp:71); ";
+        if (meta[2] < 4 || meta[2] > 32) w += "kmerSize = " + std::to_string(meta[2]) + " is outside 4..32; ";
+        if (meta[0] > (1ull << 24)) w += "noOfBins = " + std::to_string(meta[0]) + " is implausibly large; ";
+        if (!w.empty()) w = std::string(path) + ": " + w + "check the layout constants in ibf_spec.h (rb_dibf_compare / --verify-ibf)";
+        set_warning(w);
     }
     fseeko(fp, 8, SEEK_SET);
     *fp_out = fp;
@@ -269,6 +284,8 @@ int rb_is_ibf_file(const char *path)
     std::fclose(fp);
     return 1;
 }
+
+const char *rb_last_warning(void) { return rb::last_warning().c_str(); }
 
 int rb_calculate_ci(double error_rate, uint8_t kmer_size, uint32_t readlen, double significance, uint16_t *low,
                     uint16_t *high)

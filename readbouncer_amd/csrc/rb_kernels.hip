@@ -792,6 +792,32 @@ __global__ void restride_blocks_kernel(const uint64_t *__restrict__ src, uint32_
     }
 }
 
+// first-contact check (rb_dibf_compare): bit statistics of two filters of one geometry -- out[0] = bits set in a,
+// out[1] = bits set in b, out[2] = bits set in b but not in a.  One 64-bit atomic per wave.
+__global__ void compare_bits_kernel(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b, uint64_t n_words,
+                                    unsigned long long *__restrict__ out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t sa = 0, sb = 0, snew = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) {
+        const uint64_t x = a[i], y = b[i];
+        sa += (uint64_t)__popcll(x);
+        sb += (uint64_t)__popcll(y);
+        snew += (uint64_t)__popcll(y & ~x);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sa += shfl64(sa, (threadIdx.x & 63) ^ m);
+        sb += shfl64(sb, (threadIdx.x & 63) ^ m);
+        snew += shfl64(snew, (threadIdx.x & 63) ^ m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + 0, (unsigned long long)sa);
+        atomicAdd(out + 1, (unsigned long long)sb);
+        atomicAdd(out + 2, (unsigned long long)snew);
+    }
+}
+
 // word w of the FILE layout (block w / bin_width, column w % bin_width) gets synth_word(seed, w); it is stored at the
 // padded position of that block
 __global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
@@ -1068,6 +1094,16 @@ hipError_t launch_restride_blocks(const uint64_t *src, uint32_t s_src, uint64_t 
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(restride_blocks_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, dst, s_dst, w_copy,
                        n_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_compare_bits(const uint64_t *a, const uint64_t *b, uint64_t n_words, uint64_t *out3, hipStream_t st)
+{
+    if (n_words == 0) return hipSuccess;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(compare_bits_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, a, b, n_words,
+                       reinterpret_cast<unsigned long long *>(out3));
     return hipGetLastError();
 }
 

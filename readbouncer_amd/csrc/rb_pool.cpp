@@ -3,6 +3,7 @@
 // The reference's scaling model is N classify threads popping one queue (src/main/adaptive_sampling.hpp:745-751);
 // here the N workers are GPUs.  Micro-batches are not split (latency): they go to one device, round-robin.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -123,6 +124,66 @@ int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *de
         if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
         w->thread = std::thread([w] { w->loop(); });
     }
+    *out = p;
+    return RB_OK;
+}
+
+int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *const *deplete_paths, size_t n_deplete,
+                              const char *const *target_paths, size_t n_target, rb_pool **out, double *replication_seconds)
+{
+    if (!out || !devices || n_devices == 0) return rb::fail(RB_ERR_INVALID_ARG, "no devices");
+    if (n_deplete + n_target == 0) return rb::fail(RB_ERR_NULL_FILTER, "No IBF provided to classify the read!");
+    rb_pool *p = new (std::nothrow) rb_pool();
+    if (!p) return rb::fail(RB_ERR_NOMEM, "alloc");
+    p->nd = n_deplete;
+    p->nt = n_target;
+    for (size_t d = 0; d < n_devices; ++d) {
+        Worker *w = new (std::nothrow) Worker();
+        if (!w) { rb_pool_destroy(p); return rb::fail(RB_ERR_NOMEM, "alloc"); }
+        w->device = devices[d];
+        p->workers.push_back(w);
+    }
+    double copy_s = 0.0;
+    for (size_t i = 0; i < n_deplete + n_target; ++i) {
+        const char *path = i < n_deplete ? deplete_paths[i] : target_paths[i - n_deplete];
+        rb_dibf *first = nullptr;
+        int rc = path ? rb_dibf_open(devices[0], path, &first) : rb::fail(RB_ERR_INVALID_ARG, "null filter path");
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+        p->workers[0]->filters.push_back(first);
+        // all peers at once: one stream per destination, each copy on its own xGMI link
+        std::vector<void *> streams(n_devices, nullptr);
+        std::vector<bool> need_file(n_devices, false);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t d = 1; d < n_devices; ++d) {
+            rb_dibf *f = nullptr;
+            int peer = 0;
+            if (rb_dibf_clone_start(first, devices[d], &f, &streams[d], &peer) == RB_OK) p->workers[d]->filters.push_back(f);
+            else need_file[d] = true;
+        }
+        for (size_t d = 1; d < n_devices; ++d) {
+            if (need_file[d]) continue;
+            if (rb_dibf_clone_finish(streams[d]) != RB_OK) {
+                rb_dibf_free(p->workers[d]->filters.back());
+                p->workers[d]->filters.pop_back();
+                need_file[d] = true;
+            }
+        }
+        copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (size_t d = 1; d < n_devices; ++d) {  // no device-to-device path: this device streams the file itself
+            if (!need_file[d]) continue;
+            rb_dibf *f = nullptr;
+            rc = rb_dibf_open(devices[d], path, &f);
+            if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+            p->workers[d]->filters.push_back(f);
+        }
+    }
+    for (Worker *w : p->workers) {
+        const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target,
+                                        &w->engine);
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+        w->thread = std::thread([w] { w->loop(); });
+    }
+    if (replication_seconds) *replication_seconds = copy_s;
     *out = p;
     return RB_OK;
 }

@@ -3,7 +3,8 @@
 // src/main/classify.hpp:142-380) on top of the C++ mirror.  The chunk loop of classify_reads is run
 // batch-wise: all reads of a batch are classified on chunk i in one GPU launch, reads that are still
 // unclassified go on to chunk i+1 -- per read this is the reference's loop (classify.hpp:262-299).
-// usage = "target" (live MinKNOW sampling) and "test" (connection test) are out of scope.
+// usage = "target" runs as an offline replay of the live classification step (pre-basecalled chunks from read_files
+// through rb_live_*); the MinKNOW client, the basecallers and usage "test" (connection test) are out of scope.
 #include <sys/resource.h>
 
 #include <chrono>
@@ -101,6 +102,52 @@ static std::vector<interleave::IBFMeta> getIBF(ConfigReader config, bool deplete
     return out;
 }
 
+// --verify-ibf: does this .ibf hold exactly what the reference fragmenter + insertKmer put there for this FASTA?  The
+// first thing to run on a filter written by the reference itself: the hash and layout constants of the IBF are restated
+// from SeqAn (readbouncer_amd/csrc/ibf_spec.h), and a file is where a wrong one would first show.
+static int verify_ibf(const std::string& ibf_path, const std::string& fasta_path, uint64_t fragment_size)
+{
+    seqio::Reader in(fasta_path);
+    if (!in.is_open()) { std::cerr << "ERROR: Unable to open the file: " << fasta_path << std::endl; return 1; }
+    std::vector<interleave::RefSeq> records;
+    std::string id, seq;
+    while (in.read_record(id, seq)) records.push_back({id.substr(0, id.find(' ')), seq});
+    interleave::IBFConfig cfg{};
+    cfg.input_filter_file = ibf_path;
+    cfg.fragment_length = fragment_size;
+    interleave::IBF f{};
+    interleave::IBF::VerifyReport rep = f.verify_filter(cfg, records);
+    if (!rep.warning.empty()) std::cout << "WARNING: " << rep.warning << std::endl;
+    const double load = rep.bits.payload_bits ? (double)rep.bits.file_bits / (double)rep.bits.payload_bits : 0.0;
+    std::cout << "VERIFY file=" << ibf_path << " kmer_size=" << cfg.kmer_size << " bins_file=" << rep.bins_file
+              << " bins_expected=" << rep.bins_expected << " file_bits=" << rep.bits.file_bits
+              << " rebuilt_bits=" << rep.bits.rebuilt_bits << " new_bits=" << rep.bits.new_bits
+              << " explained=" << (rep.bits.file_bits ? (double)(rep.bits.rebuilt_bits - rep.bits.new_bits) / (double)rep.bits.file_bits : 0.0)
+              << " load=" << load << std::endl;
+    if (rep.ok()) {
+        std::cout << "VERIFY OK: re-inserting " << records.size() << " sequences sets no new bit" << std::endl;
+        return 0;
+    }
+    if (rep.bins_file != rep.bins_expected)
+        std::cout << "VERIFY FAILED: the file has " << rep.bins_file << " bins, these sequences at fragment_size " << fragment_size
+                  << " make " << rep.bins_expected << " (wrong FASTA or fragment size?)" << std::endl;
+    else
+        std::cout << "VERIFY FAILED: " << rep.bits.new_bits << " of " << rep.bits.rebuilt_bits
+                  << " re-inserted bits are clear in the file -- hash/layout constants (ibf_spec.h) or k-mer encoding differ" << std::endl;
+    return 3;
+}
+
+// (seqan::Dna5String) of a character, printed back: ACGT in either case -> upper case, U/u -> T, everything else -> N
+static const struct Dna5CharTable {
+    char t[256];
+    Dna5CharTable()
+    {
+        for (int c = 0; c < 256; ++c) t[c] = 'N';
+        t['A'] = t['a'] = 'A'; t['C'] = t['c'] = 'C'; t['G'] = t['g'] = 'G'; t['T'] = t['t'] = 'T'; t['U'] = t['u'] = 'T';
+    }
+    char operator[](unsigned char c) const { return t[c]; }
+} kDna5Char;
+
 struct ReadState
 {
     bool classified = false, failed = false;
@@ -115,6 +162,7 @@ struct IngestOptions
     unsigned classify_threads = 2;  // threads running the chunk loop on the GPU (one engine each)
     size_t segment_mb = 64;      // file bytes per parsed segment
     size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
+    size_t live_batch = 64;      // usage "target" replay: chunks per micro-batch
     size_t bytes() const { return segment_bytes ? segment_bytes : (segment_mb << 20); }
 };
 
@@ -213,7 +261,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             const std::vector<seqio::Record>& recs = seg.batch.records;
             for (size_t i = 0; i < recs.size(); ++i)
                 if (recs[i].seq_len >= chunk_length && !state[i].failed && !state[i].classified)
-                    unclassified_bytes += recs[i].id_len + recs[i].seq_len + 3;
+                    unclassified_bytes += recs[i].id_len + recs[i].seq_len + recs[i].seq_len / 70 + 4;
             job.bufs.back().reserve(unclassified_bytes);
             for (size_t i = 0; i < recs.size(); ++i) {
                 const seqio::Record& r = recs[i];
@@ -233,8 +281,21 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                 out->push_back('>');
                 out->append(r.id, r.id_len);
                 out->push_back('\n');
-                out->append(r.seq, r.seq_len);
-                out->push_back('\n');
+                if (out != &job.bufs.back()) {  // target FASTAs: `targetFastas[i] << seq << std::endl` -- the raw read on one line
+                    out->append(r.seq, r.seq_len);
+                    out->push_back('\n');
+                } else {
+                    // unclassified.fasta: seqan::writeRecord(UnclassifiedOut, id, (seqan::Dna5String)seq) (classify.hpp:301) --
+                    // the Dna5 alphabet (upper case, everything but ACGT[U] becomes N) in SeqAn's default 70-column lines
+                    for (size_t p = 0; p < r.seq_len; p += 70) {
+                        const size_t n = std::min<size_t>(70, r.seq_len - p);
+                        const size_t at = out->size();
+                        out->resize(at + n + 1);
+                        char* dst = &(*out)[at];
+                        for (size_t k = 0; k < n; ++k) dst[k] = kDna5Char[(unsigned char)r.seq[p + k]];
+                        dst[n] = '\n';
+                    }
+                }
             }
             return job;
         };
@@ -408,6 +469,96 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
     }
 }
 
+// usage = "target" as an OFFLINE REPLAY of the live classification step (src/main/adaptive_sampling.hpp:214-356: what
+// happens to a basecalled chunk between classification_queue and action_queue).  The MinKNOW gRPC client and the
+// basecallers are out of scope; what they would deliver -- basecalled chunks, in arrival order -- comes from
+// [IBF] read_files instead: one record per chunk, the first word of the record id is the read id (chunks of one read
+// carry the same id and appear in the order they were sequenced; anything after the first blank, e.g. "ch=12 chunk=3",
+// is carried along as a comment).  The chunks go through rb_live_process in micro-batches of `live_batch` records (what
+// the basecaller threads would have queued while the GPU was busy), with the reference's bookkeeping: once_seen,
+// concatenation of undecided chunks, the 1500 bp cut-off, decision -> action (Data::sendActions, Data.cpp:169-187).
+// Output: <output_directory>/live_actions.tsv, one line per chunk in arrival order:
+//   record  read_id  action(none|unblock_read|stop_receiving_data)  status  classified_length
+// and the tallies the reference logs for a run.
+static int replay_target(ConfigReader& config, std::vector<interleave::IBFMeta>& DepletionFilters,
+                         std::vector<interleave::IBFMeta>& TargetFilters, size_t live_batch)
+{
+    if (config.IBF_Parsed.read_files.empty()) {
+        std::cerr << "usage \"target\": the live MinKNOW/basecaller connection is outside this engine's scope; list pre-basecalled "
+                     "chunk files under [IBF] read_files to replay them through the live classification step" << std::endl;
+        return 2;
+    }
+    rb_engine* engine = interleave::detail::engine_for(DepletionFilters, TargetFilters);
+    rb_live* live = nullptr;
+    // Conf.significance = 0.95, Conf.error_rate = exp_seq_error_rate (adaptive_sampling.hpp:563-566); 1500 bp cut-off (:315)
+    interleave::throw_status(rb_live_create(engine, config.IBF_Parsed.error_rate, 0.95, 1500, &live), "rb_live_create");
+    std::ofstream out(std::filesystem::path(config.output_dir) / "live_actions.tsv");
+    out << "record\tread_id\taction\tstatus\tclassified_length\n";
+    static const char* kAction[3] = {"none", "unblock_read", "stop_receiving_data"};
+    uint64_t n_records = 0, n_unblock = 0, n_stop = 0, n_failed = 0, n_calls = 0;
+    double classify_s = 0.0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (const std::filesystem::path& read_file : config.IBF_Parsed.read_files) {
+        seqio::MappedFile mapped(read_file.string());
+        if (!mapped.is_open()) { rb_live_destroy(live); throw interleave::FileParserException("ERROR: Unable to open the file: " + read_file.string()); }
+        seqio::Parser parser(mapped.data(), mapped.size());
+        seqio::Batch batch;
+        for (;;) {
+            parser.next_batch(batch, live_batch);
+            const size_t n = batch.records.size();
+            if (n) {
+                std::string ids, seqs;
+                std::vector<uint64_t> id_off(n), off(n);
+                std::vector<uint32_t> id_len(n), len(n);
+                for (size_t i = 0; i < n; ++i) {
+                    const seqio::Record& r = batch.records[i];
+                    size_t w = 0;
+                    while (w < r.id_len && r.id[w] != ' ' && r.id[w] != '\t') ++w;
+                    id_off[i] = ids.size(); id_len[i] = (uint32_t)w; ids.append(r.id, w);
+                    off[i] = seqs.size(); len[i] = (uint32_t)r.seq_len; seqs.append(r.seq, r.seq_len);
+                }
+                if (seqs.empty()) seqs.push_back('N');
+                std::vector<uint8_t> action(n), status(n);
+                std::vector<uint32_t> clen(n);
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = rb_live_process(live, ids.data(), id_off.data(), id_len.data(), seqs.data(), off.data(), len.data(), n,
+                                               action.data(), status.data(), clen.data());
+                classify_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (rc != RB_OK) { rb_live_destroy(live); interleave::throw_status(rc, "rb_live_process"); }
+                ++n_calls;
+                for (size_t i = 0; i < n; ++i) {
+                    out << n_records + i << '\t';
+                    out.write(ids.data() + id_off[i], id_len[i]);
+                    out << '\t' << kAction[action[i] < 3 ? action[i] : 0] << '\t' << (int)status[i] << '\t' << clen[i] << '\n';
+                    n_unblock += action[i] == 1;
+                    n_stop += action[i] == 2;
+                    if (status[i] != RB_OK) {
+                        ++n_failed;  // adaptive_sampling.hpp:340-349: logged, no action, state untouched
+                        log_line("error", "Error classifying Read : " + std::string(ids.data() + id_off[i], id_len[i]) + "(Len=" + std::to_string(len[i]) + ")");
+                    }
+                }
+                n_records += n;
+            }
+            if (!batch.error.empty()) { rb_live_destroy(live); throw interleave::FileParserException("ERROR: " + batch.error); }
+            if (batch.eof) break;
+        }
+    }
+    const size_t pending = rb_live_pending(live);
+    rb_live_destroy(live);
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    std::cout << "------------------------------- Live Replay Results -------------------------------" << std::endl;
+    std::cout << "Number of chunks replayed                          :   " << n_records << std::endl;
+    std::cout << "Number of unblock_read actions                     :   " << n_unblock << std::endl;
+    std::cout << "Number of stop_receiving_data actions              :   " << n_stop << std::endl;
+    std::cout << "Number of chunks that failed to classify           :   " << n_failed << std::endl;
+    std::cout << "Reads still waiting for more data (once_seen)      :   " << pending << std::endl;
+    std::cout << "LIVE chunks=" << n_records << " unblock=" << n_unblock << " stop=" << n_stop << " failed=" << n_failed
+              << " pending=" << pending << " calls=" << n_calls << " classify_s=" << classify_s << " wall_s=" << wall << std::endl;
+    log_line("info", "live replay: " + std::to_string(n_records) + " chunks, " + std::to_string(n_unblock) + " unblock, " +
+                         std::to_string(n_stop) + " stop_receiving");
+    return 0;
+}
+
 static int run_program(ConfigReader& config, const IngestOptions& opt, const std::vector<int>& devices)
 {
     config.parse();
@@ -431,7 +582,12 @@ static int run_program(ConfigReader& config, const IngestOptions& opt, const std
         classify_reads(config, DepletionFilters, TargetFilters, opt, devices);
         return 0;
     }
-    std::cerr << "usage \"" << config.usage << "\" is outside this engine's scope (supported: build, classify)" << std::endl;
+    if (config.usage == "target") {  // main.cpp:365-378, with the chunk source replaced (see replay_target)
+        std::vector<interleave::IBFMeta> DepletionFilters = getIBF(config, true, false);
+        std::vector<interleave::IBFMeta> TargetFilters = getIBF(config, false, true);
+        return replay_target(config, DepletionFilters, TargetFilters, opt.live_batch);
+    }
+    std::cerr << "usage \"" << config.usage << "\" is outside this engine's scope (supported: build, classify, target as an offline replay)" << std::endl;
     return 2;
 }
 
@@ -442,6 +598,8 @@ int main(int argc, char const* argv[])
     IngestOptions opt;
     bool no_digest = false;
     std::vector<int> devices{0};
+    std::string verify_path, verify_ref;
+    uint64_t verify_fragment = 100000;  // [IBF] fragment_size default (configReader.cpp)
     for (int i = 1; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) {  // e.g. --devices 0,1,2,3,4,5,6,7
             devices.clear();
@@ -459,12 +617,16 @@ int main(int argc, char const* argv[])
         }
         if ((!std::strcmp(argv[i], "--config") || !std::strcmp(argv[i], "-c")) && i + 1 < argc) config_path = argv[++i];
         else if (!std::strcmp(argv[i], "--dump-config")) dump_only = true;
+        else if (!std::strcmp(argv[i], "--verify-ibf") && i + 1 < argc) verify_path = argv[++i];
+        else if (!std::strcmp(argv[i], "--reference") && i + 1 < argc) verify_ref = argv[++i];
+        else if (!std::strcmp(argv[i], "--fragment-size") && i + 1 < argc) verify_fragment = (uint64_t)std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--no-digest")) no_digest = true;
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-bytes") && i + 1 < argc) opt.segment_bytes = (size_t)std::stoull(argv[++i]);
+        else if (!std::strcmp(argv[i], "--live-batch") && i + 1 < argc) opt.live_batch = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--parse-stats") && i + 1 < argc) {
             // ingest self-check (no GPU): records, bases and an FNV-1a digest over "id\tseq\n" of every record
             seqio::MappedFile mf(argv[++i]);
@@ -490,8 +652,18 @@ int main(int argc, char const* argv[])
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
             std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] "
-                         "[--devices 0,1,...] [--parse-stats file]" << std::endl;
+                         "[--devices 0,1,...] [--parse-stats file]\n"
+                         "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;
+        }
+    }
+    if (!verify_path.empty()) {
+        if (verify_ref.empty()) { std::cerr << "ERROR: --verify-ibf <file.ibf> needs --reference <file.fasta> [--fragment-size N]" << std::endl; return 1; }
+        try {
+            return verify_ibf(verify_path, verify_ref, verify_fragment);
+        } catch (const std::exception& e) {
+            std::cerr << "ERROR: " << e.what() << std::endl;
+            return 1;
         }
     }
     if (config_path.empty()) {

@@ -10,6 +10,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdlib>
@@ -181,16 +182,42 @@ class BlockPool
     BlockAllocator a_;
     std::mutex mu_;
     std::vector<std::pair<char*, size_t>> idle_;
+    std::vector<char*> heap_;  // blocks that fell back to the heap
 public:
     explicit BlockPool(BlockAllocator a) : a_(a) {}
     ~BlockPool()
     {
-        for (auto& b : idle_) free_block(b.first);
+        std::vector<std::pair<char*, size_t>> idle;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            idle.swap(idle_);
+        }
+        for (auto& b : idle) free_block(b.first);
     }
     BlockPool(const BlockPool&) = delete;
     BlockPool& operator=(const BlockPool&) = delete;
-    char* raw_alloc(size_t bytes) { return (char*)(a_.alloc ? a_.alloc(bytes) : std::malloc(bytes)); }
-    void free_block(char* p) { if (a_.release) a_.release(p); else std::free(p); }
+    // page-locked memory can run out (or be refused): such a block comes from the heap instead -- slower copies, same results
+    char* raw_alloc(size_t bytes)
+    {
+        char* p = a_.alloc ? (char*)a_.alloc(bytes) : nullptr;
+        if (p) return p;
+        p = (char*)std::malloc(bytes);
+        if (p && a_.alloc) {
+            std::lock_guard<std::mutex> lock(mu_);
+            heap_.push_back(p);
+        }
+        return p;
+    }
+    void free_block(char* p)
+    {
+        bool heap = !a_.release;
+        if (!heap) {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto it = std::find(heap_.begin(), heap_.end(), p);
+            if (it != heap_.end()) { heap_.erase(it); heap = true; }
+        }
+        if (heap) std::free(p); else a_.release(p);
+    }
     // a block of at least `bytes` (capacity returned through cap); throws std::bad_alloc
     char* get(size_t bytes, size_t* cap)
     {
@@ -311,6 +338,9 @@ class ParallelReader
                 if (stop_) return;
             }
             std::unique_ptr<Segment> seg(new Segment());
+            // nothing may escape a worker thread (std::terminate, with the consumers blocked in next()): a failure becomes
+            // a segment whose batch.error is set -- the consumer's ordinary error path, and the last segment it sees
+            try {
             Parser parser(data_ + starts_[s], starts_[s + 1] - starts_[s]);
             parser.next_batch(seg->batch, (size_t)-1);
             seg->batch.eof = seg->batch.eof && (!seg->batch.error.empty() || s + 2 == starts_.size());
@@ -328,6 +358,13 @@ class ParallelReader
                     out += prefix_len_;
                     seg->prefix_idx.push_back((uint32_t)i);
                 }
+            }
+            } catch (const std::exception& ex) {
+                seg->batch.error = std::string("ingest worker: ") + ex.what();
+                seg->batch.eof = true;
+            } catch (...) {
+                seg->batch.error = "ingest worker: unknown failure";
+                seg->batch.eof = true;
             }
             {
                 std::lock_guard<std::mutex> lock(mu_);

@@ -1,0 +1,71 @@
+// test_seqio.cpp -- CPU-only checks of the parallel ingest's failure paths (readbouncer_amd/host/seqio.hpp):
+// a page-locked allocator that refuses falls back to the heap with the same records and prefixes; an allocator that
+// throws inside a worker thread ends the stream with an error segment instead of std::terminate.
+#include <cstdio>
+#include <iostream>
+#include <new>
+#include <string>
+
+#include "../../readbouncer_amd/host/seqio.hpp"
+
+static int failures = 0;
+#define CHECK(c)                                                                  \
+    do {                                                                          \
+        if (!(c)) { ++failures; std::cerr << "FAILED " #c " at line " << __LINE__ << std::endl; } \
+    } while (0)
+
+static std::string make_fastq(size_t n)
+{
+    std::string s;
+    uint32_t x = 99;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t len = 30 + (i * 37) % 400;
+        std::string seq;
+        for (size_t k = 0; k < len; ++k) { x = x * 1664525u + 1013904223u; seq += "ACGT"[(x >> 24) & 3]; }
+        s += "@r" + std::to_string(i) + "\n" + seq + "\n+\n" + std::string(len, 'I') + "\n";
+    }
+    return s;
+}
+
+struct Digest { size_t records = 0, rows = 0; uint64_t h = 1469598103934665603ull; std::string error; };
+
+static Digest drain(seqio::ParallelReader& rd, uint32_t prefix_len)
+{
+    Digest d;
+    while (std::unique_ptr<seqio::Segment> seg = rd.next()) {
+        d.records += seg->batch.records.size();
+        d.rows += seg->prefix_idx.size();
+        for (size_t i = 0; i < seg->prefix_idx.size() * (size_t)prefix_len; ++i) { d.h ^= (unsigned char)seg->prefix[i]; d.h *= 1099511628211ull; }
+        if (!seg->batch.error.empty()) d.error = seg->batch.error;
+    }
+    return d;
+}
+
+int main()
+{
+    const std::string fq = make_fastq(3000);
+    seqio::ParallelReader plain(fq.data(), fq.size(), 3, 8192, 100);
+    const Digest a = drain(plain, 100);
+    CHECK(a.records == 3000 && a.rows > 1000 && a.error.empty());
+
+    seqio::BlockAllocator refusing;  // "page-locked memory is exhausted"
+    refusing.alloc = [](size_t) -> void* { return nullptr; };
+    refusing.release = [](void*) { std::abort(); };  // must never see a heap block
+    {
+        seqio::ParallelReader rd(fq.data(), fq.size(), 3, 8192, 100, refusing);
+        const Digest b = drain(rd, 100);
+        CHECK(b.records == a.records && b.rows == a.rows && b.h == a.h && b.error.empty());
+    }
+
+    seqio::BlockAllocator throwing;
+    throwing.alloc = [](size_t) -> void* { throw std::bad_alloc(); };
+    throwing.release = [](void*) {};
+    {
+        seqio::ParallelReader rd(fq.data(), fq.size(), 3, 8192, 100, throwing);
+        const Digest c = drain(rd, 100);
+        CHECK(!c.error.empty() && c.error.find("ingest worker") != std::string::npos);
+        CHECK(c.records <= a.records);
+    }
+    std::cout << "seqio checks done, failures: " << failures << std::endl;
+    return failures ? 1 : 0;
+}

@@ -455,6 +455,29 @@ def test_pool_shards_reads_across_engines():
             assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)
         pool.destroy()
     assert len(set(exp_dec.tolist())) == 3
+    # the same pool from .ibf FILES: streamed into device 0 once, replicated device to device (xGMI between peers; a
+    # same-device copy on this box), no host image -- same outputs
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for i, h in enumerate(images):
+            paths.append(os.path.join(tmp, "f%d.ibf" % i))
+            h.store(paths[-1])
+        for devices in ([0], [0, 0, 0]):
+            pool = capi.Pool.from_files(devices, paths[:1], paths[1:])
+            assert pool.size() == len(devices) and pool.replication_seconds >= 0.0
+            pool.set_min_split(500)
+            mc, best, dec, st = pool.classify(buf, offs, lens)
+            assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)
+            pool.destroy()
+        with pytest.raises(capi.RBError):
+            capi.Pool.from_files([0, 0], [os.path.join(tmp, "missing.ibf")], [])
+    # a clone is a bit-identical replica
+    d = capi.DeviceIBF.upload(0, images[0])
+    c = d.clone_to(0)
+    assert np.array_equal(c.download().words(), images[0].words())
+    cmp_ = d.compare(c)
+    assert cmp_["new_bits"] == 0 and cmp_["file_bits"] == cmp_["rebuilt_bits"] > 0
 
 
 def test_alphabet_conversion_on_device():
@@ -668,7 +691,7 @@ def test_classify_any_matches_oracle(nd, nt):
     for i in range(nd + nt):
         n_bins, k = geos[i % len(geos)]
         W = (n_bins + 63) // 64
-        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 2003)
+        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 200003)  # sparse: unrelated reads really count 0 everywhere
         d.add_sequence(ref[i * 5000: i * 5000 + 9000], 1000)
         o, kp = oracle_view(d)
         filters.append(d); views.append(o); keep.append(kp)

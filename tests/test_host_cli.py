@@ -357,3 +357,133 @@ def test_pipeline_settings_do_not_change_the_outputs(tmp_path):
     # with both filter sets only target reads count as classified (classify.hpp:58-111): kinds 2 and 4
     assert 950 < found < 1100 and len(exp_t) == found and short == 500 and len(exp_un) > 1000
     assert failed > 50  # a last chunk shorter than k throws in the reference (classify.hpp:306-316): counted, not written
+
+
+@pytest.mark.gpu
+def test_verify_ibf_first_contact_check(tmp_path):
+    """--verify-ibf: re-inserting the reference a filter was built from must set no new bit.  A file written by
+    the oracle builder passes; the same sequences hashed under another seedValue -- a stand-in for "the recalled SeqAn
+    constants are wrong" -- fail with about (1 - load) of the re-inserted bits on clear positions; the wrong FASTA or
+    fragment size is told apart by the bin count."""
+    rng = np.random.default_rng(4242)
+    seqs = [H.random_dna(rng, 250_000), H.random_dna(rng, 90_000) + "N" * 50 + H.random_dna(rng, 30_000), "ACGT"]
+    fasta = tmp_path / "ref.fasta"
+    fasta.write_text("".join(">s%d some description\n%s\n" % (i, s) for i, s in enumerate(seqs)))
+    good = H.build_filter_like_reference(seqs, k=13, fragment_length=100000)
+    good.store(str(tmp_path / "good.ibf"))
+    p = run_cli("--verify-ibf", str(tmp_path / "good.ibf"), "--reference", str(fasta))
+    assert "VERIFY OK" in p.stdout and " new_bits=0 " in p.stdout and "explained=1 " in p.stdout, p.stdout
+    # the same build under a different seed
+    cleaned = [po.cut_out_nnns(s) for s in seqs if len(s) >= 13]
+    n_bins = sum(len(c) // 100000 + 1 for c in cleaned)
+    bad = po.OracleIBF(n_bins, 3, 13, po.calculate_filter_size_bits(100000, 13, 3, 0.01, n_bins))
+    bad.set_seed_for_tests(0x9E3779B97F4A7C15)
+    b = 0
+    for c in cleaned:
+        b = bad.add_sequence(po.encode(c), 100000, b)
+    bad.store(str(tmp_path / "bad.ibf"))
+    p = run_cli("--verify-ibf", str(tmp_path / "bad.ibf"), "--reference", str(fasta), check=False)
+    assert p.returncode == 3 and "VERIFY FAILED" in p.stdout and "constants" in p.stdout, p.stdout
+    fields = dict(kv.split("=") for kv in p.stdout.split("VERIFY file=")[1].split("\n")[0].split()[1:])
+    assert int(fields["new_bits"]) > 0.7 * int(fields["rebuilt_bits"])  # about (1 - load) of them
+    # right constants, wrong fragment size: told apart by the bin count
+    p = run_cli("--verify-ibf", str(tmp_path / "good.ibf"), "--reference", str(fasta), "--fragment-size", "50000", check=False)
+    assert p.returncode == 3 and "wrong FASTA or fragment size" in p.stdout
+    # a file whose metadata tail holds values the reference never writes still loads, with a warning
+    odd = po.OracleIBF(n_bins, 2, 13, good.n_bits)
+    odd.store(str(tmp_path / "odd.ibf"))
+    p = run_cli("--verify-ibf", str(tmp_path / "odd.ibf"), "--reference", str(fasta), check=False)
+    assert "WARNING" in p.stdout and "noOfHashFunc = 2" in p.stdout
+
+
+@pytest.mark.gpu
+def test_unclassified_fasta_is_written_like_seqan_writes_it(tmp_path, refdata):
+    """classify.hpp:301: seqan::writeRecord(UnclassifiedOut, id, (seqan::Dna5String)seq) -- Dna5 alphabet (upper case,
+    U -> T, every other non-ACGT byte -> N), SeqAn's default 70-column FASTA lines.  Target FASTAs get the raw read
+    on one line (classify.hpp:288-289)."""
+    tgt_fa = os.path.join(refdata, "classifyTests_test.fasta")
+    tgt_seq = H.read_fasta(tgt_fa)[0][1]
+    rng = np.random.default_rng(31)
+    raw = H.random_dna(rng, 333)
+    mixed = raw[:100].lower() + "RYKM-*" + raw[100:200] + "uU" + raw[200:]        # 341 bases
+    hit = tgt_seq[100:400].lower()[:150] + tgt_seq[250:400]                       # target read, partly lower case
+    reads = tmp_path / "reads.fasta"
+    reads.write_text(">mixed case and IUPAC\n%s\n>exact70\n%s\n>hit\n%s\n" % (mixed, raw[:280], hit))
+    out = tmp_path / "out"
+    cfg = tmp_path / "c.toml"
+    write_config(cfg, "classify", out, kmer_size=13, fragment_size=100000, target_files=[tgt_fa], read_files=[reads],
+                 chunk_length=250, max_chunks=1)
+    run_cli("--config", str(cfg))
+    text = (out / "unclassified.fasta").read_text().split("\n")
+    exp_mixed = raw[:100] + "NNNNNN" + raw[100:200] + "TT" + raw[200:]
+    assert text[0] == ">mixed case and IUPAC"
+    assert text[1:6] == [exp_mixed[i:i + 70] for i in range(0, 341, 70)]
+    assert text[6] == ">exact70" and text[7:11] == [raw[i:i + 70] for i in range(0, 280, 70)] and text[11:] == [""]
+    assert (out / "classifyTests_test.fasta").read_text() == ">hit\n%s\n" % hit
+
+
+def test_ingest_worker_failures_do_not_terminate():
+    """tests/cpp/test_seqio.cpp (CPU only): refused page-locked blocks fall back to the heap, an exception inside a parser
+    thread ends the stream with an error segment"""
+    exe = os.path.join(ROOT, "readbouncer_amd", "test_seqio")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+def test_usage_target_replays_chunks_through_the_live_step(tmp_path):
+    """usage = "target" on the TOML surface (main.cpp:365-378) as an offline replay: pre-basecalled chunks in arrival order
+    -> rb_live_process micro-batches -> action list, equal to the sequential restatement of classify_live_reads
+    (adaptive_sampling.hpp:227-350) driven by the oracle, for every micro-batch size."""
+    from tests.test_gpu_live import reference_live
+    rng = np.random.default_rng(77)
+    host, bug = H.random_dna(rng, 30000), H.random_dna(rng, 30000)
+    (tmp_path / "host.fasta").write_text(">host\n%s\n" % host)
+    (tmp_path / "bug.fasta").write_text(">bug\n%s\n" % bug)
+    stream = []
+    mols = {}
+    for m in range(120):
+        kind, L = m % 5, int(rng.integers(300, 2600))
+        src = host if kind in (0, 4) else bug
+        s = int(rng.integers(0, 30000 - L))
+        mol = (H.mutate(rng, src[s:s + L], 0.25 if kind == 4 else 0.12) if kind in (0, 1, 4)
+               else H.random_dna(rng, L) if kind == 3 else H.mutate(rng, host[s:s + L // 2] + bug[s:s + L // 2], 0.05))
+        chunks, pos = [], 0
+        while pos < len(mol):
+            step = int(rng.choice([8, 120, 250, 360, 400]))
+            chunks.append(mol[pos:pos + step]); pos += step
+        mols["read%03d" % m] = chunks
+    alive = sorted(mols)
+    while alive:  # interleave the reads, chunks of one read stay in order
+        rid = alive[int(rng.integers(0, len(alive)))]
+        stream.append((rid, mols[rid].pop(0)))
+        if not mols[rid]:
+            alive.remove(rid)
+    fq = tmp_path / "chunks.fastq"
+    fq.write_text("".join("@%s ch=%d chunk=%d\n%s\n+\n%s\n" % (rid, i % 512, i, s, "I" * len(s)) for i, (rid, s) in enumerate(stream)))
+    od = H.build_filter_like_reference([host], k=13)
+    ot = H.build_filter_like_reference([bug], k=13)
+    exp, exp_once = reference_live([od], [ot], stream, r=0.1)
+    names = {0: "none", 1: "unblock_read", 2: "stop_receiving_data"}
+    for live_batch in (1, 7, 64):
+        out = tmp_path / ("out%d" % live_batch)
+        cfg = tmp_path / ("t%d.toml" % live_batch)
+        cfg.write_text('usage = "target"\noutput_directory = \'%s\'\nlog_directory = \'%s/logs\'\n\n[IBF]\nkmer_size = 13\n'
+                       "fragment_size = 100000\nexp_seq_error_rate = 0.1\ndeplete_files = ['%s']\ntarget_files = ['%s']\n"
+                       "read_files = ['%s']\n\n[MinKNOW]\nhost = \"localhost\"\nport = \"9502\"\nflowcell = \"MS00000\"\n\n"
+                       "[Basecaller]\ncaller = \"DeepNano\"\n" % (out, out, tmp_path / "host.fasta", tmp_path / "bug.fasta", fq))
+        p = run_cli("--config", str(cfg), "--live-batch", str(live_batch))
+        rows = [l.split("\t") for l in (out / "live_actions.tsv").read_text().splitlines()[1:]]
+        assert [r[1] for r in rows] == [rid for rid, _ in stream]
+        assert [(r[2], int(r[3])) for r in rows] == [(names[a], st) for a, st in exp]
+        summary = [l for l in p.stdout.splitlines() if l.startswith("LIVE ")][0]
+        assert "chunks=%d " % len(stream) in summary and "pending=%d " % len(exp_once) in summary
+        assert "unblock=%d " % sum(a == 1 for a, _ in exp) in summary and "stop=%d " % sum(a == 2 for a, _ in exp) in summary
+    assert sum(a == 1 for a, _ in exp) > 5 and sum(a == 2 for a, _ in exp) > 5
+    # without read_files the live connection would be needed: refused, with a pointer to the replay
+    cfg = tmp_path / "nofiles.toml"
+    cfg.write_text('usage = "target"\noutput_directory = \'%s\'\nlog_directory = \'%s/logs\'\n\n[IBF]\ndeplete_files = [\'%s\']\n'
+                   % (tmp_path / "o", tmp_path / "o", tmp_path / "host.fasta"))
+    p = run_cli("--config", str(cfg), check=False)
+    assert p.returncode == 2 and "read_files" in p.stderr
