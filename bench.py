@@ -121,6 +121,7 @@ def parse():
     ap.add_argument("--rate", type=float, default=150000.0, help="c5: total chunk arrival rate (chunks/s) over all GPUs")
     ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
     ap.add_argument("--read-len", type=int, default=0, help="override the read length of the workload (e.g. 1500: 16 counter planes)")
+    ap.add_argument("--phased", default="", help="tuning: 'off' or 'min_mib,max_mib,base_ticks,ticks_per_mib' for the clock-phased gathers of narrow filters")
     ap.add_argument("--no-extras", action="store_true",
                     help="default c2 run on one GPU: do not append the short runs of configs 3, 4 and 5 (`other_configs`)")
     return ap.parse_args()
@@ -196,30 +197,14 @@ def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
     arrival = np.cumsum(rng.exponential(1.0 / rate, size=n))
     offs0 = np.arange(n, dtype=np.uint64) * np.uint64(read_len)
     lens0 = np.full(n, read_len, dtype=np.uint32)
-    lat = np.zeros(n)
-    batches = []
     for _ in range(20):  # warm-up (allocations, threshold table, code objects of both kernel forms)
         eng.classify(buf[: 64 * read_len], offs0[:64], lens0[:64])
         eng.classify(buf[: 4096 * read_len], offs0[:4096], lens0[:4096])
     if dist is not None:
         dist.barrier()
-    decisions = np.zeros(n, dtype=np.uint8)
-    t0 = _t.perf_counter()
-    done = 0
-    while done < n:
-        now = _t.perf_counter() - t0
-        hi = int(np.searchsorted(arrival, now, side="right"))
-        if hi <= done:
-            continue  # spin until the next chunk arrives
-        hi = min(hi, done + 16384)
-        m = hi - done
-        _, _, dec, _ = eng.classify(buf[done * read_len: hi * read_len], offs0[:m], lens0[:m])
-        t_done = _t.perf_counter() - t0
-        lat[done:hi] = t_done - arrival[done:hi]
-        decisions[done:hi] = dec
-        batches.append(m)
-        done = hi
-    elapsed = _t.perf_counter() - t0
+    # the dispatcher loop runs inside the library (rb_replay_arrivals, C++ spin on the steady clock): no interpreter
+    # between an arrival and its call
+    decisions, lat, batches, service, elapsed = eng.replay_arrivals(buf, read_len, arrival, max_batch=16384)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -242,6 +227,12 @@ def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
                                    "micro-batches" % args.rate,
                        "arrival_rate_per_gpu": rate, "replay_seconds": args.replay_seconds,
                        "micro_batch_reads": {"mean": float(np.mean(batches)), "max": int(np.max(batches))},
+                       "dispatcher": {"kind": "C++ spin loop inside the library (rb_replay_arrivals)",
+                                      "call_service_ms": {"p50": float(np.percentile(service, 50) * 1e3),
+                                                          "p99": float(np.percentile(service, 99) * 1e3),
+                                                          "max": float(service.max() * 1e3)},
+                                      "note": "latency = queueing (waiting for the engine to come free) + the service "
+                                              "time of the call that carried the chunk"},
                        "decisions": np.bincount(decisions, minlength=3).tolist()},
             "latency": {"what": "arrival -> decision on the host, per read (queueing + H2D + kernels + D2H)",
                         "p50_ms": p50 * 1e3, "p99_ms": p99 * 1e3, "p99.9_ms": p999 * 1e3, "max_ms": pmax * 1e3,
@@ -408,6 +399,11 @@ def main():
     eng = capi.Engine(dev_index, deplete, target)
     if args.no_overlap:
         eng.set_overlap(False)
+    if args.phased == "off":
+        eng.set_phased(0, 0, 0, 0, 0)
+    elif args.phased:
+        lo, hi, base, tk = [int(x) for x in args.phased.split(",")]
+        eng.set_phased(lo << 20, hi << 20, base, tk, 1024)  # "0,0,300,3": plain gathers, but the short-read kernel for one-word filters
     # a dedicated non-null stream: steps are queued asynchronously; torch.cuda.synchronize() covers it
     side = torch.cuda.Stream(device=dev)
     stream = side.cuda_stream

@@ -312,6 +312,17 @@ RB_API size_t rb_live_pending(rb_live *lv);
 /* drop a read that ended on the sequencer before a decision was reached */
 RB_API int rb_live_forget(rb_live *lv, const char *id, uint32_t id_len);
 
+/* Replay of an arrival process through the engine (measurement aid for the live scenario; rb_live.cpp): chunk i = read_len
+ * bytes at seqs + i*read_len, available arrival_s[i] seconds after the start (ascending); a work-conserving dispatcher
+ * takes everything that has arrived (<= max_batch chunks, 0 = 16384) per rb_classify_batch call (check_unblock).
+ * out_latency_s[i] = decision - arrival; the first call_cap calls report their size and service time; out_calls = number of
+ * calls made.  The reference's counterpart is its classification thread popping one read at a time
+ * (src/main/adaptive_sampling.hpp:214-356). */
+RB_API int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len, size_t n, const double *arrival_s,
+                              size_t max_batch, double error_rate, double significance, uint8_t *out_decision,
+                              double *out_latency_s, uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap,
+                              size_t *out_calls, double *out_elapsed_s);
+
 /* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
  * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
  * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */
@@ -330,6 +341,20 @@ RB_API int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t 
 /* Filters larger than table_bytes are gathered with non-temporal loads (default 512 MiB = 2x the Infinity
  * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
+
+/* Narrow filters -- blocks of one to eight words, tables of a few L2 sizes (10-20 MB: a bacterial genome at the reference's
+ * default fragment_size) -- are bound by fabric REQUESTS, not bytes: each 8-byte gather that misses the XCD's 4 MiB L2
+ * costs a 128-byte request.  Two measures, both leave the results untouched:
+ *  - filters of at most `table_bytes` (default 64 MiB) never run beside another filter of the same call, so each has the
+ *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
+ *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads reads the
+ *    throughput kernel gathers in clock-phased slices: the table is cut into <= 8 slices and the 100 MHz wall clock tells
+ *    every wave which slice to gather from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns, so an
+ *    XCD's L2 holds one slice at a time (rb_engine_set_phased; max_table_bytes = 0 switches it off; all five arguments 0
+ *    also takes one-word filters back to the plain kernel, whose 512-k-mer tiles are half empty on 250 bp reads). */
+RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
+RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
+                                uint32_t ticks_per_mib, uint32_t min_reads);
 
 /* Host batches above 8 MB of read bytes cross PCIe in slices of about slice_bytes (default 32 MiB): slice i+1 is
  * copied on a copy stream while slice i is counted.  0 = one slice (no overlap).  Results are identical. */

@@ -100,11 +100,15 @@ SIGNATURES = {
     "rb_live_process": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp]),
     "rb_live_pending": (_sz, [_vp]),
     "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
+    "rb_replay_arrivals": (_int, [_vp, _vp, _u32, _sz, _vp, _sz, _dbl, _dbl, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz),
+                                  C.POINTER(_dbl)]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
+    "rb_engine_set_serial_table_bytes": (_int, [_vp, _u64]),
+    "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
 }
@@ -372,6 +376,22 @@ class Engine:
                                             significance, mode, d_best, d_decision, d_status, stream),
                "rb_decide_device_parts")
 
+    def replay_arrivals(self, seqs, read_len, arrival_s, max_batch=16384, error_rate=0.1, significance=0.95):
+        """work-conserving replay in C++ -> (decision[n], latency_s[n], call_reads[calls], call_service_s[calls], elapsed_s)"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        arrival_s = np.ascontiguousarray(arrival_s, dtype=np.float64)
+        n = len(arrival_s)
+        assert len(seqs) >= n * read_len
+        dec = np.zeros(n, dtype=np.uint8)
+        lat = np.zeros(n, dtype=np.float64)
+        cr = np.zeros(n, dtype=np.uint32)
+        cs = np.zeros(n, dtype=np.float64)
+        calls, el = C.c_size_t(0), C.c_double(0)
+        _check(lib().rb_replay_arrivals(self.h, _ptr(seqs), read_len, n, _ptr(arrival_s), max_batch, error_rate, significance,
+                                        _ptr(dec), _ptr(lat), _ptr(cr), _ptr(cs), n, C.byref(calls), C.byref(el)),
+               "rb_replay_arrivals")
+        return dec, lat, cr[:calls.value], cs[:calls.value], el.value
+
     def set_column_shard(self, rank, world):
         _check(lib().rb_engine_set_column_shard(self.h, rank, world), "rb_engine_set_column_shard")
 
@@ -386,6 +406,13 @@ class Engine:
 
     def set_nt_threshold(self, table_bytes):
         _check(lib().rb_engine_set_nt_threshold(self.h, table_bytes), "rb_engine_set_nt_threshold")
+
+    def set_serial_table_bytes(self, table_bytes):
+        _check(lib().rb_engine_set_serial_table_bytes(self.h, table_bytes), "rb_engine_set_serial_table_bytes")
+
+    def set_phased(self, min_table_bytes=6 << 20, max_table_bytes=32 << 20, base_ticks=350, ticks_per_mib=4, min_reads=32768):
+        _check(lib().rb_engine_set_phased(self.h, min_table_bytes, max_table_bytes, base_ticks, ticks_per_mib, min_reads),
+               "rb_engine_set_phased")
 
     def set_host_slice_bytes(self, slice_bytes):
         _check(lib().rb_engine_set_host_slice_bytes(self.h, slice_bytes), "rb_engine_set_host_slice_bytes")

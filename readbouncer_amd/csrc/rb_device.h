@@ -33,6 +33,15 @@ struct ReadSrc {
     uint32_t base_off;              // bases skipped at the start of every read (chunk start)
 };
 
+// Clock-phased gathers for tables of a few L2 sizes (narrow filters; rb_kernels.hip, "phased form"): the table is cut into
+// n_slices runs of 2^shift blocks, and window number (wall clock * inv_ticks) >> 32 tells the whole chip which slice to
+// gather from.  n_slices == 0: off.
+struct PhaseCfg {
+    uint32_t shift;      // log2 blocks per slice
+    uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 16
+    uint32_t inv_ticks;  // floor(2^32 / window length in 10 ns ticks)
+};
+
 constexpr unsigned kMaxFused = 8;
 constexpr int kSplitAnyWaves = 8;  // waves per workgroup of the mixed-geometry latency kernel (built for 512 threads)
 
@@ -56,6 +65,8 @@ struct CountLaunch {
     uint32_t n_slices;            // column slices of 2^lg * wpl words
     int lg, wpl, planes;
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
+    PhaseCfg phase;               // throughput form on narrow filters: clock-phased gathers (n_slices == 0: off)
+    int short_only;               // the declared max_len gives at most 256 k-mers per read
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
     int grid_parts;               // latency form: workgroups launched per (read, slice) = max parts of the fused filters

@@ -94,9 +94,16 @@ struct rb_engine {
     int shard_rank = 0, shard_world = 1;
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
+    // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
+    uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 32ull << 20;
+    uint32_t phase_base_ticks = 350, phase_ticks_per_mib = 4;  // window length in 10 ns ticks: base + per MiB of table
+    uint32_t phase_min_reads = 32768;
+    bool short_read_kernel = true;
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
+    bool tickets_dirty = false;  // a call that launched the multi-workgroup latency kernel did not come back clean: the arrival
+                                 // counters may be non-zero (the kernel zeroes them itself only when it runs to its end)
     // threshold tables u16[len][filter][{r, r-0.02}], one per (error rate, significance) pair; the two most recently used
     // pairs stay resident so that a caller alternating two error rates never rebuilds (or waits for) a table.  A table
     // that is replaced or outgrown may still be read by queued kernels: its device block is parked in thr_retired.
@@ -645,6 +652,30 @@ int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes)
     return RB_OK;
 }
 
+int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
+                         uint32_t ticks_per_mib, uint32_t min_reads)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->phase_min_bytes = min_table_bytes;
+    e->phase_max_bytes = max_table_bytes;
+    if (base_ticks || ticks_per_mib) {
+        e->phase_base_ticks = base_ticks;
+        e->phase_ticks_per_mib = ticks_per_mib;
+    }
+    e->phase_min_reads = min_reads;
+    e->short_read_kernel = !(min_table_bytes == 0 && max_table_bytes == 0 && base_ticks == 0 && ticks_per_mib == 0 && min_reads == 0);
+    return RB_OK;
+}
+
+int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->serial_table_bytes = table_bytes;
+    return RB_OK;
+}
+
 int rb_engine_set_host_slice_bytes(rb_engine *e, uint64_t slice_bytes)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -784,6 +815,27 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     a.split_waves = 0;
     if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
         a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
+    a.phase = PhaseCfg{0, 0, 0};
+    a.short_only = kmers <= 256;
+    const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
+    if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
+        if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
+            n_reads >= e->phase_min_reads) {
+            uint32_t sh = 0;
+            while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
+            uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
+            ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
+            a.phase.shift = sh;
+            a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
+            a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
+        } else if (a.lg == 0 && e->short_read_kernel) {
+            // one-word blocks outside the phased range still take that kernel for its both-strands-in-one-tile path for
+            // reads of up to 256 k-mers: one "slice" that holds every offset, no clock, no waiting
+            a.phase.shift = 31;
+            a.phase.n_slices = 1;
+            a.phase.inv_ticks = 0;
+        }
+    }
     a.split_parts = 1;
     a.split_sub = 1;
     if (a.split_waves >= 2)
@@ -809,6 +861,7 @@ static int launch_fused_groups(rb_engine *e, const std::vector<CountLaunch> &pen
     for (size_t i = 0; i < pending.size(); ++i) {
         if (done[i]) continue;
         CountLaunch g = pending[i];
+        g.phase.n_slices = 0;  // fused launches keep the plain gathers
         const bool split = g.split_waves >= 2;
         g.n_fused = 0;
         int want_waves = 0, grid_parts = 1;
@@ -863,8 +916,9 @@ static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipSt
     const size_t old_cap = e->d_split_tickets.cap;
     rc = e->d_split_tickets.ensure(items * 4);
     if (rc != RB_OK) return rc;
-    if (e->d_split_tickets.p != old || e->d_split_tickets.cap != old_cap)
+    if (e->d_split_tickets.p != old || e->d_split_tickets.cap != old_cap || e->tickets_dirty)
         RB_HIP(hipMemsetAsync(e->d_split_tickets.p, 0, e->d_split_tickets.cap, st));
+    e->tickets_dirty = true;  // until the call that uses them returns RB_OK
     a.split_ws = (uint64_t *)e->d_split_ws.p;
     a.split_tickets = (uint32_t *)e->d_split_tickets.p;
     return RB_OK;
@@ -1051,6 +1105,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         if (rc != RB_OK) return rc;
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
+    e->tickets_dirty = false;  // every launch of this call was accepted (and, on the engine's own stream, has finished)
     return RB_OK;
 }
 

@@ -119,6 +119,35 @@ struct Planes {
     }
 };
 
+// 64 x 64 bit-matrix transpose across the wave: bit j of lane i <-> bit i of lane j (six block swaps)
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane)
+{
+    constexpr uint64_t kMask[6] = {0x00000000FFFFFFFFULL, 0x0000FFFF0000FFFFULL, 0x00FF00FF00FF00FFULL,
+                                   0x0F0F0F0F0F0F0F0FULL, 0x3333333333333333ULL, 0x5555555555555555ULL};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int sft = 32 >> t;
+        const uint64_t m = kMask[t];
+        const uint64_t o = shfl64(x, lane ^ sft);
+        x = (lane & sft) ? ((x & ~m) | ((o & ~m) >> sft)) : ((x & m) | ((o & m) << sft));
+    }
+    return x;
+}
+
+// per-bin counts of 4 one-bit-per-bin words per lane, summed over the 64 lanes: lane b returns the count of bin b.
+// The lane-local sum (0..4 per bin) is three bit planes; each plane is transposed across the wave, so that lane b holds
+// bit b of every lane's plane word, and a popcount finishes the sum -- 36 cross-lane moves instead of the 120 of a
+// butterfly over ten counter planes.
+__device__ __forceinline__ uint32_t wave_bin_counts4(uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3, int lane)
+{
+    uint64_t h, l;
+    RB_CSA(h, l, x0, x1, x2);
+    const uint64_t c = l & x3;
+    const uint64_t p0 = l ^ x3, p1 = h ^ c, p2 = h & c;
+    return (uint32_t)__popcll(wave_transpose64(p0, lane)) + 2u * (uint32_t)__popcll(wave_transpose64(p1, lane)) +
+           4u * (uint32_t)__popcll(wave_transpose64(p2, lane));
+}
+
 // max over all bins held by the wave (WPL plane sets per lane), MSB plane first
 template <int NP, int WPL>
 __device__ __forceinline__ uint32_t planes_max(const Planes<NP> (&pl)[WPL], const uint64_t (&valid)[WPL])
@@ -219,11 +248,105 @@ struct BaseSrc {
 // Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
 // mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves) and of
 // each macro tile the eight-step blocks [blk_first, blk_end) (all STEPS / 8 of them, or a wave's share in the split kernel).
-template <int LG, int WPL, int NP, int H, bool NT>
+// The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the
+// window of its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  With ph = {shift 0.., n_slices 1, inv_ticks 0} and
+// a slice_shift of 31 this is one batch of predicated gathers with no waiting (tables that need no phasing).
+template <int H, bool NT>
+__device__ __forceinline__ void phased_gather8(uint64_t (&x)[8], const uint32_t (&bn)[8][H], const uint64_t *words,
+                                               uint32_t slice_shift, const PhaseCfg ph)
+{
+    const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+    uint32_t cur = w0 % ph.n_slices;
+#pragma unroll 1
+    for (uint32_t q = 0; q < ph.n_slices; ++q) {
+        // window w0 + q: wait for it to open (bounded: the clock's 32-bit wrap, once in 43 s, must not park a wave)
+        for (uint32_t guard = 0; guard < 2048; ++guard) {
+            const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+            if ((int32_t)(wn - (w0 + q)) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        uint64_t ld[8][H];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                ld[u][h] = ~0ULL;
+                // the offset is made opaque per window: otherwise the 24 addresses are widened to 64 bits and hoisted out
+                // of the window loop (48 registers that cost the third wave per SIMD)
+                uint32_t off = bn[u][h];
+                asm volatile("" : "+v"(off));
+                if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
+                    ld[u][h] = load_word<NT>(reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(words) + off));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int h = 0; h < H; ++h) x[u] &= ld[u][h];
+        }
+        cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
+    }
+}
+
+// The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's eight k-mers.
+// The twelve gathers of four k-mers go out together (48 registers of results in flight, like the 24 eight-byte ones).
+template <int H>
+__device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x1)[8], const uint32_t (&bn)[8][H],
+                                                 const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
+{
+    const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+    uint32_t cur = w0 % ph.n_slices;
+#pragma unroll 1
+    for (uint32_t q = 0; q < ph.n_slices; ++q) {
+        for (uint32_t guard = 0; guard < 2048; ++guard) {
+            const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+            if ((int32_t)(wn - (w0 + q)) >= 0) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            rb_u64x2 ld[4][H];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    ld[uu][h].x = ~0ULL;
+                    ld[uu][h].y = ~0ULL;
+                    uint32_t off = bn[half * 4 + uu][h];
+                    asm volatile("" : "+v"(off));
+                    if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
+                        ld[uu][h] = *reinterpret_cast<const rb_u64x2 *>(reinterpret_cast<const char *>(words) + off);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    x0[half * 4 + uu] &= ld[uu][h].x;
+                    x1[half * 4 + uu] &= ld[uu][h].y;
+                }
+            }
+        }
+        cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
+    }
+}
+
+// PH = clock-phased gathers (PhaseCfg): for a table of a few L2 sizes -- one- and two-word blocks, 10-20 MB -- every
+// 8-byte gather that misses the XCD's 4 MiB L2 costs a full 128-byte fabric request, and the chip serves about 60 G of
+// those per second whatever their useful size (profiles/r02/gather_probe.txt: 76 G gathers/s on 20 MiB against 269 G/s
+// from an L2-resident slice).  So the chip is made to work on ONE slice of the table at a time: the block numbers of a
+// macro tile stay in registers (they do anyway), the wall clock (s_memrealtime, the same on every CU) names the slice of
+// the moment, and each wave gathers only its lookups that fall into that slice, ANDing them into the per-k-mer words it
+// keeps in registers; after n_slices windows every lookup has been served once, in whatever window its slice came up.
+// Nothing depends on the timing but the speed: a wave that is ahead of the clock sleeps until its next window opens, one
+// that is behind never waits, and the result is the same AND of the same words.
+template <int LG, int WPL, int NP, int H, bool NT, bool PH = false>
 __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
                                              const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
                                              uint32_t mt_first, uint32_t mt_step, int blk_first, int blk_end,
-                                             uint8_t *stage, int lane)
+                                             uint8_t *stage, int lane, const PhaseCfg ph = PhaseCfg{0, 0, 0})
 {
     using T = TileShape<LG>;
     constexpr int NG = T::NG, SPT = T::SPT, J = T::J, ITEMS = T::ITEMS;
@@ -277,7 +400,33 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 if (first >= n) break;  // wave-uniform
             }
             uint64_t x[WPL][8];
-            if constexpr (H > 0) {
+            if constexpr (H > 0 && PH) {
+                static_assert(WPL == 1, "the phased form serves blocks of at most 8 words");
+                // what a lane keeps per lookup is the BYTE offset of its word in the table (32 bits: the engine plans this
+                // form for tables far below 4 GiB), so that the gathers take the scalar-base + 32-bit-offset form -- block
+                // numbers plus 64-bit addresses would not leave room for three waves per SIMD
+                uint32_t bn[8][H];
+                const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
+                const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(S)));  // S (words per block) is a power of two here
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int s = blk * 8 + u;
+                    const int j = (SPT >= 8) ? 0 : (u / SPT);
+                    const int it = (s % SPT) * NG + g;
+                    const uint32_t p = mt + (uint32_t)(j * 64 + it);
+                    const bool ok = (p < n) && lc.colok;
+                    x[0][u] = ok ? lc.valid[0] : 0ULL;
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        uint32_t b;
+                        if constexpr (LG == 0) b = idx[j][h];
+                        else b = shfl32(idx[j][h], it);
+                        // a lookup that is not to be made gets an offset no slice ever has
+                        bn[u][h] = ok ? b * (S * 8u) + col_bytes : 0xFFFFFFFFu;
+                    }
+                }
+                phased_gather8<H, NT>(x[0], bn, f.words, slice_shift, ph);
+            } else if constexpr (H > 0) {
                 constexpr int HALF = (WPL == 1) ? 8 : 4;  // steps per load batch
 #pragma unroll
                 for (int half = 0; half < 8 / HALF; ++half) {
@@ -414,6 +563,142 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
         best = m > best ? m : best;
     }
     if (lane == 0) out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)best;
+}
+
+// throughput form with clock-phased gathers (see count_strand): narrow filters of a few L2 sizes, one column slice
+// (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with.  SHORT = the engine
+// knows that no read of the batch has more than 256 k-mers: only the both-strands path is compiled in, which fits four
+// waves per SIMD.)
+template <int LG, int NP, bool SHORT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, (SHORT && LG == 0) ? 8 : 4))) void ibf_count_max_phased_kernel(
+    IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
+    uint32_t out_read_stride)
+{
+    __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
+    if (read >= n_reads) return;  // wave-uniform; no block-level barriers below
+    const LaneCols<1> lc = make_lane_cols<LG, 1>(f, lane, col_begin, col_end, 0);
+    uint32_t len;
+    const BaseSrc seq = make_base_src(src, read, &len);
+    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
+    uint32_t best = 0;
+    if constexpr (LG == 0) {
+        // One-word blocks, reads of up to 256 k-mers (the reference's default 250 bp chunk): a 512-k-mer macro tile per
+        // strand would leave more than half of the 24 lookups a lane can keep in flight unused -- and the windows of the
+        // phased form live on lookups held in registers.  So both strands share one macro tile: tiles 0-3 are the
+        // forward k-mers, tiles 4-7 the k-mers of the reverse complement (separate counters, as in the reference).
+        if (n <= 256) {
+            uint8_t *stage = s_stage[wave];
+            for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);  // len <= 256 + k - 1 <= kStageBytes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t k = f.k;
+            uint32_t bn[8][3];
+            uint64_t x[8];
+            const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t p = (uint32_t)((j & 3) * 64 + lane);
+                const bool ok = (p < n) && lc.colok;
+                uint64_t v = 0;
+                if (ok) {
+                    const uint8_t *b = stage + p;
+                    if (j < 4) {
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
+                    } else {
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                    }
+                }
+                x[j] = ok ? lc.valid[0] : 0ULL;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                    bn[j][h] = ok ? blk * (f.stride * 8u) + col_bytes : 0xFFFFFFFFu;
+                }
+            }
+            const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
+            phased_gather8<3, false>(x, bn, f.words, slice_shift, ph);
+            // counts per bin and strand (at most 256 each: no counter planes needed), then the max over bins and strands
+            const uint32_t cf = wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
+            const uint32_t cr = wave_bin_counts4(x[4], x[5], x[6], x[7], lane);
+            uint32_t m = cf > cr ? cf : cr;  // bins beyond noOfBins count 0: the gathered words were masked with lc.valid
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const uint32_t o = shfl32(m, lane ^ sft);
+                m = o > m ? o : m;
+            }
+            if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)m;
+            return;
+        }
+    }
+    if constexpr (LG == 1) {
+        // Two-word blocks (65-128 bins), reads of up to 256 k-mers: the same both-strands tile with ONE lane per block and
+        // 16-byte gathers -- twice the lookups a wave holds per round of windows compared with two lanes per block, and
+        // a 20 MB table has to cross the fabric once per round whatever a wave asks of it.
+        if (n <= 256 && col_begin == 0 && col_end == 2 && f.stride == 2) {
+            uint8_t *stage = s_stage[wave];
+            for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t k = f.k;
+            const uint32_t rem = f.n_bins & 63u;
+            const uint64_t valid1 = rem ? ((1ULL << rem) - 1) : ~0ULL;
+            uint32_t bn[8][3];
+            uint64_t x0[8], x1[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t p = (uint32_t)((j & 3) * 64 + lane);
+                const bool ok = p < n;
+                uint64_t v = 0;
+                if (ok) {
+                    const uint8_t *b = stage + p;
+                    if (j < 4) {
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
+                    } else {
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                    }
+                }
+                x0[j] = ok ? ~0ULL : 0ULL;
+                x1[j] = ok ? valid1 : 0ULL;
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                    bn[j][h] = ok ? blk * 16u : 0xFFFFFFFFu;
+                }
+            }
+            const uint32_t slice_shift = min(31u, ph.shift + 4u);
+            phased_gather8x2<3>(x0, x1, bn, f.words, slice_shift, ph);
+            uint32_t m = wave_bin_counts4(x0[0], x0[1], x0[2], x0[3], lane);
+            uint32_t c = wave_bin_counts4(x1[0], x1[1], x1[2], x1[3], lane);
+            m = c > m ? c : m;
+            c = wave_bin_counts4(x0[4], x0[5], x0[6], x0[7], lane);
+            m = c > m ? c : m;
+            c = wave_bin_counts4(x1[4], x1[5], x1[6], x1[7], lane);
+            m = c > m ? c : m;
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const uint32_t o = shfl32(m, lane ^ sft);
+                m = o > m ? o : m;
+            }
+            if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)m;
+            return;
+        }
+    }
+    if constexpr (!SHORT) {
+        for (int strand = 0; strand < 2; ++strand) {
+            Planes<NP> pl[1];
+            pl[0].clear();
+            count_strand<LG, 1, NP, 3, false, true>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0,
+                                                    TileShape<LG>::STEPS / 8, s_stage[wave], lane, ph);
+            const uint32_t m = planes_max<NP, 1>(pl, lc.valid);
+            best = m > best ? m : best;
+        }
+    }
+    // SHORT: a read with more k-mers than promised writes 0 here; the decision kernel turns a length above the declared
+    // max_len into RB_ERR_INVALID_ARG, so the value is never used
+    if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)best;
 }
 
 // latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
@@ -1033,9 +1318,41 @@ static hipError_t dispatch_geometry(const CountLaunch &a, hipStream_t st)
     }
 }
 
+template <int LG, int NP>
+static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
+{
+    dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+    // both-strands-only build when every read of the batch fits it (LG 0/1, whole blocks owned by this rank)
+    if constexpr (LG <= 1 && NP == 10) {
+        if (a.short_only && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
+            hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, true>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, false>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+    return hipGetLastError();
+}
+
+template <int NP>
+static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
+{
+    switch (a.lg) {
+    case 0: return launch_phased<0, NP>(a, st);
+    case 1: return launch_phased<1, NP>(a, st);
+    case 2: return launch_phased<2, NP>(a, st);
+    default: return launch_phased<3, NP>(a, st);
+    }
+}
+
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
 {
     if (a.n_reads == 0) return hipSuccess;
+    if (a.phase.n_slices && a.split_waves < 2) {  // planned by the engine for: 3 hash functions, one slice, lg <= 3, wpl 1, n_fused 0
+        if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 3 || a.n_slices != 1 || a.n_fused > 0) return hipErrorInvalidValue;
+        return a.planes <= 10 ? dispatch_phased<10>(a, st) : dispatch_phased<16>(a, st);
+    }
     if (a.split_waves >= 2) {  // latency form (three hash functions only; the engine plans it for those)
         if (a.f.n_hash != 3) return hipErrorInvalidValue;
         return a.planes <= 10 ? launch_split<10>(a, st) : launch_split<16>(a, st);

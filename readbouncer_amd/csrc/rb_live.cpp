@@ -11,6 +11,7 @@
 // The action codes follow Data::sendActions (src/minknow/Data.cpp:169-187): unblock=true -> unblock_read,
 // unblock=false -> stop_receiving_data.
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -178,6 +179,56 @@ int rb_live_process(rb_live *lv, const char *ids, const uint64_t *id_offsets, co
         }
         todo.swap(later);
     }
+    return RB_OK;
+}
+
+// Work-conserving replay of an arrival process (BASELINE configs[4], the 48-flowcell scenario): chunk i -- read_len bytes
+// at seqs + i * read_len -- becomes available arrival_s[i] seconds after the start (ascending).  Whenever the engine is
+// free the dispatcher takes everything that has arrived, at most max_batch chunks, through ONE rb_classify_batch call
+// (host buffers in, decisions back on the host) and otherwise spins on the steady clock.  Per chunk: the decision and the
+// latency decision - arrival; per call: its size and its service time, so that queueing (waiting for the engine) and
+// service (the call itself) can be told apart.  This is the reference's classification thread (adaptive_sampling.hpp:
+// 214-356 pops one read at a time) with a queue drained in micro-batches; it lives in the library so that the
+// measurement does not carry an interpreter's loop in its percentiles.
+int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len, size_t n, const double *arrival_s, size_t max_batch,
+                       double error_rate, double significance, uint8_t *out_decision, double *out_latency_s,
+                       uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap, size_t *out_calls,
+                       double *out_elapsed_s)
+{
+    if (!e || !seqs || !arrival_s || !out_latency_s || read_len == 0) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (max_batch == 0) max_batch = 16384;
+    std::vector<uint64_t> offs(max_batch);
+    std::vector<uint32_t> lens(max_batch, read_len);
+    for (size_t i = 0; i < max_batch; ++i) offs[i] = (uint64_t)i * read_len;
+    std::vector<uint8_t> dec(max_batch), st(max_batch);
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto now_s = [&] { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    size_t done = 0, hi = 0, calls = 0;
+    while (done < n) {
+        const double now = now_s();
+        while (hi < n && arrival_s[hi] <= now) ++hi;
+        if (hi <= done) continue;  // spin until the next chunk arrives
+        const size_t m = std::min(hi - done, max_batch);
+        const double a = now_s();
+        const int rc = rb_classify_batch(e, seqs + done * (size_t)read_len, offs.data(), lens.data(), m, error_rate, significance,
+                                         RB_MODE_CHECK_UNBLOCK, nullptr, nullptr, dec.data(), st.data());
+        if (rc != RB_OK) return rc;
+        const double b = now_s();
+        for (size_t i = 0; i < m; ++i) {
+            out_latency_s[done + i] = b - arrival_s[done + i];
+            if (out_decision) out_decision[done + i] = dec[i];
+        }
+        if (calls < call_cap) {
+            if (out_call_reads) out_call_reads[calls] = (uint32_t)m;
+            if (out_call_service_s) out_call_service_s[calls] = b - a;
+        }
+        ++calls;
+        done += m;
+        hi = std::max(hi, done);
+    }
+    if (out_calls) *out_calls = calls;
+    if (out_elapsed_s) *out_elapsed_s = now_s();
     return RB_OK;
 }
 

@@ -58,6 +58,12 @@ def test_random_geometry(seed):
         mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
         assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, split)
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, split)
+    # throughput form with clock-phased gathers (forced; serves blocks of up to 8 words with three hash functions)
+    eng.set_phased(0, 1 << 40, int(rng.choice([0, 100, 1500])), int(rng.choice([1, 30])), 1)
+    mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
+    assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, "phased")
+    assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, "phased")
+    eng.set_phased(0, 0, 0, 0, 0)
     # latency form with several workgroups per read (wide filters), on the batch and on a few reads of it (more parts)
     eng.set_split_threshold(2048)
     eng.set_split_parts(int(rng.choice([2, 3, 8, 16])), int(rng.choice([1, 2, 4, 8])))

@@ -92,6 +92,15 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     eng.set_split_threshold(2048)
     assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], expect)
     eng.set_nt_threshold(512 << 20)
+    # throughput form with clock-phased gathers (planned for narrow filters of 6-32 MiB only; forced here for every
+    # geometry it can serve: blocks of up to 8 words): windows from far shorter to far longer than a wave needs
+    eng.set_split_threshold(0)
+    for base_ticks in (1, 300, 2000):
+        eng.set_phased(0, 1 << 40, base_ticks, 3, 1)
+        mc3, _, dec3, st3 = eng.classify(buf, offs, lens)
+        assert np.array_equal(mc3[:, 0], expect) and np.array_equal(dec3, decision) and np.array_equal(st3, status), base_ticks
+    eng.set_phased(6 << 20, 32 << 20, 350, 4, 32768)
+    eng.set_split_threshold(2048)
     # latency form with several workgroups per read (wide filters only; a no-op setting for the narrow ones):
     # workgroups per read x shares per 64-k-mer tile, twice each (the arrival counters must come back to zero)
     for parts, shares in ((1, 1), (2, 1), (8, 2), (8, 8), (3, 4), (16, 8), (8, 4)):
@@ -715,3 +724,34 @@ def test_classify_any_matches_oracle(nd, nt):
                 n_quirk += int(exp and best == -1)
         if r == 0.1:
             assert n_quirk >= 8  # reads that the bool overload accepts and the argmax overload does not
+
+
+def test_multi_workgroup_latency_kernel_back_to_back():
+    """The latency form on a wide filter spreads a read over several workgroups that meet through a workspace and an
+    arrival counter per (filter, read) which the last workgroup resets (rb_kernels.hip, split_body).  Thousands of
+    micro-batches back to back, at the largest number of parts and varying batch sizes, against the throughput form:
+    a counter left non-zero, a stale partial sum or a missed release would show as a wrong maximum."""
+    rng = np.random.default_rng(2024)
+    ref = H.random_dna(rng, 30000)
+    d = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * 4099)  # 128 word columns: 16-byte lanes, up to 8 parts
+    d.fill_synth(99)
+    d.add_sequence(ref, 100)
+    t = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 30011)     # a narrow target in the same launch
+    t.add_sequence(ref[:6000], 100)
+    reads = make_reads(rng, ref, 64, lo=300, hi=420, err=0.1)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [t])
+    eng.set_split_threshold(0)
+    exp_mc, _, exp_dec, exp_st = eng.classify(buf, offs, lens)  # throughput form
+    od, _k1 = oracle_view(d)
+    assert np.array_equal(exp_mc[:, 0], po.batch_raw_max(od, buf, offs, lens, 4))
+    eng.set_split_threshold(2048)
+    eng.set_split_parts(8, 4)
+    bad = 0
+    for it in range(3000):
+        n = (1, 2, 3, 7, 14, 25, 64)[it % 7]
+        lo = (it * 5) % (len(reads) - n + 1)
+        sub = np.ascontiguousarray(buf[int(offs[lo]): int(offs[lo + n - 1]) + int(lens[lo + n - 1])])
+        mc, _, dec, st = eng.classify(sub, offs[lo:lo + n] - offs[lo], lens[lo:lo + n])
+        bad += int(not (np.array_equal(mc, exp_mc[lo:lo + n]) and np.array_equal(dec, exp_dec[lo:lo + n])))
+    assert bad == 0
