@@ -483,11 +483,6 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
 static int replay_target(ConfigReader& config, std::vector<interleave::IBFMeta>& DepletionFilters,
                          std::vector<interleave::IBFMeta>& TargetFilters, size_t live_batch)
 {
-    if (config.IBF_Parsed.read_files.empty()) {
-        std::cerr << "usage \"target\": the live MinKNOW/basecaller connection is outside this engine's scope; list pre-basecalled "
-                     "chunk files under [IBF] read_files to replay them through the live classification step" << std::endl;
-        return 2;
-    }
     rb_engine* engine = interleave::detail::engine_for(DepletionFilters, TargetFilters);
     rb_live* live = nullptr;
     // Conf.significance = 0.95, Conf.error_rate = exp_seq_error_rate (adaptive_sampling.hpp:563-566); 1500 bp cut-off (:315)
@@ -583,6 +578,11 @@ static int run_program(ConfigReader& config, const IngestOptions& opt, const std
         return 0;
     }
     if (config.usage == "target") {  // main.cpp:365-378, with the chunk source replaced (see replay_target)
+        if (config.IBF_Parsed.read_files.empty()) {  // before any filter is loaded or built
+            std::cerr << "usage \"target\": the live MinKNOW/basecaller connection is outside this engine's scope; list pre-basecalled "
+                         "chunk files under [IBF] read_files to replay them through the live classification step" << std::endl;
+            return 2;
+        }
         std::vector<interleave::IBFMeta> DepletionFilters = getIBF(config, true, false);
         std::vector<interleave::IBFMeta> TargetFilters = getIBF(config, false, true);
         return replay_target(config, DepletionFilters, TargetFilters, opt.live_batch);

@@ -116,8 +116,12 @@ def test_defaults_and_errors(tmp_path):
     cfg.write_text('usage = "build"\noutput_directory = "%s"\n' % (tmp_path / "out"))
     p = run_cli("--config", str(cfg), check=False)
     assert p.returncode == 1 and "log_directory" in p.stderr
-    # unsupported usage is refused, not silently ignored
+    # usage "target" without chunk files would need the live MinKNOW connection: refused with a pointer to the replay
     write_config(cfg, "target", tmp_path / "out", deplete_files=[ref])
+    p = run_cli("--config", str(cfg), check=False)
+    assert p.returncode == 2 and "outside this engine's scope" in p.stderr and "read_files" in p.stderr
+    # unsupported usage is refused, not silently ignored
+    write_config(cfg, "test", tmp_path / "out", deplete_files=[ref])
     p = run_cli("--config", str(cfg), check=False)
     assert p.returncode == 2 and "outside this engine's scope" in p.stderr
     p = run_cli(check=False)
