@@ -122,6 +122,8 @@ def parse():
     ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
     ap.add_argument("--read-len", type=int, default=0, help="override the read length of the workload (e.g. 1500: 16 counter planes)")
     ap.add_argument("--phased", default="", help="tuning: 'off' or 'min_mib,max_mib,base_ticks,ticks_per_mib' for the clock-phased gathers of narrow filters")
+    ap.add_argument("--serial-table-mib", type=int, default=-1,
+                    help="tuning: filters up to this size take turns instead of overlapping (default: the engine's 64; 0 = round 1 behaviour)")
     ap.add_argument("--no-extras", action="store_true",
                     help="default c2 run on one GPU: do not append the short runs of configs 3, 4 and 5 (`other_configs`)")
     return ap.parse_args()
@@ -399,6 +401,8 @@ def main():
     eng = capi.Engine(dev_index, deplete, target)
     if args.no_overlap:
         eng.set_overlap(False)
+    if args.serial_table_mib >= 0:
+        eng.set_serial_table_bytes(args.serial_table_mib << 20)
     if args.phased == "off":
         eng.set_phased(0, 0, 0, 0, 0)
     elif args.phased:
@@ -481,6 +485,8 @@ def main():
     if rank == 0:
         avg_kernel_s = (kernel_ms / max(1, n_calls)) / 1e3
         achieved = bytes_per_read * n_reads / avg_kernel_s / 1e9
+        if bin_sharded:
+            achieved /= world  # every rank gathers its share of the word columns of every block
         # fabric-side traffic of one launch: NOT measured in this run -- rocprofv3 --pmc passes of an earlier run of the
         # same workload (profiles/collect_pmc.sh), kept in profiles/traffic.json and replayed here per read
         traffic, traffic_source = None, None
@@ -490,9 +496,16 @@ def main():
             traffic_source = "profiles/traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc, separate passes, round 1")
         ceil = load_json("ceilings.json").get(args.workload, {})
         decisions = t_dec.cpu().numpy()
+        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- to eight-word blocks with a
+        # table of 6-32 MiB (or one-word blocks of any size) take the phased kernel, everything else the plain one
+        def phased(f):
+            tb = f.info["n_blocks"] * f.device_stride() * 8
+            return f.info["bin_width"] <= 8 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= (32 << 20) or f.info["bin_width"] == 1)
+        forms = {("ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel") for f in filters}
+        kernel_name = " + ".join(sorted(forms))
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": "ibf_count_max_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_read": bytes_per_read,
                 "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
         if ceil.get("GBps"):

@@ -20,39 +20,44 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 if os.path.exists(os.path.join(src, "hbm_peak.txt")):
     shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
-for w in ("c2", "c3", "c4", "c5"):
+for w in ("c2", "c3", "c4", "c5", "readme", "c1"):
     hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
 
 
 def counter_means(path):
-    """{counter: (dispatches, value per step, kernel ms per step)} of the throughput count kernels.  A step launches one
-    count kernel per filter (different template instantiations): the per-step figure is the sum over the kernels of
-    their per-dispatch means."""
-    acc = {}
+    """{counter: (dispatches, value per step, kernel ms per step)} of the count kernels (every form of K1).  A step launches
+    one count kernel per filter -- different template instantiations, or the same one several times (the three one-word
+    targets of the README shape): the per-step figure is the sum over all dispatches divided by the number of steps, and
+    the number of steps is the smallest dispatch count of any kernel name."""
+    tot, per_kernel = {}, {}
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
-            if "ibf_count_max_kernel" not in r["Kernel_Name"]:
+            if "ibf_count_max" not in r["Kernel_Name"]:
                 continue
-            a = acc.setdefault((r["Counter_Name"], r["Kernel_Name"]), [0, 0.0, 0.0])
+            a = tot.setdefault(r["Counter_Name"], [0, 0.0, 0.0])
             a[0] += 1
             a[1] += float(r["Counter_Value"])
             a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            k = (r["Counter_Name"], r["Kernel_Name"])
+            per_kernel[k] = per_kernel.get(k, 0) + 1
     out = {}
-    for (name, _kernel), (n, v, ms) in acc.items():
-        o = out.setdefault(name, [0, 0.0, 0.0])
-        o[0] += n
-        o[1] += v / n
-        o[2] += ms / n
-    return {k: tuple(v) for k, v in out.items()}
+    for name, (n, v, ms) in tot.items():
+        steps = min(c for (cn, _k), c in per_kernel.items() if cn == name)
+        out[name] = (n, v / steps, ms / steps)
+    return out
 
 
 from readbouncer_amd import synth  # noqa: E402
 
 rows, traffic = [], {}
-FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"]}
-for w in ("c2", "c3", "c4", "grch38_f100k"):
+FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
+           "readme": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"], "c1_r01": ["c1"],
+           "readme_r01": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]}
+READ_LEN = {"readme": 250, "readme_r01": 250}
+when = os.environ.get("RB_EVIDENCE_DATE", "")
+for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):
         continue
@@ -68,7 +73,7 @@ for w in ("c2", "c3", "c4", "grch38_f100k"):
         continue
     reads = 500_000 if w == "grch38_f100k" else 1_000_000
     wls = [synth.WORKLOADS[k] for k in FILTERS[w]]
-    alg = synth.algorithmic_bytes_per_read(360, [(x["n_bins"], x["k"], x["h"]) for x in wls])
+    alg = synth.algorithmic_bytes_per_read(READ_LEN.get(w, 360), [(x["n_bins"], x["k"], x["h"]) for x in wls])
     hbm = m["FETCH_SIZE"] * 1024 * 2
     traffic[w] = {
         "reads_per_launch": reads,
@@ -82,6 +87,7 @@ for w in ("c2", "c3", "c4", "grch38_f100k"):
         "l2_hit_rate": m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) if "TCC_HIT_sum" in m else None,
         "valu_insts_per_read": m.get("SQ_INSTS_VALU", 0) / reads,
         "wait_any_frac_of_wave_cycles": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+        "source": "rocprofv3 --pmc, separate passes (profiles/collect_pmc.sh), %s, %s" % (os.path.basename(dst.rstrip("/")), when),
         "note": "separate rocprofv3 --pmc passes (profiles/collect_pmc.sh); FETCH_SIZE x1024 x2 per MI355X_MICROARCH.md "
                 "HBM section; cross-checked by TCC_EA0_RDREQ x 128 B",
     }

@@ -96,7 +96,10 @@ struct rb_engine {
     uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
     // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
     uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 32ull << 20;
-    uint32_t phase_base_ticks = 350, phase_ticks_per_mib = 4;  // window length in 10 ns ticks: base + per MiB of table
+    // window length in 10 ns ticks: base + per MiB of table (+ short_extra when the both-strands-only kernel runs: it keeps
+    // four to five waves per SIMD, and more waves want longer windows).  Measured optimum: 4-5 us for the general kernel on a
+    // 20 MB one-word filter (360 bp reads), 5.5-6 us for the short-read kernels on 10 and 20 MB filters; flat within +-1 us.
+    uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0, phase_short_extra_ticks = 125;
     uint32_t phase_min_reads = 32768;
     bool short_read_kernel = true;
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
@@ -659,9 +662,14 @@ int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_ta
     std::lock_guard<std::mutex> lock(e->mu);
     e->phase_min_bytes = min_table_bytes;
     e->phase_max_bytes = max_table_bytes;
-    if (base_ticks || ticks_per_mib) {
+    if (base_ticks || ticks_per_mib) {  // an explicit window length replaces the built-in rule
         e->phase_base_ticks = base_ticks;
         e->phase_ticks_per_mib = ticks_per_mib;
+        e->phase_short_extra_ticks = 0;
+    } else {
+        e->phase_base_ticks = 450;
+        e->phase_ticks_per_mib = 0;
+        e->phase_short_extra_ticks = 125;
     }
     e->phase_min_reads = min_reads;
     e->short_read_kernel = !(min_table_bytes == 0 && max_table_bytes == 0 && base_ticks == 0 && ticks_per_mib == 0 && min_reads == 0);
@@ -824,6 +832,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint32_t sh = 0;
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
             uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
+            if (a.short_only && a.lg <= 1 && a.planes <= 10) ticks += e->phase_short_extra_ticks;
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             a.phase.shift = sh;
             a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
