@@ -291,7 +291,7 @@ __device__ __forceinline__ void phased_gather8(uint64_t (&x)[8], const uint32_t 
 
 // The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's eight k-mers.
 // The twelve gathers of four k-mers go out together (48 registers of results in flight, like the 24 eight-byte ones).
-template <int H>
+template <int H, int KB = 4>
 __device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x1)[8], const uint32_t (&bn)[8][H],
                                                  const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
 {
@@ -305,15 +305,15 @@ __device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            rb_u64x2 ld[4][H];
+        for (int part = 0; part < 8 / KB; ++part) {
+            rb_u64x2 ld[KB][H];
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
+            for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     ld[uu][h].x = ~0ULL;
                     ld[uu][h].y = ~0ULL;
-                    uint32_t off = bn[half * 4 + uu][h];
+                    uint32_t off = bn[part * KB + uu][h];
                     asm volatile("" : "+v"(off));
                     if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
                         ld[uu][h] = *reinterpret_cast<const rb_u64x2 *>(reinterpret_cast<const char *>(words) + off);
@@ -321,11 +321,11 @@ __device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
+            for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    x0[half * 4 + uu] &= ld[uu][h].x;
-                    x1[half * 4 + uu] &= ld[uu][h].y;
+                    x0[part * KB + uu] &= ld[uu][h].x;
+                    x1[part * KB + uu] &= ld[uu][h].y;
                 }
             }
         }
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                 }
             }
             const uint32_t slice_shift = min(31u, ph.shift + 4u);
-            phased_gather8x2<3>(x0, x1, bn, f.words, slice_shift, ph);
+            phased_gather8x2<3, 4>(x0, x1, bn, f.words, slice_shift, ph);
             uint32_t m = wave_bin_counts4(x0[0], x0[1], x0[2], x0[3], lane);
             uint32_t c = wave_bin_counts4(x1[0], x1[1], x1[2], x1[3], lane);
             m = c > m ? c : m;
