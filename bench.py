@@ -67,6 +67,12 @@ def launch_ranks(n):
     never execs: it waits for the children and exits with the worst of their codes.  The reference's scaling model is N
     classification workers behind one queue (src/main/adaptive_sampling.hpp:745-751); here a worker is a GPU."""
     import subprocess
+    if os.environ.get("RB_BENCH_SAME_GPU") != "1" and os.environ.get("RB_BENCH_ENGINE") != "none":
+        import torch  # counting devices does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < n:
+            print("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have), file=sys.stderr)
+            sys.exit(2)
     port = _free_port()
     procs = []
     for r in range(n):

@@ -183,3 +183,26 @@ int main() {
                            "-o", str(exe)])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert int(out[0]) > 1_000_000 and int(out[1]) == 0
+
+
+def test_odd_metadata_loads_with_a_warning(tmp_path):
+    """A file whose metadata tail holds values the reference never writes still parses, but says so (rb_last_warning):
+    the order {noOfBins, noOfHashFunc, kmerSize, spare} is recalled from SeqAn, not read from the reference tree."""
+    from oracle import pyoracle as po
+    good = po.OracleIBF(70, 3, 13, 128 * 1009)
+    good.store(str(tmp_path / "good.ibf"))
+    odd = po.OracleIBF(70, 2, 13, 128 * 1009)
+    odd.store(str(tmp_path / "odd.ibf"))
+    h = capi.HostIBF.open(str(tmp_path / "good.ibf"))
+    assert capi.last_warning() == "" and h.info["n_hash"] == 3
+    h = capi.HostIBF.open(str(tmp_path / "odd.ibf"))
+    assert "noOfHashFunc = 2" in capi.last_warning() and h.info["n_hash"] == 2
+    assert capi.is_ibf_file(str(tmp_path / "odd.ibf"))
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RB_BENCH_SAME_GPU", "RB_BENCH_ENGINE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "GPU(s) visible" in p.stderr and p.stdout.strip() == ""
