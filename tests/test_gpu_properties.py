@@ -130,3 +130,60 @@ def test_c4_sample_against_oracle(c4):
     assert np.array_equal(base[2][idx], exp_dec) and np.array_equal(base[3][idx], exp_st)
     for f, o in enumerate(views):
         assert np.array_equal(base[0][idx, f], po.batch_raw_max(o, buf, offs[idx], lens[idx], 8))
+
+
+@pytest.fixture(scope="module")
+def narrow():
+    """the README benchmark shape (README.md:254-262): one two-word deplete filter (122 bins, 20 MB) and three one-word
+    target filters (43 / 29 / 49 bins, 10 MB each) at their real sizes -- the geometry the phased kernels are planned for"""
+    deplete, target, refs = [], [], []
+    for i, key in enumerate(("mock_deplete", "mock_t1", "mock_t2", "mock_t3")):
+        f, r = synth.build_device_filter(0, synth.WORKLOADS[key], fill_seed=11 + i, plant_seed=110 + i, n_segments=512)
+        (deplete if i == 0 else target).append(f)
+        refs.append(r)
+    ref = np.concatenate(refs)
+    eng = capi.Engine(0, deplete, target)
+    return deplete, target, ref, eng
+
+
+def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
+    """Plain gathers, clock-phased gathers at several window lengths, both-strands tiles (250 bp) and per-strand tiles
+    (360 bp, ragged lengths), filters overlapped or taking turns: the same maxima and decisions for 10^5 reads each;
+    strand symmetry on top; a sample against the oracle."""
+    deplete, target, ref, eng = narrow
+    rng = np.random.default_rng(8)
+    for read_len in (250, 360):
+        buf, offs, lens = synth.make_reads(90 + read_len, 100_000, read_len, ref)
+        eng.set_phased(0, 0, 0, 0, 0)           # plain kernels, one-word filters on the round-1 tiles
+        eng.set_serial_table_bytes(0)
+        base = eng.classify(buf, offs, lens)
+        assert len(set(base[2].tolist())) == 3
+        eng.set_serial_table_bytes(64 << 20)
+        for args in ((6 << 20, 32 << 20, 0, 0, 32768), (6 << 20, 32 << 20, 120, 0, 1024), (6 << 20, 32 << 20, 1500, 0, 1024),
+                     (0, 0, 450, 0, 1024)):     # the last one: short-read tiles without windows
+            eng.set_phased(*args)
+            got = eng.classify(buf, offs, lens)
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2]) and np.array_equal(got[1], base[1]), args
+        # ragged lengths around the 256-k-mer switch, in one batch (both paths of one launch)
+        eng.set_phased(6 << 20, 32 << 20, 0, 0, 1024)
+        m = 40_000
+        rl = rng.integers(200, 330, size=m).astype(np.uint32)
+        ro = (np.arange(m, dtype=np.uint64) * np.uint64(read_len))
+        rl = np.minimum(rl, read_len).astype(np.uint32)
+        g1 = eng.classify(buf, ro, rl)
+        eng.set_phased(0, 0, 0, 0, 0)
+        g0 = eng.classify(buf, ro, rl)
+        assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[2], g0[2])
+        eng.set_phased(6 << 20, 32 << 20, 0, 0, 32768)
+        # strand symmetry through the phased kernels
+        comp = np.zeros(256, dtype=np.uint8)
+        comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
+        rc = comp[buf.reshape(-1, read_len)[:, ::-1]].reshape(-1).copy()
+        got = eng.classify(rc, offs, lens)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2])
+        # oracle sample
+        keep = [f.download() for f in deplete + target]
+        views = [po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()) for h in keep]
+        n = 3000
+        exp_dec, exp_st = po.batch_check_unblock(views[:1], views[1:], buf, offs[:n], lens[:n], n_threads=8)
+        assert np.array_equal(base[2][:n], exp_dec) and np.array_equal(base[3][:n], exp_st)
