@@ -151,6 +151,40 @@ __global__ __launch_bounds__(256) void gather_phased(const uint64_t *__restrict_
     if (acc == 0x123456789ULL) out[0] = acc;
 }
 
+// "phased dense": what the phased scheme would deliver if the lookups of a window were COMPACTED -- the same 24 lookups
+// per lane and round, but as NBUF/S full-width load instructions per window instead of NBUF predicated ones with 1/S of
+// the lanes active each (is the texture-address path, one vector-memory instruction per ~25 cycles and CU, the limit?)
+template <int S, int NBUF>
+__global__ __launch_bounds__(256) void gather_phased_dense(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                           uint32_t dt, uint64_t *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_slice = (n_elems + S - 1) / S;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint64_t w0 = wall_clock64() / dt;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)S; ++q) {
+            const uint64_t w = w0 + q;
+            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            const uint32_t p = (uint32_t)(w % S);
+            uint64_t v[NBUF / S];
+#pragma unroll
+            for (int u = 0; u < NBUF / S; ++u) {
+                s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+                uint32_t idx = p * per_slice + (uint32_t)(((s >> 32) * (uint64_t)per_slice) >> 32);
+                idx = idx < n_elems ? idx : n_elems - 1;
+                v[u] = table[idx];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NBUF / S; ++u) acc += v[u];
+        }
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
 static void *alloc_kind(size_t bytes, int kind);
 static void one(const char *mode, int mib, int esz, int policy, int kind, uint64_t *out);
 
@@ -179,6 +213,35 @@ static void run_phased(int mib, uint32_t dt, uint64_t *out)
     const double gathers = (double)blocks * 256 * iters * NBUF;
     printf("phased table %4d MiB  S=%2d  %2d lookups buffered per lane  prefetch %d  window %5.2f us : %7.1f G gathers/s\n", mib, S,
            NBUF, PF, dt / 100.0, gathers / best / 1e6);
+    fflush(stdout);
+    (void)hipFree(t);
+}
+
+template <int S, int NBUF>
+static void run_phased_dense(int mib, uint32_t dt, uint64_t *out)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+    if (!t) return;
+    const uint32_t n = (uint32_t)(bytes / 8);
+    const uint32_t iters = 16 * 24 / NBUF;
+    const int blocks = 256 * 64;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather_phased_dense<S, NBUF>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * NBUF;
+    printf("phased DENSE table %4d MiB  S=%2d  %2d lookups per lane and round (%d full-width loads per window)  window %5.2f us : %7.1f G gathers/s\n",
+           mib, S, NBUF, NBUF / S, dt / 100.0, gathers / best / 1e6);
     fflush(stdout);
     (void)hipFree(t);
 }
@@ -289,6 +352,13 @@ int main(int argc, char **argv)
         }
         for (uint32_t dt : {200u, 400u}) run_phased<4, 24>(10, dt, out);
         for (uint32_t dt : {400u, 800u}) run_phased<16, 48>(40, dt, out);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_dense")) {
+        for (int mib : {10, 20}) {
+            for (uint32_t dt : {50u, 100u, 150u, 200u, 300u, 450u, 600u}) run_phased_dense<8, 24>(mib, dt, out);
+            for (uint32_t dt : {100u, 200u, 300u, 450u}) run_phased_dense<8, 48>(mib, dt, out);
+        }
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "phased_pf")) {
