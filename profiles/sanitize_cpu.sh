@@ -26,4 +26,9 @@ PY
 (cd $R/readbouncer_amd/host && g++ -O1 -g -std=c++17 -fsanitize=thread rb_main.cpp -o $T/cli_tsan -L.. -lreadbouncer_amd \
     -Wl,-rpath,$R/readbouncer_amd -lpthread)
 TSAN_OPTIONS="halt_on_error=1" $T/cli_tsan --ingest-threads 4 --segment-bytes 250000 --parse-stats $T/tsan.fq
+# the ingest's failure paths (refused / throwing page-locked allocator) under ASan+UBSan and under TSan
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer $R/tests/cpp/test_seqio.cpp -o $T/seqio_asan -lpthread
+$T/seqio_asan
+g++ -O1 -g -std=c++17 -fsanitize=thread $R/tests/cpp/test_seqio.cpp -o $T/seqio_tsan -lpthread
+TSAN_OPTIONS="halt_on_error=1" $T/seqio_tsan
 echo "sanitizers: clean"
