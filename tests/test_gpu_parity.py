@@ -343,6 +343,25 @@ def test_device_pointer_api_and_column_shards():
         torch.cuda.synchronize()
         assert np.array_equal(t_dec2.cpu().numpy(), exp_dec)
     eng.set_column_shard(0, 1)
+    # the same with a narrow filter (5 word columns) through the phased throughput kernel: every rank gathers its columns
+    d5 = capi.DeviceIBF.create(0, 300, 3, 13, 320 * 30011)
+    d5.add_sequence(ref, 100)
+    o5, _k5 = oracle_view(d5)
+    exp5 = po.batch_raw_max(o5, buf, offs, lens, 4)
+    eng5 = capi.Engine(0, [d5], [])
+    eng5.set_split_threshold(0)
+    eng5.set_phased(0, 1 << 40, 200, 0, 1)
+    for world in (1, 2, 3):
+        acc = np.zeros(n, dtype=np.uint16)
+        for rank in range(world):
+            eng5.set_column_shard(rank, world)
+            t_part = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+            torch.cuda.synchronize()
+            eng5.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, int(lens.max()),
+                                 d_maxcount=t_part.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            acc = np.maximum(acc, t_part.cpu().numpy().view(np.uint16)[:, 0])
+        assert np.array_equal(acc, exp5), world
 
 
 def test_empty_batch_and_null_filters():
@@ -562,9 +581,12 @@ def test_resize_bins_and_update(old_bins, new_bins):
         d2.resize_bins(new_bins - 1)
 
 
-def test_packed_reads_and_on_gpu_chunking():
+@pytest.mark.parametrize("form", ["latency", "throughput", "phased"])
+def test_packed_reads_and_on_gpu_chunking(form):
     """2-bit + N-bitmap reads and chunk selection on the device (classify.hpp:262-271) give exactly what the
-    ASCII path gives on the sliced strings; read-id indirection covers the 'still unclassified' subset of a chunk loop."""
+    ASCII path gives on the sliced strings; read-id indirection covers the 'still unclassified' subset of a chunk loop.
+    Through every form of K1: the latency kernels (micro-batch), the plain throughput kernels, and the phased kernels with
+    their both-strands tiles (forced: the filters here are far smaller than the ones they are planned for)."""
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(19)
     ref = H.random_dna(rng, 30000)
@@ -579,6 +601,12 @@ def test_packed_reads_and_on_gpu_chunking():
     buf, offs, lens = H.pack_reads(reads)
     n = len(reads)
     eng = capi.Engine(0, [dep], [tgt])
+    if form != "latency":
+        eng.set_split_threshold(0)
+        if form == "phased":
+            eng.set_phased(0, 1 << 40, 200, 0, 1)
+        else:
+            eng.set_phased(0, 0, 0, 0, 0)
     packed, p_off, nmask, n_off = capi.pack_reads(buf, offs, lens)
     assert len(packed) < len(buf) // 3 + n  # ~4x smaller payload
     dev = torch.device("cuda:0")
