@@ -824,7 +824,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
         a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
     a.phase = PhaseCfg{0, 0, 0};
-    a.short_only = kmers <= 256;
+    a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
     if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
@@ -832,7 +832,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint32_t sh = 0;
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
             uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
-            if (a.short_only && a.lg <= 1 && a.planes <= 10) ticks += e->phase_short_extra_ticks;
+            if (a.planes <= 10 && a.short_only && a.lg <= 1) ticks += e->phase_short_extra_ticks;
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             a.phase.shift = sh;
             a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);

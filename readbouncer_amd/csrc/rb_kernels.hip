@@ -566,10 +566,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 }
 
 // throughput form with clock-phased gathers (see count_strand): narrow filters of a few L2 sizes, one column slice
-// (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with.  SHORT = the engine
-// knows that no read of the batch has more than 256 k-mers: only the both-strands path is compiled in, which fits four
-// waves per SIMD.)
-template <int LG, int NP, bool SHORT>
+// (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with.  SHORT != 0: the engine
+// knows that no read of the batch has more than 256 (SHORT 1) or 512 (SHORT 2, one-word blocks) k-mers: only the
+// both-strands path is compiled in, which fits five resp. four waves per SIMD for one-word blocks.  The two-round build
+// for two-word blocks needs 177 registers; held to three waves per SIMD it spills eight of them, outside the window loop.)
+template <int LG, int NP, int SHORT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, (SHORT && LG == 0) ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride)
@@ -585,22 +586,31 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     uint32_t best = 0;
     if constexpr (LG == 0) {
-        // One-word blocks, reads of up to 256 k-mers (the reference's default 250 bp chunk): a 512-k-mer macro tile per
-        // strand would leave more than half of the 24 lookups a lane can keep in flight unused -- and the windows of the
-        // phased form live on lookups held in registers.  So both strands share one macro tile: tiles 0-3 are the
-        // forward k-mers, tiles 4-7 the k-mers of the reverse complement (separate counters, as in the reference).
-        if (n <= 256) {
+        // One-word blocks, reads of up to 512 k-mers: a 512-k-mer macro tile per strand would leave more than half of the 24
+        // lookups a lane can keep in flight unused on the reference's default 250 bp chunk (238 k-mers) -- and the windows
+        // of the phased form live on lookups held in registers.  So both strands share a macro tile: tiles 0-3 are 256
+        // forward k-mers, tiles 4-7 the k-mers of the reverse complement over the same windows (separate counts, as in
+        // the reference).
+        // (SHORT 1 keeps the single round free of loop state: 93 VGPRs, five waves per SIMD; with the loop 114 and four.)
+        constexpr uint32_t kBothMax = SHORT == 1 ? 256u : 512u;  // the general build takes two rounds as well: 360 bp reads
+        if (n <= kBothMax) {  // len <= 512 + k - 1 <= kStageBytes: the whole read is staged once
             uint8_t *stage = s_stage[wave];
-            for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);  // len <= 256 + k - 1 <= kStageBytes
+            for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
+            const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
+            const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
+            uint32_t cf = 0, cr = 0;  // lane b: count of bin b, forward / reverse complement
+            // rounds of 256 k-mers per strand (one for the 250 bp chunk, two for 360 bp): the counts of a round are summed
+            // across the wave at once, so no counter planes are carried
+#pragma unroll 1
+            for (uint32_t base = 0; base < (SHORT == 1 ? 1u : n); base += 256) {
             uint32_t bn[8][3];
             uint64_t x[8];
-            const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t p = (uint32_t)((j & 3) * 64 + lane);
+                const uint32_t p = base + (uint32_t)((j & 3) * 64 + lane);
                 const bool ok = (p < n) && lc.colok;
                 uint64_t v = 0;
                 if (ok) {
@@ -611,18 +621,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
                     }
                 }
-                x[j] = ok ? lc.valid[0] : 0ULL;
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
                     bn[j][h] = ok ? blk * (f.stride * 8u) + col_bytes : 0xFFFFFFFFu;
                 }
             }
-            const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = bn[j][0] != 0xFFFFFFFFu ? lc.valid[0] : 0ULL;  // after the hashing: 16 registers less there
             phased_gather8<3, false>(x, bn, f.words, slice_shift, ph);
-            // counts per bin and strand (at most 256 each: no counter planes needed), then the max over bins and strands
-            const uint32_t cf = wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
-            const uint32_t cr = wave_bin_counts4(x[4], x[5], x[6], x[7], lane);
+            cf += wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
+            cr += wave_bin_counts4(x[4], x[5], x[6], x[7], lane);
+            }
             uint32_t m = cf > cr ? cf : cr;  // bins beyond noOfBins count 0: the gathered words were masked with lc.valid
 #pragma unroll
             for (int sft = 1; sft < 64; sft <<= 1) {
@@ -634,10 +644,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         }
     }
     if constexpr (LG == 1) {
-        // Two-word blocks (65-128 bins), reads of up to 256 k-mers: the same both-strands tile with ONE lane per block and
+        // Two-word blocks (65-128 bins), reads of up to 512 k-mers: the same both-strands tile with ONE lane per block and
         // 16-byte gathers -- twice the lookups a wave holds per round of windows compared with two lanes per block, and
         // a 20 MB table has to cross the fabric once per round whatever a wave asks of it.
-        if (n <= 256 && col_begin == 0 && col_end == 2 && f.stride == 2) {
+        // (two rounds only in the build that has nothing else in it: next to the per-strand path the loop state spills)
+        constexpr uint32_t kBothMax = SHORT == 2 ? 512u : 256u;
+        if (n <= kBothMax && col_begin == 0 && col_end == 2 && f.stride == 2) {
             uint8_t *stage = s_stage[wave];
             for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -645,11 +657,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             const uint32_t k = f.k;
             const uint32_t rem = f.n_bins & 63u;
             const uint64_t valid1 = rem ? ((1ULL << rem) - 1) : ~0ULL;
+            const uint32_t slice_shift = min(31u, ph.shift + 4u);
+            uint32_t cf = 0, cr = 0;  // lane b: counts of bins b (low half) and 64 + b (high half), forward / reverse complement
+#pragma unroll 1
+            for (uint32_t base = 0; base < (SHORT == 2 ? n : 1u); base += 256) {
             uint32_t bn[8][3];
             uint64_t x0[8], x1[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const uint32_t p = (uint32_t)((j & 3) * 64 + lane);
+                const uint32_t p = base + (uint32_t)((j & 3) * 64 + lane);
                 const bool ok = p < n;
                 uint64_t v = 0;
                 if (ok) {
@@ -660,23 +676,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
                     }
                 }
-                x0[j] = ok ? ~0ULL : 0ULL;
-                x1[j] = ok ? valid1 : 0ULL;
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
                     bn[j][h] = ok ? blk * 16u : 0xFFFFFFFFu;
                 }
             }
-            const uint32_t slice_shift = min(31u, ph.shift + 4u);
-            phased_gather8x2<3, 4>(x0, x1, bn, f.words, slice_shift, ph);
-            uint32_t m = wave_bin_counts4(x0[0], x0[1], x0[2], x0[3], lane);
-            uint32_t c = wave_bin_counts4(x1[0], x1[1], x1[2], x1[3], lane);
-            m = c > m ? c : m;
-            c = wave_bin_counts4(x0[4], x0[5], x0[6], x0[7], lane);
-            m = c > m ? c : m;
-            c = wave_bin_counts4(x1[4], x1[5], x1[6], x1[7], lane);
-            m = c > m ? c : m;
+            // the AND accumulators start as "every existing bin" for the k-mers that exist (set up after the hashing: 32
+            // registers less while the hash chains are in flight)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = bn[j][0] != 0xFFFFFFFFu;
+                x0[j] = ok ? ~0ULL : 0ULL;
+                x1[j] = ok ? valid1 : 0ULL;
+            }
+            // (the two-round build sends two k-mers' gathers at a time: with four the loop state does not fit three waves per SIMD)
+            phased_gather8x2<3, SHORT == 2 ? 2 : 4>(x0, x1, bn, f.words, slice_shift, ph);
+            cf += wave_bin_counts4(x0[0], x0[1], x0[2], x0[3], lane) | (wave_bin_counts4(x1[0], x1[1], x1[2], x1[3], lane) << 16);
+            cr += wave_bin_counts4(x0[4], x0[5], x0[6], x0[7], lane) | (wave_bin_counts4(x1[4], x1[5], x1[6], x1[7], lane) << 16);
+            }
+            uint32_t m = max(max(cf & 0xFFFFu, cf >> 16), max(cr & 0xFFFFu, cr >> 16));  // at most 512 each: no carry between halves
 #pragma unroll
             for (int sft = 1; sft < 64; sft <<= 1) {
                 const uint32_t o = shfl32(m, lane ^ sft);
@@ -696,7 +715,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             best = m > best ? m : best;
         }
     }
-    // SHORT: a read with more k-mers than promised writes 0 here; the decision kernel turns a length above the declared
+    // SHORT: a read with more k-mers than promised (256 / 512) writes 0 here; the decision kernel turns a length above the declared
     // max_len into RB_ERR_INVALID_ARG, so the value is never used
     if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)best;
 }
@@ -1324,13 +1343,20 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
     dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
     // both-strands-only build when every read of the batch fits it (LG 0/1, whole blocks owned by this rank)
     if constexpr (LG <= 1 && NP == 10) {
-        if (a.short_only && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
-            hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, true>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+        if (a.short_only == 1 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
+            hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 1>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, false>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+    if constexpr (LG <= 1 && NP == 10) {
+        if (a.short_only == 2 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
+            hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 0>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                        a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
     return hipGetLastError();
 }
