@@ -347,7 +347,7 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
  * costs a 128-byte request.  Two measures, both leave the results untouched:
  *  - filters of at most `table_bytes` (default 64 MiB) never run beside another filter of the same call, so each has the
  *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
- *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads reads the
+ *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads (4096) reads the
  *    throughput kernel gathers in clock-phased slices: the table is cut into <= 8 slices and the 100 MHz wall clock tells
  *    every wave which slice to gather from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns (both 0 =
  *    the built-in rule, 4.5-5.8 us), so an XCD's L2 holds one slice at a time (rb_engine_set_phased; max_table_bytes = 0 switches it off; all five arguments 0

@@ -100,7 +100,7 @@ struct rb_engine {
     // four to five waves per SIMD, and more waves want longer windows).  Measured optimum: 4-5 us for the general kernel on a
     // 20 MB one-word filter (360 bp reads), 5.5-6 us for the short-read kernels on 10 and 20 MB filters; flat within +-1 us.
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0, phase_short_extra_ticks = 125;
-    uint32_t phase_min_reads = 32768;
+    uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile

@@ -99,7 +99,7 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
         eng.set_phased(0, 1 << 40, base_ticks, 3, 1)
         mc3, _, dec3, st3 = eng.classify(buf, offs, lens)
         assert np.array_equal(mc3[:, 0], expect) and np.array_equal(dec3, decision) and np.array_equal(st3, status), base_ticks
-    eng.set_phased(6 << 20, 32 << 20, 0, 0, 32768)  # the built-in window rule
+    eng.set_phased(6 << 20, 32 << 20, 0, 0, 4096)  # the built-in window rule
     eng.set_split_threshold(2048)
     # latency form with several workgroups per read (wide filters only; a no-op setting for the narrow ones):
     # workgroups per read x shares per 64-k-mer tile, twice each (the arrival counters must come back to zero)

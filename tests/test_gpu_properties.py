@@ -159,7 +159,7 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         base = eng.classify(buf, offs, lens)
         assert len(set(base[2].tolist())) == 3
         eng.set_serial_table_bytes(64 << 20)
-        for args in ((6 << 20, 32 << 20, 0, 0, 32768), (6 << 20, 32 << 20, 120, 0, 1024), (6 << 20, 32 << 20, 1500, 0, 1024),
+        for args in ((6 << 20, 32 << 20, 0, 0, 4096), (6 << 20, 32 << 20, 120, 0, 1024), (6 << 20, 32 << 20, 1500, 0, 1024),
                      (0, 0, 450, 0, 1024)):     # the last one: short-read tiles without windows
             eng.set_phased(*args)
             got = eng.classify(buf, offs, lens)
@@ -174,7 +174,7 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         eng.set_phased(0, 0, 0, 0, 0)
         g0 = eng.classify(buf, ro, rl)
         assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[2], g0[2])
-        eng.set_phased(6 << 20, 32 << 20, 0, 0, 32768)
+        eng.set_phased(6 << 20, 32 << 20, 0, 0, 4096)
         # strand symmetry through the phased kernels
         comp = np.zeros(256, dtype=np.uint8)
         comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
