@@ -389,6 +389,8 @@ def main():
         if args.workload in ("c3", "c3np2") and not args.reads:
             n_reads = 2_000_000  # per step; BASELINE's 10 M reads are five such steps (3.6 GB of read bytes per 10 M)
         read_len = w["read_len"]
+        if n_reads != w["reads"]:
+            wname += " [%d reads per step]" % n_reads
     if args.read_len:
         read_len = args.read_len
     filters = deplete + target
