@@ -336,7 +336,13 @@ def main():
     same_gpu = os.environ.get("RB_BENCH_SAME_GPU") == "1"
     no_engine = os.environ.get("RB_BENCH_ENGINE") == "none"
     dev_index = 0 if (same_gpu or world == 1) else local_rank
-    if world > 1:
+    # RB_BENCH_FORCE_GROUP=1 (tests): a process group of ONE rank, so that the RCCL code paths of this script -- barrier,
+    # reductions, the bin-sharded all-gather on the engine's stream -- run on a one-GPU box
+    force_group = world == 1 and os.environ.get("RB_BENCH_FORCE_GROUP") == "1"
+    if force_group:
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    if world > 1 or force_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -421,7 +427,7 @@ def main():
     stream = side.cuda_stream
     max_len = int(lens.max())
 
-    bin_sharded = args.bin_sharded and world > 1
+    bin_sharded = args.bin_sharded and (world > 1 or force_group)
     if bin_sharded:
         # every rank classifies the SAME reads (seed of rank 0) against its column slice of every filter
         t_seq, t_off, t_len = synth.make_reads_device(1000, n_reads, read_len, ref, dev)
@@ -555,7 +561,7 @@ def main():
     if rank == 0:
         cap = min(n_reads, 1 << 21)  # host copy of the head of the batch: CPU baseline, parity, latency legs
         buf = t_seq[: cap * read_len].cpu().numpy()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not force_group and not args.no_cpu_baseline:
         from oracle import pyoracle as po
         keep = []
         views = []
@@ -626,7 +632,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and args.workload == "c2" and not args.reads and not args.read_len and not args.no_extras:
+    if rank == 0 and world == 1 and not force_group and args.workload == "c2" and not args.reads and not args.read_len and not args.no_extras:
         # free this process's filters and reads first: the children need the HBM (config 3 alone is 8 GiB + reads)
         del eng, t_seq, t_off, t_len, t_max, t_best, t_dec, t_st
         for f in filters:

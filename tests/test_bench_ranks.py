@@ -90,3 +90,18 @@ def test_gpus2_real_engine_decisions_equal_one_rank():
     assert d3["n_gpus"] == 2 and d3["scaling"] == "strong"
     # every rank counts its word columns of every block; all-gather + max in the decision kernel == the unsharded run
     assert d3["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
+
+
+@pytest.mark.gpu
+def test_rccl_code_paths_with_a_group_of_one():
+    """RCCL refuses two ranks on one GPU, so the box cannot run `--gpus 2` over RCCL; a process group of ONE rank still
+    drives every RCCL call of bench.py (init with device_id, barrier, max-reduce, gathers, the bin-sharded all-gather of
+    u16 maxima enqueued on the engine's stream + the decision over gathered parts) on real hardware."""
+    p1, d1 = _run(["--gpus", "1"] + SMALL, {"RB_BENCH_DUMP_DECISIONS": "1"}, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    for extra in ([], ["--bin-sharded"]):
+        p, d = _run(["--gpus", "1"] + extra + SMALL, {"RB_BENCH_DUMP_DECISIONS": "1", "RB_BENCH_FORCE_GROUP": "1"}, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert d["ranks"]["backend"] == "nccl" and d["n_gpus"] == 1
+        assert d["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
+        assert d["scaling"] == ("strong" if extra else "weak")
