@@ -114,12 +114,15 @@ struct rb_engine {
         void *d = nullptr;       // device copy
         PinnedBuf host;          // page-locked host copy (source of the asynchronous upload; rows are appended on growth)
         uint32_t len = 0;        // rows
+        size_t bytes = 0;        // size of each copy
         double r = -1.0, conf = -1.0;
         uint64_t last_use = 0;
     };
     ThrTable thr[2];
     uint64_t thr_clock = 0;
-    std::vector<std::pair<void *, size_t>> thr_retired;
+    // replaced copies, device and host: a queued kernel may still read the device block, a queued upload the host block
+    std::vector<void *> thr_retired_dev;
+    std::vector<PinnedBuf> thr_retired_host;
     size_t thr_retired_bytes = 0;
     // workspaces
     DevBuf d_maxcount;
@@ -604,7 +607,8 @@ void rb_engine_destroy(rb_engine *e)
         if (t.d) (void)hipFree(t.d);
         t.host.release();
     }
-    for (auto &r : e->thr_retired) (void)hipFree(r.first);
+    for (void *r : e->thr_retired_dev) (void)hipFree(r);
+    for (PinnedBuf &h : e->thr_retired_host) h.release();
     for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_efflens, &e->d_prestatus, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
@@ -758,13 +762,14 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     while (cap < need) cap <<= 1;
     const size_t nf = e->filters.size();
     const size_t row = nf * 2;
-    // grow the host copy in place (rows [0, t->len) stay valid), then compute the new rows only
+    // a new, longer host copy (rows [0, t->len) carried over), then only the new rows are computed.  The copies it replaces
+    // are parked, not freed: an upload from the old host block or a kernel reading the old device block may still be queued.
     {
         PinnedBuf bigger;
         int rc = bigger.ensure((size_t)cap * row * 2);
         if (rc != RB_OK) return rc;
         if (t->len) std::memcpy(bigger.p, t->host.p, (size_t)t->len * row * 2);
-        t->host.release();
+        if (t->host.p) e->thr_retired_host.push_back(t->host);
         t->host = bigger;
     }
     uint16_t *tab = (uint16_t *)t->host.p;
@@ -776,17 +781,20 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
             tab[((size_t)len * nf + fi) * 2 + 1] = threshold_u16(len, k, r2, conf);
         }
     }
-    if (t->d) {  // may still be read by kernels in flight
-        e->thr_retired.emplace_back(t->d, (size_t)t->len * row * 2);
-        e->thr_retired_bytes += (size_t)t->len * row * 2;
+    if (t->d) {
+        e->thr_retired_dev.push_back(t->d);
         t->d = nullptr;
-        if (e->thr_retired_bytes > ((size_t)64 << 20)) {
-            RB_HIP(hipDeviceSynchronize());
-            for (auto &x : e->thr_retired) (void)hipFree(x.first);
-            e->thr_retired.clear();
-            e->thr_retired_bytes = 0;
-        }
     }
+    e->thr_retired_bytes += 2 * t->bytes;
+    if (e->thr_retired_bytes > ((size_t)64 << 20)) {
+        RB_HIP(hipDeviceSynchronize());
+        for (void *x : e->thr_retired_dev) (void)hipFree(x);
+        for (PinnedBuf &h : e->thr_retired_host) h.release();
+        e->thr_retired_dev.clear();
+        e->thr_retired_host.clear();
+        e->thr_retired_bytes = 0;
+    }
+    t->bytes = (size_t)cap * row * 2;
     RB_HIP(hipMalloc(&t->d, (size_t)cap * row * 2));
     RB_HIP(hipMemcpyAsync(t->d, tab, (size_t)cap * row * 2, hipMemcpyHostToDevice, st));
     t->len = cap;

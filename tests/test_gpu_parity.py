@@ -783,3 +783,27 @@ def test_multi_workgroup_latency_kernel_back_to_back():
         mc, _, dec, st = eng.classify(sub, offs[lo:lo + n] - offs[lo], lens[lo:lo + n])
         bad += int(not (np.array_equal(mc, exp_mc[lo:lo + n]) and np.array_equal(dec, exp_dec[lo:lo + n])))
     assert bad == 0
+
+
+def test_threshold_tables_survive_eviction_and_growth():
+    """The engine keeps the threshold tables of the two most recent (error rate, significance) pairs resident, appends rows
+    when a longer read shows up and parks replaced copies while queued work may still read them.  Three error rates in
+    rotation (every call evicts), lengths growing across calls, all back to back on one engine: decisions stay the
+    oracle's."""
+    rng = np.random.default_rng(77)
+    ref = H.random_dna(rng, 20000)
+    d = capi.DeviceIBF.create(0, 200, 3, 13, 256 * 40009)
+    d.add_sequence(ref, 1000)
+    o, _k = oracle_view(d)
+    eng = capi.Engine(0, [d], [])
+    rates = (0.1, 0.05, 0.15)
+    for it in range(36):
+        top = 300 + 150 * it  # 300 .. 5550: crosses the 1024-, 2048- and 4096-row table sizes
+        reads = [H.mutate(rng, ref[s:s + L], 0.1) for s, L in zip(rng.integers(0, 12000, size=24), rng.integers(20, top, size=24))]
+        buf, offs, lens = H.pack_reads(reads)
+        r = rates[it % 3]
+        _, _, dec, st = eng.classify(buf, offs, lens, error_rate=r)
+        exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, r=r, n_threads=4)
+        assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (it, r, top)
+    with pytest.raises(capi.RBError):  # NormalCDFInverse would throw (IBF.hpp:284-308)
+        eng.classify(buf, offs, lens, significance=1.5)
