@@ -100,6 +100,7 @@ struct rb_engine {
     // four to five waves per SIMD, and more waves want longer windows).  Measured optimum: 4-5 us for the general kernel on a
     // 20 MB one-word filter (360 bp reads), 5.5-6 us for the short-read kernels on 10 and 20 MB filters; flat within +-1 us.
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0, phase_short_extra_ticks = 125;
+    uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
     uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
@@ -573,6 +574,11 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     }
     e->nd = (uint32_t)n_deplete;
     e->nt = (uint32_t)n_target;
+    {
+        int khz = 0;
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) e->wall_clock_khz = (uint32_t)khz;
+        else (void)hipGetLastError();
+    }
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->d_parts.resize(e->filters.size());
     const size_t n_aux = std::min<size_t>(3, e->filters.size() - 1);
@@ -842,6 +848,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
             if (a.planes <= 10 && a.short_only && a.lg <= 1) ticks += e->phase_short_extra_ticks;
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
+            ticks = std::max<uint64_t>(1, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock
             a.phase.shift = sh;
             a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
