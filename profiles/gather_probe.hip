@@ -185,6 +185,99 @@ __global__ __launch_bounds__(256) void gather_phased_dense(const uint64_t *__res
     if (acc == 0x123456789ULL) out[0] = acc;
 }
 
+// "phased sorted": the compaction done for real -- per round every wave counting-sorts its 24 x 64 lookups by slice into
+// LDS (block number + owner slot in 32 bits), then each window is ceil(count / 64) full-width loads whose results are
+// ANDed into the owners' words with ds_and_b64; the words come back to the owners' registers at the end of the round.
+template <int S>
+__global__ __launch_bounds__(256) void gather_phased_sorted(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                            uint32_t dt, uint64_t *out)
+{
+    constexpr int NBUF = 24;
+    __shared__ uint32_t s_ent[4][NBUF * 64];
+    __shared__ uint64_t s_acc[4][8 * 64];
+    __shared__ uint32_t s_cnt[4][S + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_slice = (n_elems + S - 1) / S;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    uint32_t *ent = s_ent[wave];
+    uint64_t *wacc = s_acc[wave];
+    uint32_t *cnt = s_cnt[wave];
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t idx[NBUF];
+        uint32_t mycnt[S];
+#pragma unroll
+        for (int p = 0; p < S; ++p) mycnt[p] = 0;
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            idx[u] = (uint32_t)(((s >> 32) * (uint64_t)n_elems) >> 32);
+            const uint32_t sl = idx[u] / per_slice;
+#pragma unroll
+            for (int p = 0; p < S; ++p) mycnt[p] += (sl == (uint32_t)p);
+        }
+        // exclusive prefix over the lanes, per slice (inclusive scan by shuffles), and the slice totals
+        uint32_t base[S];
+        uint32_t run = 0;
+#pragma unroll
+        for (int p = 0; p < S; ++p) {
+            uint32_t v = mycnt[p];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, (int)v);
+                if (lane >= d) v += o;
+            }
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+            base[p] = run + v - mycnt[p];
+            if (lane == 0) cnt[p] = run;
+            run += total;
+        }
+        if (lane == 0) cnt[S] = run;
+        for (int u = 0; u < 8; ++u) wacc[u * 64 + lane] = ~0ULL;
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            const uint32_t sl = idx[u] / per_slice;
+            uint32_t pos = 0;
+#pragma unroll
+            for (int p = 0; p < S; ++p)
+                if (sl == (uint32_t)p) { pos = base[p]; base[p] += 1; }
+            ent[pos] = (idx[u] << 9) | (uint32_t)((u / 3) * 64 + lane);  // block number (<= 23 bits) | owner word
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t w0 = wall_clock64() / dt;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)S; ++q) {
+            const uint64_t w = w0 + q;
+            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            const uint32_t p = (uint32_t)(w % S);
+            const uint32_t lo = cnt[p], hi = cnt[p + 1];
+            const uint32_t n_loop = (hi - lo + 255) / 256;  // wave-uniform
+            for (uint32_t tl = 0; tl < n_loop; ++tl) {
+                const uint32_t i = lo + tl * 256 + lane;
+                uint32_t e[4];
+                uint64_t v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t j = i + 64 * k;
+                    e[k] = j < hi ? ent[j] : 0xFFFFFFFFu;
+                    v[k] = ~0ULL;
+                    if (j < hi) v[k] = table[e[k] >> 9];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e[k] != 0xFFFFFFFFu) __hip_atomic_fetch_and(&wacc[e[k] & 511u], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int u = 0; u < 8; ++u) acc += wacc[u * 64 + lane];
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
 static void *alloc_kind(size_t bytes, int kind);
 static void one(const char *mode, int mib, int esz, int policy, int kind, uint64_t *out);
 
@@ -242,6 +335,35 @@ static void run_phased_dense(int mib, uint32_t dt, uint64_t *out)
     const double gathers = (double)blocks * 256 * iters * NBUF;
     printf("phased DENSE table %4d MiB  S=%2d  %2d lookups per lane and round (%d full-width loads per window)  window %5.2f us : %7.1f G gathers/s\n",
            mib, S, NBUF, NBUF / S, dt / 100.0, gathers / best / 1e6);
+    fflush(stdout);
+    (void)hipFree(t);
+}
+
+template <int S>
+static void run_phased_sorted(int mib, uint32_t dt, uint64_t *out)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+    if (!t) return;
+    const uint32_t n = (uint32_t)(bytes / 8);
+    const uint32_t iters = 16;
+    const int blocks = 256 * 64;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather_phased_sorted<S>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * 24;
+    printf("phased SORTED (LDS compaction + ds_and) table %4d MiB  S=%2d  window %5.2f us : %7.1f G gathers/s\n", mib, S, dt / 100.0,
+           gathers / best / 1e6);
     fflush(stdout);
     (void)hipFree(t);
 }
@@ -352,6 +474,11 @@ int main(int argc, char **argv)
         }
         for (uint32_t dt : {200u, 400u}) run_phased<4, 24>(10, dt, out);
         for (uint32_t dt : {400u, 800u}) run_phased<16, 48>(40, dt, out);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_sorted")) {
+        for (int mib : {10, 20})
+            for (uint32_t dt : {200u, 300u, 450u, 600u, 800u}) run_phased_sorted<8>(mib, dt, out);
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "phased_dense")) {
