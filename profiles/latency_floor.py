@@ -12,8 +12,6 @@ small = [capi.DeviceIBF.create(0, 60, 3, 13, 64 * 200003) for _ in range(3)]
 buf, offs, lens = synth.make_reads(3, 4096, 360, ref)
 for name, dep, tgt in (("1 filter", [d], []), ("1+1 filters", [d], small[:1]), ("1+3 filters", [d], small)):
     eng = capi.Engine(0, dep, tgt)
-    if len(sys.argv) > 1:
-        eng.set_zero_copy_bytes(int(sys.argv[1]))
     for n in (1, 8, 64, 256, 1024):
         sub = np.ascontiguousarray(buf[: n * 360]); so, sl = offs[:n].copy(), lens[:n].copy()
         for _ in range(20):
