@@ -323,6 +323,15 @@ RB_API int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len,
                               double *out_latency_s, uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap,
                               size_t *out_calls, double *out_elapsed_s);
 
+/* What the reverse strand holds where the read has an N.  The reference counts the second strand on
+ * ModifiedString<ModifiedString<Dna5String, ModComplementDna>, ModReverse> (src/IBF/IBF.hpp:96-97, used at
+ * src/IBF/IBFClassify.cpp:98,150): the four-letter complement functor over a Dna5 host, for which SeqAn converts N to A
+ * (value & 3) before complementing -- the reverse strand sees T (ordinal 3), the forward strand hashes N as ordinal 4.
+ * That is the default (rbspec::kRevCompOfN in readbouncer_amd/csrc/ibf_spec.h, a recalled SeqAn fact like the hash
+ * constants).  ordinal = 4 gives the other candidate, "N stays N" (ModComplementDna5); anything else is refused.  Only
+ * k-mers of the reverse strand that cover an N are affected. */
+RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
+
 /* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
  * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
  * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */

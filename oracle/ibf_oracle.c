@@ -38,12 +38,29 @@ void orc_dna5_encode(const char *ascii, size_t len, uint8_t *ord)
     for (size_t i = 0; i < len; ++i) ord[i] = orc_dna5_ord((unsigned char)ascii[i]);
 }
 
-/* TSeqRevComp = ModReverse<ModComplementDna<Dna5String>>, src/IBF/IBF.hpp:96-97 */
+/* TSeqRevComp = ModifiedString<ModifiedString<Dna5String, ModComplementDna>, ModReverse>, src/IBF/IBF.hpp:96-97.
+ * [SeqAn, RECALLED] ModComplementDna = ModView<FunctorComplement<Dna>>: the FOUR-letter functor.  Its argument type is
+ * Dna, and the Dna5 -> Dna assignment is `value & 0x03` (alphabet_residue.h), so an N of the read (ordinal 4) becomes A
+ * before it is complemented: the reverse strand holds T (3) there.  ("N stays N" would be ModComplementDna5, which the
+ * reference does not name.)  One constant, switchable for the tests that run both candidates; the forward strand is not
+ * touched -- it hashes N as ordinal 4. */
+#define ORC_REVCOMP_OF_N 3
+static int g_revcomp_of_n = ORC_REVCOMP_OF_N;
+
+int orc_set_revcomp_of_n(int ordinal)
+{
+    if (ordinal != 3 && ordinal != 4) return -1;
+    g_revcomp_of_n = ordinal;
+    return 0;
+}
+
+int orc_get_revcomp_of_n(void) { return g_revcomp_of_n; }
+
 void orc_revcomp(const uint8_t *ord, size_t len, uint8_t *out)
 {
     for (size_t i = 0; i < len; ++i) {
         uint8_t o = ord[len - 1 - i];
-        out[i] = (o < 4) ? (uint8_t)(3 - o) : 4;
+        out[i] = (o < 4) ? (uint8_t)(3 - o) : (uint8_t)g_revcomp_of_n;
     }
 }
 

@@ -67,8 +67,12 @@ typedef struct orc_ibf {
 /* a.2  ASCII -> Dna5 ordinal (A0 C1 G2 T3/U3, everything else 4) */
 uint8_t orc_dna5_ord(unsigned char c);
 void orc_dna5_encode(const char *ascii, size_t len, uint8_t *ord);
-/* TSeqRevComp (IBF.hpp:96-97): reverse + complement, N stays N */
+/* TSeqRevComp (IBF.hpp:96-97): reverse + ModComplementDna.  An N of the read becomes ordinal orc_get_revcomp_of_n() on
+ * the reverse strand: 3 (T) by default -- the four-letter functor sees N as A -- or 4 ("N stays N", the ModComplementDna5
+ * reading); process-wide switch for the tests that run both. */
 void orc_revcomp(const uint8_t *ord, size_t len, uint8_t *out);
+int orc_set_revcomp_of_n(int ordinal); /* 3 or 4; -1 otherwise */
+int orc_get_revcomp_of_n(void);
 
 /* a.1  TIbf(bins, h, k, bits)  (IBFBuild.cpp:465) */
 orc_ibf *orc_ibf_new(uint64_t n_bins, uint64_t n_hash, uint64_t kmer_size, uint64_t n_bits);

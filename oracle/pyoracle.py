@@ -104,6 +104,10 @@ def lib():
     L.orc_ibf_resize_bins.argtypes = [C.c_void_p, C.c_uint64]
     L.orc_dna5_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
     L.orc_revcomp.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.orc_set_revcomp_of_n.restype = C.c_int
+    L.orc_set_revcomp_of_n.argtypes = [C.c_int]
+    L.orc_get_revcomp_of_n.restype = C.c_int
+    L.orc_get_revcomp_of_n.argtypes = []
     _lib = L
     return L
 
@@ -121,6 +125,21 @@ def revcomp(ord_arr):
     out = np.empty_like(ord_arr)
     lib().orc_revcomp(ord_arr.ctypes.data, len(ord_arr), out.ctypes.data)
     return out
+
+
+REVCOMP_OF_N_DEFAULT = 3  # ORC_REVCOMP_OF_N: the reverse strand sees T where the read has N (ModComplementDna, IBF.hpp:96-97)
+
+
+def set_revcomp_of_n(ordinal):
+    """process-wide: 3 = N -> (Dna) A -> T, 4 = N stays N; returns the previous value"""
+    prev = lib().orc_get_revcomp_of_n()
+    if lib().orc_set_revcomp_of_n(int(ordinal)) != 0:
+        raise ValueError("the reverse strand's image of N is ordinal 3 or 4")
+    return prev
+
+
+def get_revcomp_of_n():
+    return lib().orc_get_revcomp_of_n()
 
 
 def _ptr_array(filters):

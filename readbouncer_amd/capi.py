@@ -102,6 +102,7 @@ SIGNATURES = {
     "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
     "rb_replay_arrivals": (_int, [_vp, _vp, _u32, _sz, _vp, _sz, _dbl, _dbl, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz),
                                   C.POINTER(_dbl)]),
+    "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
@@ -394,6 +395,10 @@ class Engine:
 
     def set_column_shard(self, rank, world):
         _check(lib().rb_engine_set_column_shard(self.h, rank, world), "rb_engine_set_column_shard")
+
+    def set_revcomp_of_n(self, ordinal):
+        """3 (default): the reverse strand sees T where the read has N (ModComplementDna on a Dna5String); 4: N stays N"""
+        _check(lib().rb_engine_set_revcomp_of_n(self.h, ordinal), "rb_engine_set_revcomp_of_n")
 
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")

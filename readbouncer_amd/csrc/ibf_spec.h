@@ -58,8 +58,19 @@ RB_HD uint32_t dna5_ord(uint32_t c)
     return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : (c == 'T' || c == 'U') ? 3u : 4u;
 }
 
-// complement on ordinals (ModComplementDna for Dna5): A<->T, C<->G, N stays N
-RB_HD uint32_t dna5_comp(uint32_t o) { return o < 4u ? 3u - o : 4u; }
+// What the reverse strand holds where the read has an N (Dna5 ordinal 4).  The reference's reverse-complement view is
+//   ModifiedString<ModifiedString<Dna5String, ModComplementDna>, ModReverse>            (src/IBF/IBF.hpp:96-97)
+// i.e. the FOUR-letter functor FunctorComplement<Dna> over a Dna5 host, not ModComplementDna5.  RECALLED from SeqAn2
+// (include/seqan/modifier/modifier_functors.h, modifier_alphabet.h; include/seqan/basic/alphabet_residue.h): the functor's
+// argument type is Dna, the Dna5 -> Dna assignment is `target.value = source.value & 0x03` (N -> A), the complement of A is
+// T, and the Dna result is hashed by Shape<Dna5> with its ordinal unchanged.  So the reverse strand sees T (3) where the
+// read has N; the forward strand still hashes N as ordinal 4.  "N stays N" (4) would be ModComplementDna5, which the
+// reference does not name.  Like the hash constants this is unverifiable here; tools/make_reference_fixtures.cpp writes
+// the two N-containing reads that decide it, and rb_engine_set_revcomp_of_n flips it at run time without a rebuild.
+constexpr uint32_t kRevCompOfN = 3;
+
+// complement on ordinals under that view: A<->T, C<->G, N -> comp_of_n
+RB_HD uint32_t dna5_comp(uint32_t o, uint32_t comp_of_n = kRevCompOfN) { return o < 4u ? 3u - o : comp_of_n; }
 
 // floor(2^64 / d) for d >= 2 (d = 1 handled by callers: everything maps to block 0)
 inline uint64_t fastmod_magic(uint64_t d)

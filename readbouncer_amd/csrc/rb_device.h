@@ -20,6 +20,7 @@ struct IbfDev {
     uint32_t stride;  // words from one block to the next in HBM (>= bin_width; padded layout)
     uint32_t k;
     uint32_t n_hash;
+    uint32_t comp_n;  // ordinal the reverse strand holds for an N of the read (rbspec::kRevCompOfN unless the engine was told otherwise)
 };
 
 // where the bases of a batch live (by-value kernel argument)
@@ -38,7 +39,7 @@ struct ReadSrc {
 // gather from.  n_slices == 0: off.
 struct PhaseCfg {
     uint32_t shift;      // log2 blocks per slice
-    uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 16
+    uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 8
     uint32_t inv_ticks;  // floor(2^32 / window length in 10 ns ticks)
 };
 

@@ -92,6 +92,7 @@ struct rb_engine {
     bool timing = false;
     std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
+    uint32_t revcomp_of_n = rbspec::kRevCompOfN;  // see ibf_spec.h: what the reverse strand holds for an N of the read
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
     // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
@@ -191,6 +192,7 @@ static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, uint64_t
     d->stride = (uint32_t)stride;
     d->k = (uint32_t)g.kmer_size;
     d->n_hash = (uint32_t)g.n_hash;
+    d->comp_n = rbspec::kRevCompOfN;
     return RB_OK;
 }
 
@@ -632,6 +634,14 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
     return RB_OK;
 }
 
+int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal)
+{
+    if (!e || (ordinal != 3 && ordinal != 4)) return rb::fail(RB_ERR_INVALID_ARG, "the reverse strand's image of N is ordinal 3 (T) or 4 (N)");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->revcomp_of_n = ordinal;
+    return RB_OK;
+}
+
 int rb_engine_set_split_threshold(rb_engine *e, uint32_t max_reads)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -841,8 +851,12 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
     if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
+        // the phased kernels take a lookup's slice from its byte offset by a shift: block strides that are a power of two
+        // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 3 on a wider
+        // filter, e.g. 3072 bins over 6 ranks -- stride 48 -- and keeps the plain kernel)
+        const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
-            n_reads >= e->phase_min_reads) {
+            n_reads >= e->phase_min_reads && stride_pow2) {
             uint32_t sh = 0;
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
             uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
@@ -1080,6 +1094,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         }
         CountLaunch a{};
         a.f = f->dev;
+        a.f.comp_n = e->revcomp_of_n;
         a.src.seqs = (const uint8_t *)d_seqs;
         a.src.offsets = (const uint64_t *)d_offsets;
         a.src.lens = (const uint32_t *)d_lens;

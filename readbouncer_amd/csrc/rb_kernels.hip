@@ -375,7 +375,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 if (strand == 0) {
                     for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
                 } else {  // k-mer of the reverse complement that covers the same window
-                    for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                    for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
                 }
             }
             kv[j] = v;
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     if (j < 4) {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
                     } else {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
                     }
                 }
 #pragma unroll
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     if (j < 4) {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
                     } else {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i]);
+                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
                     }
                 }
 #pragma unroll
@@ -1377,6 +1377,8 @@ hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
     if (a.n_reads == 0) return hipSuccess;
     if (a.phase.n_slices && a.split_waves < 2) {  // planned by the engine for: 3 hash functions, one slice, lg <= 3, wpl 1, n_fused 0
         if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 3 || a.n_slices != 1 || a.n_fused > 0) return hipErrorInvalidValue;
+        // slice of a lookup = byte offset >> (shift + 3 + log2 stride): more than one slice needs a power-of-two block stride
+        if (a.phase.n_slices > 1 && (a.f.stride & (a.f.stride - 1)) != 0) return hipErrorInvalidValue;
         return a.planes <= 10 ? dispatch_phased<10>(a, st) : dispatch_phased<16>(a, st);
     }
     if (a.split_waves >= 2) {  // latency form (three hash functions only; the engine plans it for those)

@@ -13,8 +13,19 @@ from tests import helpers as H
 
 
 # RB_FUZZ_SEEDS=<n> widens the sweep for an offline soak (profiles/r01/deep_parity.txt)
+# n_rule: what the reverse strand holds for an N of the read -- 3 (T; ModComplementDna over a Dna5String, the default)
+# or 4 (N).  Both candidates of that recalled SeqAn fact are fuzzed, kernels and oracle under the same rule.
+@pytest.mark.parametrize("n_rule", [3, 4])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("RB_FUZZ_SEEDS", "24"))))
-def test_random_geometry(seed):
+def test_random_geometry(seed, n_rule):
+    prev = po.set_revcomp_of_n(n_rule)
+    try:
+        _random_geometry(seed, n_rule)
+    finally:
+        po.set_revcomp_of_n(prev)
+
+
+def _random_geometry(seed, n_rule):
     rng = np.random.default_rng(1000 + seed)
     n_bins = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, int(rng.integers(1, 9000)), int(rng.integers(1, 700))]))
     k = int(rng.choice([3, 5, 8, 11, 13, 15, 19, 27, 28, 32, int(rng.integers(3, 33))]))
@@ -53,6 +64,7 @@ def test_random_geometry(seed):
     r_err = float(rng.choice([0.1, 0.05, 0.14]))
     exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, r=r_err, n_threads=4)
     eng = capi.Engine(0, [d], [])
+    eng.set_revcomp_of_n(n_rule)
     for split in (2048, 0):
         eng.set_split_threshold(split)
         mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)

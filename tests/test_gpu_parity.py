@@ -807,3 +807,100 @@ def test_threshold_tables_survive_eviction_and_growth():
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (it, r, top)
     with pytest.raises(capi.RBError):  # NormalCDFInverse would throw (IBF.hpp:284-308)
         eng.classify(buf, offs, lens, significance=1.5)
+
+
+N_REVERSE = "ATAATATATAANATCTCCTCTCTTTTGGGGCTCTCTCTCTCC"  # tests/test_oracle_kat.py: revcomp of test.fasta[30:72], one A -> N
+
+
+@pytest.mark.parametrize("n_rule", [3, 4])
+def test_n_reads_under_both_revcomp_rules(refdata, n_rule):
+    """What the reverse strand holds for an N of the read (src/IBF/IBF.hpp:96-97: ModComplementDna over a Dna5String) is a
+    recalled SeqAn fact with two candidates: T (3, the default) and N (4).  Kernels and oracle each keep ONE constant and
+    a switch; both candidates run through every kernel form against the oracle under the same rule, and the KAT read
+    whose reverse-strand count tells them apart (30 vs 18) goes through the GPU."""
+    prev = po.set_revcomp_of_n(n_rule)
+    try:
+        rng = np.random.default_rng(40 + n_rule)
+        ref = H.random_dna(rng, 12000)
+        comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+        rc = lambda t: "".join(comp[c] for c in reversed(t))
+        reads = []
+        for i in range(160):
+            L = int(rng.integers(20, 900 if i % 8 == 0 else 420))
+            s = int(rng.integers(0, len(ref) - L))
+            r = H.mutate(rng, ref[s:s + L], 0.03)
+            if i % 2:
+                r = rc(r)  # positives on the reverse strand: this is where the rule shows
+            r = list(r)
+            for p in rng.integers(0, L, size=int(rng.integers(1, 5))):
+                r[int(p)] = "N" if rng.random() < 0.8 else "n"
+            reads.append("".join(r))
+        reads += ["N" * 40, "N", "ACGTN" * 30, "N" + ref[50:300], rc(ref[50:300]) + "N", rc(ref[400:760])[:100] + "NN" + rc(ref[400:760])[102:]]
+        buf, offs, lens = H.pack_reads(reads)
+        differs = 0
+        for n_bins, n_blocks in ((40, 30011), (100, 20011), (200, 9973), (1024, 4099), (8192, 257)):
+            W = (n_bins + 63) // 64
+            d = capi.DeviceIBF.create(0, n_bins, 3, 13, W * 64 * n_blocks)
+            d.add_sequence(ref, 12000 // min(n_bins, 60) + 1)
+            o, _keep = oracle_view(d)
+            expect = po.batch_raw_max(o, buf, offs, lens, 4)
+            po.set_revcomp_of_n(7 - n_rule)
+            differs += int((po.batch_raw_max(o, buf, offs, lens, 4) != expect).sum())
+            po.set_revcomp_of_n(n_rule)
+            exp_dec, exp_st = po.batch_check_unblock([o], [], buf, offs, lens, n_threads=4)
+            eng = capi.Engine(0, [d], [])
+            eng.set_revcomp_of_n(n_rule)
+            for form in ("latency", "throughput", "phased"):
+                eng.set_split_threshold(2048 if form == "latency" else 0)
+                if form == "phased":
+                    eng.set_phased(0, 1 << 40, 200, 0, 1)
+                else:
+                    eng.set_phased(0, 0, 0, 0, 0) if form == "throughput" else eng.set_phased()
+                mc, _, dec, st = eng.classify(buf, offs, lens)
+                assert np.array_equal(mc[:, 0], expect), (n_bins, form)
+                assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, form)
+            with pytest.raises(capi.RBError):
+                eng.set_revcomp_of_n(2)
+        assert differs > 50  # the two rules really give different counts on this batch
+        # the KAT: filter of the reference's test.fasta, read N_REVERSE -> 30 shared 13-mers under T-for-N, 18 under N-for-N
+        (_, seq), = H.read_fasta(os.path.join(refdata, "libIBFTests_test.fasta"))
+        c = capi.cut_out_nnns(seq)
+        d = capi.DeviceIBF.create(0, 1, 3, 13, capi.calculate_filter_size_bits(100000, 13, 3, 0.01, 1))
+        d.add_sequence(c, 100000, 0)
+        eng = capi.Engine(0, [d], [])
+        eng.set_revcomp_of_n(n_rule)
+        kb, ko, kl = H.pack_reads([N_REVERSE])
+        assert eng.classify(kb, ko, kl)[0][0, 0] == {3: 30, 4: 18}[n_rule]
+        if n_rule == 3:  # and 3 is what an engine does when nobody tells it anything
+            assert capi.Engine(0, [d], []).classify(kb, ko, kl)[0][0, 0] == 30
+    finally:
+        po.set_revcomp_of_n(prev)
+
+
+def test_bin_sharded_rank_with_odd_stride_keeps_the_plain_kernel():
+    """a bin-sharded rank can reach <= 8 word columns on a filter whose HBM block stride is not a power of two
+    (3072 bins: 48 words, stride 48; 6 ranks x 8 columns).  The phased kernels take a lookup's slice from its byte offset
+    by a shift, which needs a power-of-two stride: the planner must not pick them there, even when forced."""
+    rng = np.random.default_rng(91)
+    ref = H.random_dna(rng, 20000)
+    for n_bins in (3072, 2560):
+        W = (n_bins + 63) // 64
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, W * 64 * 24007)  # 9.2 / 7.7 MB: inside the phased size range
+        assert d.device_stride() == W and (W & (W - 1)) != 0
+        d.fill_synth(17)
+        d.add_sequence(ref, 50)
+        o, _keep = oracle_view(d)
+        reads = make_reads(rng, ref, 300, lo=100, hi=400)
+        buf, offs, lens = H.pack_reads(reads)
+        expect = po.batch_raw_max(o, buf, offs, lens, 4)
+        eng = capi.Engine(0, [d], [])
+        eng.set_split_threshold(0)
+        for forced in (False, True):
+            if forced:
+                eng.set_phased(0, 1 << 40, 300, 0, 1)
+            acc = np.zeros(len(reads), dtype=np.uint16)
+            for rank in range(6):
+                eng.set_column_shard(rank, 6)
+                acc = np.maximum(acc, eng.classify(buf, offs, lens)[0][:, 0])
+            assert np.array_equal(acc, expect), (n_bins, forced)
+        eng.set_column_shard(0, 1)

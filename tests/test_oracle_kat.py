@@ -294,3 +294,102 @@ def test_reference_written_ibf_pins_hash_and_layout(refdata, name, fasta, expect
     ours = H.build_filter_like_reference([s for _, s in H.read_fasta(os.path.join(refdata, fasta))])
     assert (ours.n_bins, ours.n_bits) == (ref_made.n_bins, ref_made.n_bits)
     assert np.array_equal(ours.words(), ref_made.words())
+
+
+# ---- the reverse strand's image of N ------------------------------------------------------------------------------------
+# TSeqRevComp is ModifiedString<ModifiedString<Dna5String, ModComplementDna>, ModReverse> (src/IBF/IBF.hpp:96-97): the
+# FOUR-letter complement functor over a Dna5 host.  RECALLED SeqAn2 behaviour: its argument type is Dna, Dna5 -> Dna is
+# `value & 3` (N -> A), so the reverse strand holds T where the read has N.  The other reading ("N stays N") is what
+# ModComplementDna5 would do.  One constant per side (ORC_REVCOMP_OF_N / rbspec::kRevCompOfN), both switchable.
+N_REVERSE = "ATAATATATAANATCTCCTCTCTTTTGGGGCTCTCTCTCTCC"  # revcomp of test.fasta[30:72] (N-free), the A mirroring a T -> N
+N_FORWARD = READ_354[:60] + "N" + READ_354[61:120]
+
+
+@pytest.fixture
+def n_rule_restored():
+    prev = po.get_revcomp_of_n()
+    yield
+    po.set_revcomp_of_n(prev)
+
+
+def test_revcomp_of_n_default_follows_the_type_the_reference_names(test_ibf, n_rule_restored):
+    assert po.get_revcomp_of_n() == po.REVCOMP_OF_N_DEFAULT == 3
+    o = po.encode(N_REVERSE)
+    assert "".join("ACGTN"[x] for x in po.revcomp(o)) == "GGAGAGAGAGAGCCCCAAAAGAGAGGAGATTTTATATATTAT"  # T for the N
+    # forward strand: nothing of this read is in the filter; reverse strand: all 30 13-mers of the reference window
+    assert test_ibf.count(o).max() == 0 and test_ibf.count(po.revcomp(o)).max() == 30 and test_ibf.raw_max(o) == 30
+    po.set_revcomp_of_n(4)  # "N stays N": the 12 k-mers covering it are lost
+    assert "".join("ACGTN"[x] for x in po.revcomp(o)) == "GGAGAGAGAGAGCCCCAAAAGAGAGGAGATNTTATATATTAT"
+    assert test_ibf.count(po.revcomp(o)).max() == 18 and test_ibf.raw_max(o) == 18
+    # an N on the forward strand is ordinal 4 under both readings
+    f = po.encode(N_FORWARD)
+    for rule in (3, 4):
+        po.set_revcomp_of_n(rule)
+        assert test_ibf.count(f).max() == 92 and test_ibf.count(po.revcomp(f)).max() == 0
+    with pytest.raises(ValueError):
+        po.set_revcomp_of_n(2)
+
+
+def check_reference_counts(doc, filters):
+    """Compares every per-bin count vector of a reference_counts.json (tools/make_reference_fixtures.cpp) with the oracle.
+    Returns the N rule (3 or 4) under which ALL reverse-strand vectors agree; forward vectors must agree regardless."""
+    prev = po.get_revcomp_of_n()
+    rules_ok = {3: True, 4: True}
+    try:
+        assert doc["kmer_size"] == 13 and doc["hash_functions"] == 3
+        for rd in doc["reads"]:
+            o = po.encode(rd["seq"])
+            for name, f in filters.items():
+                ref = rd[name]
+                assert ref["bins"] == f.n_bins, (rd["name"], name)
+                assert f.count(o).tolist() == ref["fwd"], "forward counts of %s vs %s differ: hash/layout" % (rd["name"], name)
+                for rule in (3, 4):
+                    po.set_revcomp_of_n(rule)
+                    rules_ok[rule] &= f.count(po.revcomp(o)).tolist() == ref["rev"]
+    finally:
+        po.set_revcomp_of_n(prev)
+    good = [r for r, ok in rules_ok.items() if ok]
+    assert good, "reverse-strand counts match under neither N rule"
+    return good
+
+
+def _self_made_counts(filters, rule):
+    """what the pin kit would write if the reference behaved like the oracle under `rule` (self-check of the consumer only)"""
+    prev = po.set_revcomp_of_n(rule)
+    try:
+        reads = [("mer35", MER_35), ("read354", READ_354), ("n_forward", N_FORWARD), ("n_reverse", N_REVERSE)]
+        doc = {"kmer_size": 13, "hash_functions": 3, "reads": []}
+        for name, seq in reads:
+            o = po.encode(seq)
+            e = {"name": name, "seq": seq}
+            for fname, f in filters.items():
+                e[fname] = {"bins": int(f.n_bins), "fwd": f.count(o).tolist(), "rev": f.count(po.revcomp(o)).tolist()}
+            doc["reads"].append(e)
+        return doc
+    finally:
+        po.set_revcomp_of_n(prev)
+
+
+def test_reference_counts_consumer_self_check(test_ibf, test1_ibf, n_rule_restored):
+    # NOT a pin: the vectors come from the oracle itself.  It shows that the consumer tells the two N rules apart and
+    # notices a wrong forward count, so that the slot below means something the day the real file is dropped in.
+    filters = {"test.ibf": test_ibf, "test1.ibf": test1_ibf}
+    assert check_reference_counts(_self_made_counts(filters, 3), filters) == [3]
+    assert check_reference_counts(_self_made_counts(filters, 4), filters) == [4]
+    bad = _self_made_counts(filters, 3)
+    bad["reads"][1]["test.ibf"]["fwd"][0] += 1
+    with pytest.raises(AssertionError):
+        check_reference_counts(bad, filters)
+
+
+def test_reference_counts_json_pins_counts_and_n_rule(refdata, test_ibf, test1_ibf, n_rule_restored):
+    import json
+    path = os.path.join(refdata, "reference_counts.json")
+    if not os.path.exists(path):
+        pytest.skip("reference_counts.json (tools/make_reference_fixtures.cpp) not available: counts and the "
+                    "reverse-complement-of-N rule stay unpinned")
+    with open(path) as fh:
+        doc = json.load(fh)
+    good = check_reference_counts(doc, {"test.ibf": test_ibf, "test1.ibf": test1_ibf})
+    assert po.REVCOMP_OF_N_DEFAULT in good, "the reference's reverse strand sees ordinal %s for N: change ORC_REVCOMP_OF_N " \
+                                            "and rbspec::kRevCompOfN" % good
