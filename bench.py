@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- reads/s of the IBF classify hot path on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path (K1 count/max for every filter + K2 decision) over one batch of
-synthetic 360 bp read prefixes that is already resident in HBM, against IBF(s) resident in HBM.
-N=1 workload = BASELINE.json configs[1] ("c2"); other configs via --workload.  With N>1 every rank
-(one process per GPU) holds a replica of the IBF and its own shard of reads (weak scaling, no data-path
-collective); time = max over ranks, value = all reads / that time.  `python bench.py --gpus N` starts
-the N ranks itself (fresh child processes, started before this process touches the GPU); under
-torchrun (WORLD_SIZE set) it is one of the ranks.
+A step = one pass of the hot path (K1 count/max for every filter + K2 decision) over one batch of synthetic 360 bp read
+prefixes that is already resident in HBM, against IBF(s) resident in HBM.
+
+Headline workload (N = 1 and N > 1 alike) = BASELINE.json configs[2], the configuration the north star's target is stated
+on: 10 M reads x 360 bp against the GRCh38-scale depletion IBF (8192 bins, 8 GiB) -- ONE launch of 10 M reads per step and
+GPU.  The same line carries `other_configs`: configs[1] (c2, whose 0.41 GB table is partly Infinity-Cache resident),
+configs[3] (c4: deplete + target, full check_unblock; full steps, CPU baseline, parity), configs[4] (c5: the 48-flowcell
+replay with its latency percentiles, plus a leg through the live step with concatenated undecided chunks) and the shape of
+the reference's README benchmark -- run in this process (and, for N > 1, by all ranks), after the headline measurement.
+
+With N > 1 every rank (one process per GPU) holds a replica of the IBF and its own shard of reads (weak scaling, no
+data-path collective); time = max over ranks, value = all reads / that time.  `python bench.py --gpus N` starts the N ranks
+itself (fresh child processes, started before this process touches the GPU); under torchrun (WORLD_SIZE set) it is one of
+the ranks.
 
 Prints ONE JSON line with the driver contract fields plus "roofline" and "cpu_baseline".
 The CPU oracle is used here only as the checker / cpu_baseline leg, never in the timed path.
@@ -24,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured: 6.5 TB/s streaming, 6.8-6.9 TB/s random rows (profiles/hbm_peak.hip)
+METRIC = "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)"
+# test hook (tests/test_bench_ranks.py only; the line then carries "test_reads_divisor"): every leg's default batch divided by
+# this, so that the full default run -- headline + other_configs -- fits a unit test
+TEST_DIVISOR = max(1, int(os.environ.get("RB_BENCH_READS_DIVISOR", "1")))
 
 
 def host_cores():
@@ -60,17 +71,36 @@ def _free_port():
     return p
 
 
+def visible_gpu_count():
+    """GPUs of this node WITHOUT touching the HIP runtime (the launcher must not initialise the GPU before its children
+    exist): the KFD topology lists one node per agent, GPUs are the ones with SIMDs; HIP_/ROCR_VISIBLE_DEVICES narrow it.
+    None = cannot tell (no KFD here): the children then find out themselves."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(l.split()[:2] for l in open(os.path.join(base, node, "properties")) if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except Exception:
+        return None
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (rank i -> GPU i, RCCL
-    rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  This process never initialises the GPU (no HIP call,
-    no torch.cuda.is_available(): children started by a process that holds the device are refused on this pool) and it
-    never execs: it waits for the children and exits with the worst of their codes.  The reference's scaling model is N
-    classification workers behind one queue (src/main/adaptive_sampling.hpp:745-751); here a worker is a GPU."""
+    rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  This process never initialises the GPU (no HIP call, no
+    torch import: devices are counted from the KFD topology) and it never execs: it waits for the children and exits with
+    the worst of their codes.  The reference's scaling model is N classification workers behind one queue
+    (src/main/adaptive_sampling.hpp:745-751); here a worker is a GPU."""
     import subprocess
     if os.environ.get("RB_BENCH_SAME_GPU") != "1" and os.environ.get("RB_BENCH_ENGINE") != "none":
-        import torch  # counting devices does not initialise the GPU
-        have = torch.cuda.device_count()
-        if have < n:
+        have = visible_gpu_count()
+        if have is not None and have < n:
             print("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have), file=sys.stderr)
             sys.exit(2)
     port = _free_port()
@@ -114,117 +144,429 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c2", help="c2 (default, BASELINE configs[1]), c3, c3np2, c1, c4, c5, readme, grch38_f100k, zymo, zymo16")
+    ap.add_argument("--workload", default="",
+                    help="default: c3 (BASELINE configs[2], 10 M reads per step) + other_configs; or one of c2, c3, c3np2, c1, c4, c5, "
+                         "readme, grch38_f100k, zymo, zymo16 on its own")
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU per step (default: the config's batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--check-reads", type=int, default=2048, help="reads checked against the oracle (rank 0)")
+    ap.add_argument("--check-reads", type=int, default=2048, help="N>1: reads of rank 0 checked against the oracle")
     ap.add_argument("--bin-sharded", action="store_true",
                     help="N>1: every rank holds a word-column slice of each block and sees ALL reads; per-read partial "
-                         "maxima are combined with one all_reduce(max) before the decision (strong scaling)")
+                         "maxima are all-gathered and the max is taken in the decision kernel (strong scaling)")
     ap.add_argument("--no-overlap", action="store_true", help="serialise the count kernels of different filters")
     ap.add_argument("--rate", type=float, default=150000.0, help="c5: total chunk arrival rate (chunks/s) over all GPUs")
-    ap.add_argument("--replay-seconds", type=float, default=3.0, help="c5: length of the replayed arrival process")
+    ap.add_argument("--replay-seconds", type=float, default=2.0, help="c5: length of the replayed arrival process")
     ap.add_argument("--read-len", type=int, default=0, help="override the read length of the workload (e.g. 1500: 16 counter planes)")
     ap.add_argument("--phased", default="", help="tuning: 'off' or 'min_mib,max_mib,base_ticks,ticks_per_mib' for the clock-phased gathers of narrow filters")
     ap.add_argument("--serial-table-mib", type=int, default=-1,
                     help="tuning: filters up to this size take turns instead of overlapping (default: the engine's 64; 0 = round 1 behaviour)")
-    ap.add_argument("--no-extras", action="store_true",
-                    help="default c2 run on one GPU: do not append the short runs of configs 3, 4 and 5 (`other_configs`)")
+    ap.add_argument("--no-extras", action="store_true", help="default run: leave `other_configs` out")
     return ap.parse_args()
 
 
-def other_configs(args):
-    """Runs of the other BASELINE configs that fit one GPU, each in a child process after the main measurement (the
-    headline line stays config 2, the configuration BASELINE.json's metric is quoted on).  Config 3 -- the 8 GiB
-    GRCh38-scale filter, the HBM-bound case -- is a FULL run: same steps and warm-up as the headline, its own roofline
-    (live hipEvent kernel time), CPU baseline and parity leg; it comes back as `hbm_bound_config`.  Short runs: deplete +
-    target check_unblock (c4), the live replay (c5), the four narrow filters of the reference's README benchmark
-    (readme).  Failures are reported, never raised."""
-    import subprocess
-    st, wu = str(args.steps), str(args.warmup)
-    runs = {
-        "c3": ["--workload", "c3", "--steps", st, "--warmup", wu, "--cpu-seconds", "8", "--no-latency"],
-        "c4": ["--workload", "c4", "--reads", "1000000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
-        "c5": ["--workload", "c5", "--replay-seconds", "2.0"],
-        # the shape of the reference's only published benchmark (README.md:254-262; ~506 reads/s there, hardware unstated)
-        "readme": ["--workload", "readme", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-latency"],
-    }
-    out, hb = {}, None
-    for name, argv in runs.items():
-        try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-extras"] + argv, capture_output=True,
-                               text=True, timeout=420)
-            line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
-            d = json.loads(line)
-            if name == "c3":
-                hb = {k: d.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                            "cpu_baseline", "parity")}
-                continue
-            o = {"workload": d["config"]["workload"], "value": d["value"], "unit": d["unit"]}
-            if d.get("roofline", {}).get("frac") is not None:
-                o["roofline_frac"] = d["roofline"]["frac"]
-                o["achieved_GBps"] = d["roofline"]["achieved"]
-                o["ms_per_step"] = d["ms_per_step"]
-                o["decisions"] = d["config"].get("decisions")
-            if name == "c5":
-                o["latency"] = {k: v for k, v in d["latency"].items() if k.endswith("_ms") or k == "slo_met"}
-                o["micro_batch_reads"] = d["config"].get("micro_batch_reads")
-                o["dispatcher"] = d["config"].get("dispatcher")
-            out[name] = o
-        except Exception as ex:  # noqa: BLE001 -- the headline line must not depend on the extras
-            err = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
-            if name == "c3":
-                hb = err
-            else:
-                out[name] = err
-    return hb, out
+def load_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
 
 
-def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
+class Ctx:
+    """what every leg of the run shares: the process group, the device, the filters already resident in HBM"""
+
+    def __init__(self, args, torch, dist, world, rank, dev_index, backend, same_gpu, force_group):
+        self.args, self.torch, self.dist = args, torch, dist
+        self.world, self.rank, self.dev_index, self.backend = world, rank, dev_index, backend
+        self.same_gpu, self.force_group = same_gpu, force_group
+        self.dev = torch.device("cuda", dev_index)
+        self.red_dev = self.dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
+        self.filters = {}  # workload key -> (DeviceIBF, planted reference)
+        self.filter_setup_s = 0.0
+
+    SEEDS = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60), "grch38_f100k": (8, 80),
+             "zymo16": (6, 60), "mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113)}
+
+    def filter(self, key):
+        from readbouncer_amd import synth
+        if key not in self.filters:
+            t = time.time()
+            fs, ps = self.SEEDS[key]
+            seg = 512 if key.startswith("mock_") else 2048
+            self.filters[key] = synth.build_device_filter(self.dev_index, synth.WORKLOADS[key], fill_seed=fs, plant_seed=ps,
+                                                          n_segments=seg)
+            self.torch.cuda.synchronize()
+            self.filter_setup_s += time.time() - t
+        return self.filters[key]
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        """element-wise max of a list of floats over the ranks (the contract's max-over-ranks timing)"""
+        if self.dist is None:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    def gather_floats(self, value):
+        if self.dist is None:
+            return [value]
+        g = self.torch.zeros(self.world, dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_gather_into_tensor(g, self.torch.tensor([value], dtype=self.torch.float64, device=self.red_dev))
+        return [float(x) for x in g.tolist()]
+
+
+def workload_spec(ctx, name):
+    """-> (deplete keys, target keys, text, default reads per step and GPU, read length)"""
+    from readbouncer_amd import synth
+    if name == "c4":
+        return (["c3"], ["zymo"], "config4: deplete=GRCh38-scale IBF (8192 bins, 8 GiB) + target=Zymo-mock-like IBF (600 bins), "
+                "check_unblock", 2_000_000, 360)
+    if name == "readme":
+        # the reference's own (only) published benchmark shape: README.md:254-262, 250 bp prefixes, 1 deplete + 3 targets
+        return (["mock_deplete"], ["mock_t1", "mock_t2", "mock_t3"],
+                "README benchmark shape: 250bp prefixes vs 1 deplete (122 bins) + 3 target (43/29/49 bins) IBFs, k=13, F=100000, "
+                "check_unblock", 1_000_000, 250)
+    w = synth.WORKLOADS[name]
+    return [name], [], w["name"], w["reads"], w["read_len"]
+
+
+def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cpu_seconds=None, latency=False,
+                   bin_sharded=False):
+    """One throughput measurement as the contract describes it: W untimed steps, then K steps between barriers, time = max
+    over ranks.  Returns the result dict on rank 0 (None elsewhere): value, roofline (live hipEvent kernel time), parity
+    against the oracle, CPU baseline (N = 1)."""
+    from readbouncer_amd import capi, synth
+    args, torch, dist = ctx.args, ctx.torch, ctx.dist
+    world, rank, dev, dev_index = ctx.world, ctx.rank, ctx.dev, ctx.dev_index
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    cpu_seconds = args.cpu_seconds if cpu_seconds is None else cpu_seconds
+    t_setup = time.time()
+    dep_keys, tgt_keys, wname, default_reads, default_len = workload_spec(ctx, name)
+    deplete = [ctx.filter(k)[0] for k in dep_keys]
+    target = [ctx.filter(k)[0] for k in tgt_keys]
+    ref = np.concatenate([ctx.filter(k)[1] for k in dep_keys + tgt_keys])
+    if not n_reads and TEST_DIVISOR > 1:
+        n_reads = max(4096, default_reads // TEST_DIVISOR)
+    n_reads = n_reads or default_reads
+    read_len = read_len or default_len
+    if n_reads != default_reads:
+        wname += " [%d reads per step and GPU]" % n_reads
+    elif name in ("c3", "c3np2"):
+        wname += " [one launch of %d reads per step and GPU]" % n_reads
+    filters = deplete + target
+    nf = len(filters)
+    geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in filters]
+    bytes_per_read = synth.algorithmic_bytes_per_read(read_len, geo)
+
+    # reads are generated on the device (plumbing) and stay resident in HBM
+    seed = 1000 if bin_sharded else 1000 + rank  # bin-sharded: every rank classifies the SAME reads against its columns
+    t_seq, t_off, t_len = synth.make_reads_device(seed, n_reads, read_len, ref, dev)
+    lens = np.full(n_reads, read_len, dtype=np.uint32)
+    offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(read_len)
+    t_max = torch.zeros((n_reads, nf), dtype=torch.int16, device=dev)
+    t_best = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    eng = capi.Engine(dev_index, deplete, target)
+    if args.no_overlap:
+        eng.set_overlap(False)
+    if args.serial_table_mib >= 0:
+        eng.set_serial_table_bytes(args.serial_table_mib << 20)
+    if args.phased == "off":
+        eng.set_phased(0, 0, 0, 0, 0)
+    elif args.phased:
+        lo, hi, base, tk = [int(x) for x in args.phased.split(",")]
+        eng.set_phased(lo << 20, hi << 20, base, tk, 1024)  # "0,0,300,3": plain gathers, but the short-read kernel for one-word filters
+    # a dedicated non-null stream: steps are queued asynchronously; torch.cuda.synchronize() covers it
+    side = torch.cuda.Stream(device=dev)
+    stream = side.cuda_stream
+    max_len = int(read_len)
+    if bin_sharded:
+        eng.set_column_shard(rank, world)
+        # the u16 partial maxima of all ranks, all-gathered as they are (byte view: an all-gather does no arithmetic, so
+        # there is no widening for the collective and half the bytes of an int32 all-reduce); the max over the ranks is
+        # taken inside the decision kernel
+        t_all = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8, device=ctx.red_dev)  # rank-major
+
+    def step():
+        if not bin_sharded:
+            eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
+                                capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), t_best.data_ptr(), t_dec.data_ptr(),
+                                t_st.data_ptr(), stream)
+            return
+        # partial maxima of this rank's columns -> all_gather over xGMI -> decision over the gathered tables.
+        # Everything is ordered on `side` (the collective is enqueued with `side` current: RCCL's own stream waits for
+        # it and `side` waits for the collective); the host never waits inside a step.
+        eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
+                            capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), None, None, None, stream)
+        with torch.cuda.stream(side):
+            if ctx.backend == "nccl":
+                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8))
+                parts = t_all
+            else:  # gloo test hook: through the host
+                side.synchronize()
+                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8).cpu())
+                parts = t_all.to(dev, non_blocking=False)
+        eng.decide_device_parts(parts.data_ptr(), world, n_reads * nf, t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
+                                capi.RB_MODE_CHECK_UNBLOCK, t_best.data_ptr(), t_dec.data_ptr(), t_st.data_ptr(), stream)
+        if ctx.backend != "nccl":
+            side.synchronize()  # `parts` is a temporary of this step
+
+    # the inputs were produced on torch's default stream; the steps run on `side` (non-blocking): order them
+    torch.cuda.synchronize()
+    setup_s = time.time() - t_setup
+    # ---------------------------------------------------------------- warm-up + timed region
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    eng.set_timing(True)  # hipEvent pairs around the count kernels, on the launch stream, no sync
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0  # this rank's own time for its K steps
+    ctx.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, n_calls = eng.kernel_time()
+    eng.set_timing(False)
+    elapsed = ctx.max_over_ranks([elapsed])[0]
+    per_rank_s = ctx.gather_floats(t_local)
+    total_reads = n_reads * (1 if bin_sharded else world) * steps
+    value = total_reads / elapsed
+
+    result = None
+    decisions = None
+    if rank == 0:
+        avg_kernel_s = (kernel_ms / max(1, n_calls)) / 1e3
+        achieved = bytes_per_read * n_reads / avg_kernel_s / 1e9
+        if bin_sharded:
+            achieved /= world  # every rank gathers its share of the word columns of every block
+        # fabric-side traffic of one launch: NOT measured in this run -- rocprofv3 --pmc passes of an earlier run of the
+        # same workload (profiles/collect_pmc.sh), kept in profiles/traffic.json and replayed here per read
+        traffic, traffic_source = None, None
+        tj = load_json("traffic.json").get(name, {})
+        if tj.get("hbm_bytes_per_read") and not bin_sharded and read_len == default_len:
+            traffic = tj["hbm_bytes_per_read"] * n_reads
+            traffic_source = "replayed: profiles/traffic.json (%s), per read x reads per launch" % tj.get("source", "rocprofv3 --pmc, separate passes")
+        probe = load_json("ceilings.json").get(name, {})
+        decisions = t_dec.cpu().numpy()
+
+        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- to eight-word blocks with a
+        # table of 6-32 MiB (or one-word blocks of any size) take the phased kernel, everything else the plain one
+        def phased(f):
+            tb = f.info["n_blocks"] * f.device_stride() * 8
+            return f.info["bin_width"] <= 8 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= (32 << 20) or f.info["bin_width"] == 1)
+        forms = {("ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel") for f in filters}
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                "kernel": " + ".join(sorted(forms)), "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_read": bytes_per_read,
+                "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
+        if probe.get("GBps"):
+            # the same access pattern with no compute attached (profiles/hbm_peak.hip / gather_probe.hip): a reference
+            # point for what this chip delivers on the pattern, NOT an upper bound (K1 keeps more gathers in flight)
+            roof["no_compute_probe_GBps"] = probe["GBps"]
+            roof["vs_no_compute_probe"] = achieved / probe["GBps"]
+            roof["no_compute_probe_source"] = probe.get("source")
+        table_bytes = sum(f.info["n_words"] * 8 for f in filters)
+        if table_bytes < (256 << 20) * 4:
+            roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
+                            "`traffic` counts L2->fabric requests, Infinity-Cache hits included, so this is a fabric "
+                            "figure -- the HBM-bound case is config 3 (the headline)" % (table_bytes / 1e9))
+        result = {
+            "metric": METRIC, "value": value, "unit": "reads/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if bin_sharded else "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": wname, "reads_per_gpu_per_step": n_reads, "launches_per_step": 1, "read_len": read_len,
+                       "filters": [{"n_bins": g[0], "k": g[1], "h": g[2], "bytes": f.info["n_words"] * 8}
+                                   for g, f in zip(geo, filters)],
+                       "parallelism": ("bin-sharded x%d, all_gather of u16 partial maxima, max taken in the decision "
+                                       "kernel" % world) if bin_sharded
+                       else "read-sharded x%d, IBF replicated" % world,
+                       "decisions": np.bincount(decisions, minlength=3).tolist()},
+            "per_rank_reads_per_s": [n_reads * steps / x for x in per_rank_s],
+            "roofline": roof,
+            "setup_s": setup_s,
+        }
+        if os.environ.get("RB_BENCH_DUMP_DECISIONS"):  # tests compare the N-rank decisions with the 1-rank run
+            import hashlib
+            result["config"]["decisions_sha1"] = hashlib.sha1(decisions.tobytes()).hexdigest()
+
+    # ---------------------------------------------------------------- parity check + CPU baseline (rank 0)
+    buf = None
+    if rank == 0:
+        cap = min(n_reads, 1 << 21)  # host copy of the head of the batch: CPU baseline, parity, latency legs
+        buf = t_seq[: cap * read_len].cpu().numpy()
+    if rank == 0 and not args.no_cpu_baseline and cpu_seconds > 0:
+        from oracle import pyoracle as po
+        keep = []
+        views = []
+        for f in filters:
+            h = f.download()
+            keep.append(h)
+            views.append(po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"],
+                                           h.words()))
+        od, ot = views[:len(deplete)], views[len(deplete):]
+        cores = host_cores()
+        cap = len(buf) // read_len
+        if world == 1 and not ctx.force_group:
+            # the CPU baseline proper (N = 1 only): a bounded sample of the same batch, all granted cores
+            pilot = min(cap, 64 * min(cores, 64))
+            tp = time.perf_counter()
+            po.batch_check_unblock(od, ot, buf, offs[:pilot], lens[:pilot], n_threads=cores)
+            pilot_s = time.perf_counter() - tp
+            sample = int(min(cap, max(pilot, pilot * cpu_seconds / max(pilot_s, 1e-6))))
+            tp = time.perf_counter()
+            cpu_dec, cpu_st = po.batch_check_unblock(od, ot, buf, offs[:sample], lens[:sample], n_threads=cores)
+            cpu_s = time.perf_counter() - tp
+            t1 = time.perf_counter()
+            n1 = min(sample, max(16, int(sample / cores / 4)))
+            po.batch_check_unblock(od, ot, buf, offs[:n1], lens[:n1], n_threads=1)
+            one_s = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
+                                      "sample": "first %d reads of the same batch, oracle check_unblock, read-parallel "
+                                                "pthreads; single-thread rate %.1f reads/s on %d reads"
+                                                % (sample, n1 / one_s, n1),
+                                      "single_thread_reads_per_s": n1 / one_s}
+        else:
+            # N > 1: no CPU baseline (the contract times it at N = 1), but rank 0's decisions are still checked
+            sample = min(cap, max(1, args.check_reads))
+            cpu_dec, cpu_st = po.batch_check_unblock(od, ot, buf, offs[:sample], lens[:sample], n_threads=cores)
+            result["cpu_baseline"] = None
+        mism = int((decisions[:sample] != cpu_dec).sum())
+        result["parity"] = {"checked_reads": sample, "decision_mismatches": mism,
+                            "against": "oracle check_unblock on rank 0's first reads of the timed batch"}
+        if mism:
+            result["parity"]["error"] = "GPU decisions differ from the oracle"
+        del views, keep
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    # ---------------------------------------------------------------- per-read classify latency (small batches)
+    if rank == 0 and latency and not args.no_latency and not bin_sharded:
+        lat = {}
+        for mb in (64, 256, 1024):
+            m = min(mb, len(buf) // read_len)
+            sub = np.ascontiguousarray(buf[: m * read_len])
+            so, sl = offs[:m].copy(), lens[:m].copy()
+            for _ in range(5):
+                eng.classify(sub, so, sl)
+            ts = []
+            for _ in range(200):
+                a = time.perf_counter()
+                eng.classify(sub, so, sl)  # host buffers in, decisions back on the host
+                ts.append((time.perf_counter() - a) * 1e3)
+            ts = np.sort(np.array(ts))
+            lat[str(mb)] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99) - 1]),
+                            "reads_per_s": m / (float(ts[len(ts) // 2]) / 1e3)}
+        # PCIe-inclusive throughput of one large host-side batch (never `value`)
+        m = min(len(buf) // read_len, 1 << 20)
+        sub = np.ascontiguousarray(buf[: m * read_len])
+        so, sl = offs[:m].copy(), lens[:m].copy()
+        eng.classify(sub, so, sl)
+        a = time.perf_counter()
+        for _ in range(3):
+            eng.classify(sub, so, sl)
+        big_s = (time.perf_counter() - a) / 3
+        result["latency"] = {"what": "host-to-host rb_classify_batch wall time per micro-batch (H2D + kernels + D2H)",
+                             "by_batch": lat,
+                             "pcie_inclusive": {"batch_reads": m, "ms": big_s * 1e3, "reads_per_s": m / big_s,
+                                                "note": "pageable host buffers in, all outputs back"}}
+    ctx.barrier()
+    eng.destroy()
+    del t_seq, t_off, t_len, t_max, t_best, t_dec, t_st
+    torch.cuda.empty_cache()
+    return result
+
+
+def replay(ctx, live_leg=True):
     """BASELINE configs[4]: 48-flowcell replay.  Poisson chunk arrivals (rate/world per GPU), 360 bp each, deplete =
     GRCh38-scale IBF + target = mock-community IBF, full check_unblock.  The dispatcher is work-conserving: whenever
     the GPU is free it takes everything that has arrived (a micro-batch) through rb_classify_batch (host buffers in,
-    decisions back on the host).  Latency of a read = decision on the host - arrival."""
-    import time as _t
-    wd, wt = synth.WORKLOADS["c3"], synth.WORKLOADS["zymo"]
-    dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
-    tgt, ref_t = synth.build_device_filter(dev_index, wt, fill_seed=6, plant_seed=60)
-    eng = capi.Engine(dev_index, [dep], [tgt])
+    decisions back on the host).  Latency of a read = decision on the host - arrival.
+    Second leg (`live_step`): the same arrival rate through rb_live_process -- the step as the reference runs it
+    (adaptive_sampling.hpp:276-338): every read sends up to four 360 bp chunks 0.4 s apart, an undecided read's next chunk is
+    classified as the concatenation with what once_seen holds (720 / 1080 / 1440 bp: the 16-plane kernels)."""
+    from readbouncer_amd import capi, synth
+    args, torch, dist, world, rank = ctx.args, ctx.torch, ctx.dist, ctx.world, ctx.rank
+    dep, ref_d = ctx.filter("c3")
+    tgt, ref_t = ctx.filter("zymo")
+    eng = capi.Engine(ctx.dev_index, [dep], [tgt])
     if args.no_overlap:
         eng.set_overlap(False)
     rate = args.rate / world
-    n = int(rate * args.replay_seconds)
+    n = max(64, int(rate * args.replay_seconds / (TEST_DIVISOR if TEST_DIVISOR > 1 else 1)))
     read_len = 360
     ref = np.concatenate([ref_d, ref_t])
-    t_seq, _, _ = synth.make_reads_device(7000 + rank, n, read_len, ref, torch.device("cuda", dev_index))
+    t_seq, _, _ = synth.make_reads_device(7000 + rank, n, read_len, ref, ctx.dev)
     buf = t_seq.cpu().numpy()
     del t_seq
     rng = np.random.default_rng(7 + rank)
     arrival = np.cumsum(rng.exponential(1.0 / rate, size=n))
     offs0 = np.arange(n, dtype=np.uint64) * np.uint64(read_len)
     lens0 = np.full(n, read_len, dtype=np.uint32)
+    w1, w2 = min(n, 64), min(n, 4096)
     for _ in range(20):  # warm-up (allocations, threshold table, code objects of both kernel forms)
-        eng.classify(buf[: 64 * read_len], offs0[:64], lens0[:64])
-        eng.classify(buf[: 4096 * read_len], offs0[:4096], lens0[:4096])
-    if dist is not None:
-        dist.barrier()
+        eng.classify(buf[: w1 * read_len], offs0[:w1], lens0[:w1])
+        eng.classify(buf[: w2 * read_len], offs0[:w2], lens0[:w2])
+    ctx.barrier()
     # the dispatcher loop runs inside the library (rb_replay_arrivals, C++ spin on the steady clock): no interpreter
     # between an arrival and its call
     decisions, lat, batches, service, elapsed = eng.replay_arrivals(buf, read_len, arrival, max_batch=16384)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        stats = torch.tensor([np.percentile(lat, 50), np.percentile(lat, 99), np.percentile(lat, 99.9), lat.max()],
-                             dtype=torch.float64, device=red_dev)
-        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        p50, p99, p999, pmax = [float(x) for x in stats.tolist()]
-    else:
-        p50, p99, p999, pmax = [float(np.percentile(lat, q)) for q in (50, 99, 99.9)] + [float(lat.max())]
+    elapsed = ctx.max_over_ranks([elapsed])[0]
+    p50, p99, p999, pmax = ctx.max_over_ranks([np.percentile(lat, 50), np.percentile(lat, 99), np.percentile(lat, 99.9), lat.max()])
+    # parity of the replayed decisions: the same chunks as ONE batch through the engine
+    exp_dec = eng.classify(buf, offs0, lens0)[2]
+    replay_equal = bool(np.array_equal(exp_dec, decisions))
+
+    live = None
+    if live_leg:
+        # reads with four chunks each, 0.4 s apart (MinKNOW's break_reads_after_seconds, adaptive_sampling.hpp:634); the
+        # chunk stream keeps the total arrival rate.  A chunk of a read already decided starts that read afresh.
+        n_chunks = 4
+        n_live = max(n_chunks, (n // n_chunks) * n_chunks)
+        reads = n_live // n_chunks
+        # first chunks uniform over n_live / rate seconds: once all four chunk generations overlap (from 1.2 s on) the stream
+        # runs at the nominal rate; the replay lasts 1.2 s longer than the plain one
+        first = np.sort(rng.uniform(0.0, n_live / rate, size=reads))
+        arr = (first[:, None] + 0.4 * np.arange(n_chunks)[None, :]).reshape(-1)
+        ids = np.repeat(np.arange(reads, dtype=np.uint32), n_chunks)
+        order = np.argsort(arr, kind="stable")
+        arr, ids = arr[order], ids[order]
+        lbuf = np.resize(buf, n_live * read_len)  # chunk j of the stream = synthetic read j (positives and negatives mixed)
+        lv = capi.Live(eng)
+        warm = capi.Live(eng)
+        warm.process([b"w%d" % i for i in range(64)], [bytes(buf[i * read_len:(i + 1) * read_len]) for i in range(64)])
+        warm.process([b"w%d" % i for i in range(64)], [bytes(buf[i * read_len:(i + 1) * read_len]) for i in range(64)])  # concatenations
+        warm.destroy()
+        ctx.barrier()
+        act, llat, clen, lcalls, lservice, lelapsed = lv.replay_arrivals(ids, lbuf, read_len, arr, max_batch=16384)
+        lelapsed = ctx.max_over_ranks([lelapsed])[0]
+        l50, l99, l999, lmax = ctx.max_over_ranks([np.percentile(llat, 50), np.percentile(llat, 99), np.percentile(llat, 99.9), llat.max()])
+        if rank == 0:
+            live = {"what": "the same arrival rate through rb_live_process (once_seen, concatenation of undecided chunks, 1500 bp "
+                            "cut-off): 4 chunks of 360 bp per read, 0.4 s apart",
+                    "value": n_live * world / lelapsed, "unit": "chunks/s",
+                    "p50_ms": l50 * 1e3, "p99_ms": l99 * 1e3, "p99.9_ms": l999 * 1e3, "max_ms": lmax * 1e3,
+                    "slo_met": bool(l99 * 1e3 < 1.0),
+                    "classified_length_share": {str(L): float((clen == L).mean()) for L in (360, 720, 1080, 1440)},
+                    "concatenated_share": float((clen > read_len).mean()),
+                    "actions": np.bincount(act, minlength=3).tolist(), "still_pending": int(lv.pending()),
+                    "micro_batch_chunks": {"mean": float(np.mean(lcalls)), "max": int(np.max(lcalls))},
+                    "call_service_ms": {"p50": float(np.percentile(lservice, 50) * 1e3), "p99": float(np.percentile(lservice, 99) * 1e3),
+                                        "max": float(lservice.max() * 1e3)}}
+        lv.destroy()
+    result = None
     if rank == 0:
-        geo = [(8192, 13, 3), (600, 13, 3)]
         result = {
             "metric": "reads/sec (360bp chunks through check_unblock, live replay) + p99 classify latency",
             "value": n * world / elapsed, "unit": "reads/s", "n_gpus": world, "steps": len(batches), "warmup": 40,
@@ -245,78 +587,146 @@ def replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist):
             "latency": {"what": "arrival -> decision on the host, per read (queueing + H2D + kernels + D2H)",
                         "p50_ms": p50 * 1e3, "p99_ms": p99 * 1e3, "p99.9_ms": p999 * 1e3, "max_ms": pmax * 1e3,
                         "slo_p99_ms": 1.0, "slo_met": bool(p99 * 1e3 < 1.0)},
+            "parity": {"replayed_decisions_equal_one_batch": replay_equal, "checked_reads": int(n)},
+            "live_step": live,
             "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                         "traffic": None, "note": "latency-bound regime; the throughput roofline is reported by c2/c3/c4"},
+                         "traffic": None, "note": "latency-bound regime; the throughput roofline is reported by c3/c4"},
             "cpu_baseline": None,
         }
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.barrier()
+    eng.destroy()
+    return result
+
+
+def rank_diagnostics(ctx, setup_s):
+    """What the first run on a multi-GPU node needs in order to explain itself: which device every rank drove, whether the
+    devices can reach each other as peers, how long the filters took to stand up -- and, on rank 0 of a node with more than
+    one visible GPU, ONE device-to-device replica of the small c2 filter onto the next GPU (rb_dibf_clone_to_ex: the xGMI
+    peer branch that a one-GPU box can never execute), timed and verified, before anything is measured.  Never fatal."""
+    torch = ctx.torch
+    me = {"rank": ctx.rank, "device": ctx.dev_index, "filter_setup_s": round(ctx.filter_setup_s, 3), "setup_s": round(setup_s, 3)}
+    try:
+        p = torch.cuda.get_device_properties(ctx.dev_index)
+        me["name"] = p.name
+        for k in ("pci_bus_id", "pci_device_id", "uuid", "total_memory", "multi_processor_count"):
+            if hasattr(p, k):
+                v = getattr(p, k)
+                me[k] = v if isinstance(v, (int, float)) else str(v)
+        n_vis = torch.cuda.device_count()
+        me["visible_devices"] = n_vis
+        me["peer_access_possible"] = [bool(torch.cuda.can_device_access_peer(ctx.dev_index, j)) if j != ctx.dev_index else None
+                                      for j in range(n_vis)]
+    except Exception as ex:  # noqa: BLE001
+        me["error"] = "%s: %s" % (type(ex).__name__, str(ex)[:160])
+    if ctx.dist is None:
+        return [me]
+    out = [None] * ctx.world
+    try:
+        ctx.dist.all_gather_object(out, me)
+    except Exception as ex:  # noqa: BLE001
+        out = [me, {"error": "all_gather_object: %s" % str(ex)[:160]}]
+    return out
+
+
+def xgmi_preflight(ctx):
+    """rank 0, before the measurements: replicate the 0.41 GB c2 filter to the next visible GPU device to device and compare
+    it there (rb_pool_create_from_files does this for every filter of a one-process pool).  Reports, never raises."""
+    from readbouncer_amd import capi
+    torch = ctx.torch
+    try:
+        n_vis = torch.cuda.device_count()
+        if n_vis < 2 or ctx.same_gpu:
+            return {"ran": False, "why": "one visible GPU" if n_vis < 2 else "same-GPU test hook"}
+        src, _ = ctx.filter("c2")
+        dst_dev = (ctx.dev_index + 1) % n_vis
+        replica, used_peer, secs = src.clone_to_ex(dst_dev)
+        moved = src.info["n_blocks"] * src.device_stride() * 8
+        back, _, _ = replica.clone_to_ex(ctx.dev_index)  # and home again, so that the comparison runs on one device
+        cmp_ = src.compare(back)
+        ok = cmp_["new_bits"] == 0 and cmp_["file_bits"] == cmp_["rebuilt_bits"]
+        replica.free()
+        back.free()
+        torch.cuda.set_device(ctx.dev_index)
+        return {"ran": True, "from": ctx.dev_index, "to": dst_dev, "peer_access_granted": used_peer, "bytes": int(moved),
+                "seconds": secs, "GBps": moved / max(secs, 1e-9) / 1e9, "round_trip_bit_identical": bool(ok)}
+    except Exception as ex:  # noqa: BLE001
+        try:
+            torch.cuda.set_device(ctx.dev_index)
+        except Exception:
+            pass
+        return {"ran": False, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
 def null_engine_run(args, torch, dist, world, rank, backend):
     """Control-flow test hook (RB_BENCH_ENGINE=none, set only by tests/): the rank flow of this script -- rendezvous,
-    barriers, max-over-ranks timing, the per-rank gather, the all-gather + max of the bin-sharded layout and the JSON
-    line -- with NO classification behind it, so that `bench.py --gpus 2` can be exercised on a box without a GPU.
-    There is no CPU implementation of the hot path: the line says so and its value means nothing."""
+    barriers, max-over-ranks timing, the per-rank gather, the all-gather + max of the bin-sharded layout, the headline +
+    other_configs structure of the JSON line -- with NO classification behind it, so that `bench.py --gpus 2` can be exercised
+    on a box without a GPU.  There is no CPU implementation of the hot path: the line says so and its values mean nothing."""
     n_reads = args.reads or 1000
     nf = 2
+    note = "none (control-flow test hook RB_BENCH_ENGINE=none: no classification ran, the value is meaningless)"
 
     def partial(r):  # what rank r "counted": deterministic, different per rank
         i = np.arange(n_reads * nf, dtype=np.uint64)
         return ((i * np.uint64(2654435761) + np.uint64(r) * np.uint64(40503)) % np.uint64(65536)).astype(np.uint16).reshape(n_reads, nf)
 
-    reduce_ok = None
+    def leg(name, steps, sharded):
+        reduce_ok = None
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            if sharded and dist is not None:
+                mine = torch.from_numpy(partial(rank).view(np.uint8).copy())  # bytes: an all-gather does no arithmetic
+                gathered = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8)
+                dist.all_gather_into_tensor(gathered, mine)
+                got = gathered.numpy().view(np.uint16).reshape(world, n_reads, nf).max(axis=0)
+                exp = np.maximum.reduce([partial(r) for r in range(world)])
+                reduce_ok = bool(np.array_equal(got, exp)) and (reduce_ok is not False)
+            time.sleep(0.002)
+        t_local = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        per_rank = [t_local]
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            g = torch.zeros(world, dtype=torch.float64)
+            dist.all_gather_into_tensor(g, torch.tensor([t_local], dtype=torch.float64))
+            per_rank = g.tolist()
+        total = n_reads * (1 if sharded else world) * steps
+        return {"metric": METRIC, "value": total / elapsed, "unit": "reads/s", "n_gpus": world, "steps": steps,
+                "warmup": args.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+                "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "engine": note, "config": {"workload": "rank-flow test (%s)" % name, "reads_per_gpu_per_step": n_reads},
+                "per_rank_reads_per_s": [n_reads * steps / x for x in per_rank],
+                "bin_sharded_reduce_ok": reduce_ok, "roofline": None, "cpu_baseline": None, "parity": None}
+
     if dist is not None:
         dist.barrier()
     if os.environ.get("RB_BENCH_TEST_DIE_RANK") == str(rank):  # tests: the launcher must not hang on a dead rank
         os._exit(7)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if args.bin_sharded and dist is not None:
-            mine = torch.from_numpy(partial(rank).view(np.uint8).copy())  # bytes: an all-gather does no arithmetic
-            gathered = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8)
-            dist.all_gather_into_tensor(gathered, mine)
-            got = gathered.numpy().view(np.uint16).reshape(world, n_reads, nf).max(axis=0)
-            exp = np.maximum.reduce([partial(r) for r in range(world)])
-            reduce_ok = bool(np.array_equal(got, exp)) and (reduce_ok is not False)
-        time.sleep(0.002)
-    t_local = time.perf_counter() - t0
+    head = leg(args.workload or "c3", args.steps, args.bin_sharded)
+    others = {}
+    if not args.workload and not args.bin_sharded and not args.no_extras:
+        for name in ("c2", "c4", "c5", "readme"):
+            others[name] = leg(name, 1, False)
+    infos = [{"rank": rank, "device": None}]
     if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    per_rank = [t_local]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        g = torch.zeros(world, dtype=torch.float64)
-        dist.all_gather_into_tensor(g, torch.tensor([t_local], dtype=torch.float64))
-        per_rank = g.tolist()
+        infos = [None] * world
+        dist.all_gather_object(infos, {"rank": rank, "device": None})
     if rank == 0:
-        total = n_reads * (1 if args.bin_sharded else world) * args.steps
-        print(json.dumps({
-            "metric": "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)", "value": total / elapsed,
-            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if args.bin_sharded else "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "engine": "none (control-flow test hook RB_BENCH_ENGINE=none: no classification ran, the value is meaningless)",
-            "config": {"workload": "rank-flow test", "reads_per_gpu_per_step": n_reads},
-            "ranks": {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0, "self_launched":
-                      os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
-                      "per_rank_reads_per_s": [n_reads * args.steps / x for x in per_rank]},
-            "bin_sharded_reduce_ok": reduce_ok, "roofline": None, "cpu_baseline": None}))
+        head["ranks"] = {"backend": backend, "rccl_ranks": world if backend == "nccl" else 0,
+                         "self_launched": os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1", "devices": infos,
+                         "per_rank_reads_per_s": head["per_rank_reads_per_s"], "xgmi_preflight": {"ran": False, "why": "no engine"}}
+        if others:
+            head["other_configs"] = others
+        print(json.dumps(head))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def load_json(name):
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
-    except Exception:
-        return {}
 
 
 def main():
@@ -325,6 +735,7 @@ def main():
         return launch_ranks(args.gpus)  # before anything touches the GPU
     import torch
 
+    t_start = time.time()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -354,296 +765,58 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if no_engine:
         return null_engine_run(args, torch, dist, world, rank, backend)
-    from readbouncer_amd import capi, synth
     torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
-
-    # ---------------------------------------------------------------- workload (untimed set-up)
-    t_setup = time.time()
-    if args.workload == "c5":
-        return replay(args, torch, capi, synth, world, rank, dev_index, red_dev, dist)
-    if args.workload == "c4":
-        wd, wt = synth.WORKLOADS["c3"], synth.WORKLOADS["zymo"]
-        dep, ref_d = synth.build_device_filter(dev_index, wd, fill_seed=4, plant_seed=40)
-        tgt, ref_t = synth.build_device_filter(dev_index, wt, fill_seed=6, plant_seed=60)
-        deplete, target = [dep], [tgt]
-        ref = np.concatenate([ref_d, ref_t])
-        wname = "config4: deplete=GRCh38-scale IBF (8192 bins, 8 GiB) + target=Zymo-mock-like IBF (600 bins), check_unblock"
-        n_reads = args.reads or 2_000_000
-        read_len = 360
-    elif args.workload == "readme":
-        # the reference's own (only) published benchmark shape: README.md:254-262, 250 bp prefixes, 1 deplete + 3 targets
-        deplete, target, refs = [], [], []
-        for i, key in enumerate(("mock_deplete", "mock_t1", "mock_t2", "mock_t3")):
-            f, r = synth.build_device_filter(dev_index, synth.WORKLOADS[key], fill_seed=11 + i, plant_seed=110 + i, n_segments=512)
-            (deplete if i == 0 else target).append(f)
-            refs.append(r)
-        ref = np.concatenate(refs)
-        wname = ("README benchmark shape: 250bp prefixes vs 1 deplete (122 bins) + 3 target (43/29/49 bins) IBFs, k=13, "
-                 "F=100000, check_unblock")
-        n_reads = args.reads or 1_000_000
-        read_len = 250
-    else:
-        w = synth.WORKLOADS[args.workload]
-        seeds = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60),
-                 "grch38_f100k": (8, 80), "zymo16": (6, 60)}[args.workload]
-        dep, ref = synth.build_device_filter(dev_index, w, fill_seed=seeds[0], plant_seed=seeds[1])
-        deplete, target = [dep], []
-        wname = w["name"]
-        n_reads = args.reads or w["reads"]
-        if args.workload in ("c3", "c3np2") and not args.reads:
-            n_reads = 2_000_000  # per step; BASELINE's 10 M reads are five such steps (3.6 GB of read bytes per 10 M)
-        read_len = w["read_len"]
-        if n_reads != w["reads"]:
-            wname += " [%d reads per step]" % n_reads
-    if args.read_len:
-        read_len = args.read_len
-    filters = deplete + target
-    nf = len(filters)
-    geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in filters]
-    bytes_per_read = synth.algorithmic_bytes_per_read(read_len, geo)
-
-    # reads are generated on the device (plumbing) and stay resident in HBM
-    t_seq, t_off, t_len = synth.make_reads_device(1000 + rank, n_reads, read_len, ref, dev)
-    lens = np.full(n_reads, read_len, dtype=np.uint32)
-    offs = np.arange(n_reads, dtype=np.uint64) * np.uint64(read_len)
-    t_max = torch.zeros((n_reads, nf), dtype=torch.int16, device=dev)
-    t_best = torch.zeros(n_reads, dtype=torch.int32, device=dev)
-    t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
-    t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
-    eng = capi.Engine(dev_index, deplete, target)
-    if args.no_overlap:
-        eng.set_overlap(False)
-    if args.serial_table_mib >= 0:
-        eng.set_serial_table_bytes(args.serial_table_mib << 20)
-    if args.phased == "off":
-        eng.set_phased(0, 0, 0, 0, 0)
-    elif args.phased:
-        lo, hi, base, tk = [int(x) for x in args.phased.split(",")]
-        eng.set_phased(lo << 20, hi << 20, base, tk, 1024)  # "0,0,300,3": plain gathers, but the short-read kernel for one-word filters
-    # a dedicated non-null stream: steps are queued asynchronously; torch.cuda.synchronize() covers it
-    side = torch.cuda.Stream(device=dev)
-    stream = side.cuda_stream
-    max_len = int(lens.max())
-
+    ctx = Ctx(args, torch, dist, world, rank, dev_index, backend, same_gpu, force_group)
     bin_sharded = args.bin_sharded and (world > 1 or force_group)
-    if bin_sharded:
-        # every rank classifies the SAME reads (seed of rank 0) against its column slice of every filter
-        t_seq, t_off, t_len = synth.make_reads_device(1000, n_reads, read_len, ref, dev)
-        eng.set_column_shard(rank, world)
-        # the u16 partial maxima of all ranks, all-gathered as they are (byte view: an all-gather does no arithmetic, so
-        # there is no widening for the collective and half the bytes of an int32 all-reduce); the max over the ranks is
-        # taken inside the decision kernel
-        t_all = torch.zeros((world * n_reads, nf * 2), dtype=torch.uint8, device=red_dev)  # rank-major
 
-    def step():
-        if not bin_sharded:
-            eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
-                                capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), t_best.data_ptr(), t_dec.data_ptr(),
-                                t_st.data_ptr(), stream)
-            return
-        # partial maxima of this rank's columns -> all_gather over xGMI -> decision over the gathered tables.
-        # Everything is ordered on `side` (the collective is enqueued with `side` current: RCCL's own stream waits for
-        # it and `side` waits for the collective); the host never waits inside a step.
-        eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
-                            capi.RB_MODE_CHECK_UNBLOCK, t_max.data_ptr(), None, None, None, stream)
-        with torch.cuda.stream(side):
-            if backend == "nccl":
-                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8))
-                parts = t_all
-            else:  # gloo test hook: through the host
-                side.synchronize()
-                dist.all_gather_into_tensor(t_all, t_max.view(torch.uint8).cpu())
-                parts = t_all.to(dev, non_blocking=False)
-        eng.decide_device_parts(parts.data_ptr(), world, n_reads * nf, t_len.data_ptr(), n_reads, max_len, 0.1, 0.95,
-                                capi.RB_MODE_CHECK_UNBLOCK, t_best.data_ptr(), t_dec.data_ptr(), t_st.data_ptr(), stream)
-        if backend != "nccl":
-            side.synchronize()  # `parts` is a temporary of this step
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # the inputs were produced on torch's default stream; the steps run on `side` (non-blocking): order them
-    torch.cuda.synchronize()
-    setup_s = time.time() - t_setup
-    # ---------------------------------------------------------------- warm-up + timed region
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    eng.set_timing(True)  # hipEvent pairs around the count kernels, on the launch stream, no sync
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0  # this rank's own time for its K steps
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms, n_calls = eng.kernel_time()
-    eng.set_timing(False)
-    per_rank_s = [t_local]
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        g = torch.zeros(world, dtype=torch.float64, device=red_dev)
-        dist.all_gather_into_tensor(g, torch.tensor([t_local], dtype=torch.float64, device=red_dev))
-        per_rank_s = g.tolist()
-    total_reads = n_reads * (1 if bin_sharded else world) * args.steps
-    value = total_reads / elapsed
-
-    result = None
-    if rank == 0:
-        avg_kernel_s = (kernel_ms / max(1, n_calls)) / 1e3
-        achieved = bytes_per_read * n_reads / avg_kernel_s / 1e9
-        if bin_sharded:
-            achieved /= world  # every rank gathers its share of the word columns of every block
-        # fabric-side traffic of one launch: NOT measured in this run -- rocprofv3 --pmc passes of an earlier run of the
-        # same workload (profiles/collect_pmc.sh), kept in profiles/traffic.json and replayed here per read
-        traffic, traffic_source = None, None
-        tj = load_json("traffic.json").get(args.workload, {})
-        if tj.get("hbm_bytes_per_read") and not bin_sharded:
-            traffic = tj["hbm_bytes_per_read"] * n_reads
-            traffic_source = "profiles/traffic.json (%s)" % tj.get("source", "rocprofv3 --pmc, separate passes, round 1")
-        ceil = load_json("ceilings.json").get(args.workload, {})
-        decisions = t_dec.cpu().numpy()
-        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- to eight-word blocks with a
-        # table of 6-32 MiB (or one-word blocks of any size) take the phased kernel, everything else the plain one
-        def phased(f):
-            tb = f.info["n_blocks"] * f.device_stride() * 8
-            return f.info["bin_width"] <= 8 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= (32 << 20) or f.info["bin_width"] == 1)
-        forms = {("ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel") for f in filters}
-        kernel_name = " + ".join(sorted(forms))
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
-                "algorithmic_bytes_per_read": bytes_per_read,
-                "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
-        if ceil.get("GBps"):
-            # the same access pattern with no compute attached (profiles/hbm_peak.hip): what this chip delivers for it
-            roof["measured_ceiling"] = ceil["GBps"]
-            roof["frac_of_measured_ceiling"] = achieved / ceil["GBps"]
-            roof["measured_ceiling_source"] = ceil.get("source")
-        table_bytes = sum(f.info["n_words"] * 8 for f in filters)
-        if table_bytes < (256 << 20) * 4:
-            roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
-                            "`traffic` counts L2->fabric requests, Infinity-Cache hits included, so this is a fabric "
-                            "figure -- the HBM-bound case is config 3 (`hbm_bound_config`)" % (table_bytes / 1e9))
-        result = {
-            "metric": "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)",
-            "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if bin_sharded else "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": wname, "reads_per_gpu_per_step": n_reads, "read_len": read_len,
-                       "filters": [{"n_bins": g[0], "k": g[1], "h": g[2], "bytes": f.info["n_words"] * 8}
-                                   for g, f in zip(geo, filters)],
-                       "parallelism": ("bin-sharded x%d, all_gather of u16 partial maxima, max taken in the decision "
-                                       "kernel" % world) if bin_sharded
-                       else "read-sharded x%d, IBF replicated" % world,
-                       "decisions": np.bincount(decisions, minlength=3).tolist()},
-            "ranks": {"backend": backend, "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,
-                      "self_launched": os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
-                      "same_gpu_test_hook": same_gpu,
-                      "per_rank_reads_per_s": [n_reads * args.steps / x for x in per_rank_s]},
-            "roofline": roof,
-            "setup_s": setup_s,
-        }
-        if os.environ.get("RB_BENCH_DUMP_DECISIONS"):  # tests compare the N-rank decisions with the 1-rank run
-            import hashlib
-            result["config"]["decisions_sha1"] = hashlib.sha1(decisions.tobytes()).hexdigest()
-
-    # ---------------------------------------------------------------- parity check + CPU baseline (rank 0, N=1)
-    buf = None
-    if rank == 0:
-        cap = min(n_reads, 1 << 21)  # host copy of the head of the batch: CPU baseline, parity, latency legs
-        buf = t_seq[: cap * read_len].cpu().numpy()
-    if rank == 0 and world == 1 and not force_group and not args.no_cpu_baseline:
-        from oracle import pyoracle as po
-        keep = []
-        views = []
-        for f in filters:
-            h = f.download()
-            keep.append(h)
-            views.append(po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"],
-                                           h.words()))
-        od, ot = views[:len(deplete)], views[len(deplete):]
-        cores = host_cores()
-        cap = len(buf) // read_len
-        pilot = min(cap, 64 * min(cores, 64))
-        tp = time.perf_counter()
-        po.batch_check_unblock(od, ot, buf, offs[:pilot], lens[:pilot], n_threads=cores)
-        pilot_s = time.perf_counter() - tp
-        sample = int(min(cap, max(pilot, pilot * args.cpu_seconds / max(pilot_s, 1e-6))))
-        tp = time.perf_counter()
-        cpu_dec, cpu_st = po.batch_check_unblock(od, ot, buf, offs[:sample], lens[:sample], n_threads=cores)
-        cpu_s = time.perf_counter() - tp
-        t1 = time.perf_counter()
-        n1 = min(sample, max(16, int(sample / cores / 4)))
-        po.batch_check_unblock(od, ot, buf, offs[:n1], lens[:n1], n_threads=1)
-        one_s = time.perf_counter() - t1
-        gpu_dec = decisions[:sample]
-        mism = int((gpu_dec != cpu_dec).sum())
-        result["cpu_baseline"] = {"value": sample / cpu_s, "unit": "reads/s", "cores": cores, "kind": "port",
-                                  "sample": "first %d reads of the same batch, oracle check_unblock, read-parallel "
-                                            "pthreads; single-thread rate %.1f reads/s on %d reads"
-                                            % (sample, n1 / one_s, n1),
-                                  "single_thread_reads_per_s": n1 / one_s}
-        result["parity"] = {"checked_reads": sample, "decision_mismatches": mism}
-        if mism:
-            result["parity"]["error"] = "GPU decisions differ from the oracle"
-    elif rank == 0:
-        result["cpu_baseline"] = None
-
-    # ---------------------------------------------------------------- per-read classify latency (small batches)
-    if rank == 0 and not args.no_latency and not bin_sharded:
-        lat = {}
-        for mb in (64, 256, 1024):
-            m = min(mb, len(buf) // read_len)
-            sub = np.ascontiguousarray(buf[: m * read_len])
-            so, sl = offs[:m].copy(), lens[:m].copy()
-            for _ in range(5):
-                eng.classify(sub, so, sl)
-            ts = []
-            for _ in range(200):
-                a = time.perf_counter()
-                eng.classify(sub, so, sl)  # host buffers in, decisions back on the host
-                ts.append((time.perf_counter() - a) * 1e3)
-            ts = np.sort(np.array(ts))
-            lat[str(mb)] = {"p50_ms": float(ts[len(ts) // 2]), "p99_ms": float(ts[int(len(ts) * 0.99) - 1]),
-                            "reads_per_s": m / (float(ts[len(ts) // 2]) / 1e3)}
-        # PCIe-inclusive throughput of one large host-side batch (never `value`)
-        m = min(len(buf) // read_len, 1 << 20)
-        sub = np.ascontiguousarray(buf[: m * read_len])
-        so, sl = offs[:m].copy(), lens[:m].copy()
-        eng.classify(sub, so, sl)
-        a = time.perf_counter()
-        for _ in range(3):
-            eng.classify(sub, so, sl)
-        big_s = (time.perf_counter() - a) / 3
-        result["latency"] = {"what": "host-to-host rb_classify_batch wall time per micro-batch (H2D + kernels + D2H)",
-                             "by_batch": lat,
-                             "pcie_inclusive": {"batch_reads": m, "ms": big_s * 1e3, "reads_per_s": m / big_s,
-                                                "note": "pageable host buffers in, all outputs back"}}
-
+    if args.workload == "c5":
+        result = replay(ctx)
+        extras = False
+    else:
+        name = args.workload or "c3"
+        extras = not args.workload and not args.reads and not args.read_len and not args.no_extras and not bin_sharded
+        pre = xgmi_preflight(ctx) if (rank == 0 and extras) else {"ran": False, "why": "default run on rank 0 only"}
+        result = run_throughput(ctx, name, n_reads=args.reads, read_len=args.read_len, latency=True, bin_sharded=bin_sharded)
+        infos = rank_diagnostics(ctx, time.time() - t_start)
+        if rank == 0:
+            result["ranks"] = {"backend": backend if dist is not None else None,
+                               "rccl_ranks": world if (backend == "nccl" and world > 1) else 0,
+                               "self_launched": os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
+                               "same_gpu_test_hook": same_gpu, "devices": infos,
+                               "per_rank_reads_per_s": result.pop("per_rank_reads_per_s"), "xgmi_preflight": pre}
+    if extras:
+        # the other BASELINE configs, by all ranks, after the headline measurement; a failure is reported, never raised
+        others = {}
+        legs = [("c4", lambda: run_throughput(ctx, "c4", cpu_seconds=8.0)),
+                ("c5", lambda: replay(ctx)),
+                ("c2", lambda: run_throughput(ctx, "c2", cpu_seconds=5.0)),
+                ("readme", lambda: run_throughput(ctx, "readme", cpu_seconds=5.0)),
+                # the README filters at the north star's read length
+                ("readme_360bp", lambda: run_throughput(ctx, "readme", read_len=360, steps=min(args.steps, 5), warmup=1, cpu_seconds=0))]
+        for lname, fn in legs:
+            try:
+                r = fn()
+            except Exception as ex:  # noqa: BLE001
+                if world > 1:
+                    raise  # a rank that drops out of the collectives would hang the others: fail the whole job loudly
+                r = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            if rank == 0:
+                if isinstance(r, dict):
+                    r.pop("per_rank_reads_per_s", None)
+                others[lname] = r
+        if rank == 0:
+            result["other_configs"] = others
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and world == 1 and not force_group and args.workload == "c2" and not args.reads and not args.read_len and not args.no_extras:
-        # free this process's filters and reads first: the children need the HBM (config 3 alone is 8 GiB + reads)
-        del eng, t_seq, t_off, t_len, t_max, t_best, t_dec, t_st
-        for f in filters:
-            f.free()
-        torch.cuda.empty_cache()
-        hb, others = other_configs(args)
-        result["hbm_bound_config"] = hb
-        result["other_configs"] = others
     if rank == 0:
+        if TEST_DIVISOR > 1:
+            result["test_reads_divisor"] = TEST_DIVISOR
         print(json.dumps(result))
-        if result.get("parity", {}).get("decision_mismatches"):
+        bad = bool(result.get("parity", {}) and result["parity"].get("decision_mismatches"))
+        for r in (result.get("other_configs") or {}).values():
+            bad |= bool(isinstance(r, dict) and r.get("parity") and r["parity"].get("decision_mismatches"))
+        if bad:
             sys.exit(3)
 
 

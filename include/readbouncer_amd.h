@@ -117,6 +117,9 @@ RB_API int rb_dibf_download(const rb_dibf *f, rb_ibf **out);
 /* replica of a resident filter on another GPU (or the same one), copied device to device -- over xGMI when the pair
  * has peer access -- in its HBM layout: no host image, no conversion */
 RB_API int rb_dibf_clone_to(const rb_dibf *src, int device, rb_dibf **out);
+/* the same, reporting how the copy travelled: *used_peer = 1 when the destination mapped the source (peer access, xGMI
+ * between two GPUs of a node), 0 for the runtime's staged path or a same-device copy; *seconds = wall time of the copy */
+RB_API int rb_dibf_clone_to_ex(const rb_dibf *src, int device, rb_dibf **out, int *used_peer, double *seconds);
 RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
 RB_API void *rb_dibf_device_words(rb_dibf *f);
 /* words between consecutive blocks of the device image (see above) */
@@ -208,7 +211,9 @@ RB_API void rb_host_free(void *p);
 
 /* Same with every buffer already resident in HBM (device pointers) and asynchronous on
  * `stream` (a hipStream_t, NULL = the engine's own stream, which is then synchronised
- * before returning).  max_len = an upper bound of lens[] (a longer read gets status RB_ERR_INVALID_ARG).  The inputs must be complete on `stream`
+ * before returning).  max_len = an upper bound of lens[]: a longer read gets status RB_ERR_INVALID_ARG, and its row of
+ * d_maxcount is then UNDEFINED (the narrow-filter kernels are built per max_len and write 0 for it) -- callers that consume raw
+ * maxima without the decision stage (the bin-sharded layout) must not understate it.  The inputs must be complete on `stream`
  * (work that produces them on another stream has to be ordered before this call by the caller).  An engine's
  * workspaces (partial maxima, threshold tables, arrival counters) are per engine: calls on one engine may come from
  * several threads, but their GPU work must be ordered -- use one stream per engine, or order the streams with events;
@@ -322,6 +327,16 @@ RB_API int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len,
                               size_t max_batch, double error_rate, double significance, uint8_t *out_decision,
                               double *out_latency_s, uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap,
                               size_t *out_calls, double *out_elapsed_s);
+/* (max_batch is clamped to min(max_batch, n, 2^20); arrival_s that is not ascending is RB_ERR_INVALID_ARG; the dispatcher
+ * spins on the steady clock between arrivals -- it owns a core for the length of the replay, like the reference's
+ * classification thread polling its queue, adaptive_sampling.hpp:226-228.)
+ * The same dispatcher in front of the live step: chunk i belongs to read read_ids[i] and goes through rb_live_process, so
+ * an undecided read's next chunk is classified as the concatenation with what once_seen holds (up to the cut-off, i.e.
+ * reads of up to ~1.9 kbp) -- adaptive_sampling.hpp:276-338.  out_action as rb_live_process. */
+RB_API int rb_live_replay_arrivals(rb_live *lv, const uint32_t *read_ids, const char *seqs, uint32_t read_len, size_t n,
+                                   const double *arrival_s, size_t max_batch, uint8_t *out_action, double *out_latency_s,
+                                   uint32_t *out_classified_len, uint32_t *out_call_reads, double *out_call_service_s,
+                                   size_t call_cap, size_t *out_calls, double *out_elapsed_s);
 
 /* What the reverse strand holds where the read has an N.  The reference counts the second strand on
  * ModifiedString<ModifiedString<Dna5String, ModComplementDna>, ModReverse> (src/IBF/IBF.hpp:96-97, used at

@@ -102,6 +102,9 @@ SIGNATURES = {
     "rb_live_forget": (_int, [_vp, C.c_char_p, _u32]),
     "rb_replay_arrivals": (_int, [_vp, _vp, _u32, _sz, _vp, _sz, _dbl, _dbl, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz),
                                   C.POINTER(_dbl)]),
+    "rb_live_replay_arrivals": (_int, [_vp, _vp, _vp, _u32, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(_sz),
+                                       C.POINTER(_dbl)]),
+    "rb_dibf_clone_to_ex": (_int, [_vp, _int, _pp, C.POINTER(_int), C.POINTER(_dbl)]),
     "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
@@ -246,6 +249,12 @@ class DeviceIBF:
         h = C.c_void_p()
         _check(lib().rb_dibf_clone_to(self.h, device, C.byref(h)), "rb_dibf_clone_to")
         return DeviceIBF(h)
+
+    def clone_to_ex(self, device):
+        """-> (replica, used_peer, seconds): how the copy travelled (peer mapping = xGMI between two GPUs) and how long"""
+        h, peer, secs = C.c_void_p(), C.c_int(0), C.c_double(0)
+        _check(lib().rb_dibf_clone_to_ex(self.h, device, C.byref(h), C.byref(peer), C.byref(secs)), "rb_dibf_clone_to_ex")
+        return DeviceIBF(h), bool(peer.value), secs.value
 
     def compare(self, rebuilt):
         """bit statistics against a filter of the same geometry re-inserted from the reference sequences"""
@@ -535,6 +544,25 @@ class Live:
         _check(lib().rb_live_process(self.h, _ptr(ib), _ptr(io), _ptr(il), _ptr(sb), _ptr(so), _ptr(sl), n, _ptr(action),
                                      _ptr(status), _ptr(clen)), "rb_live_process")
         return action, status, clen
+
+    def replay_arrivals(self, read_ids, seqs, read_len, arrival_s, max_batch=16384):
+        """work-conserving replay through the live step -> (action[n], latency_s[n], classified_len[n], call_reads, call_service_s,
+        elapsed_s)"""
+        read_ids = np.ascontiguousarray(read_ids, dtype=np.uint32)
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        arrival_s = np.ascontiguousarray(arrival_s, dtype=np.float64)
+        n = len(arrival_s)
+        assert len(seqs) >= n * read_len and len(read_ids) == n
+        act = np.zeros(n, dtype=np.uint8)
+        lat = np.zeros(n, dtype=np.float64)
+        clen = np.zeros(n, dtype=np.uint32)
+        cr = np.zeros(n, dtype=np.uint32)
+        cs = np.zeros(n, dtype=np.float64)
+        calls, el = C.c_size_t(0), C.c_double(0)
+        _check(lib().rb_live_replay_arrivals(self.h, _ptr(read_ids), _ptr(seqs), read_len, n, _ptr(arrival_s), max_batch,
+                                             _ptr(act), _ptr(lat), _ptr(clen), _ptr(cr), _ptr(cs), n, C.byref(calls),
+                                             C.byref(el)), "rb_live_replay_arrivals")
+        return act, lat, clen, cr[:calls.value], cs[:calls.value], el.value
 
     def pending(self):
         return lib().rb_live_pending(self.h)

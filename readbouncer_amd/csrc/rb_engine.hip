@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -119,6 +120,8 @@ struct rb_engine {
         size_t bytes = 0;        // size of each copy
         double r = -1.0, conf = -1.0;
         uint64_t last_use = 0;
+        hipStream_t up_stream = nullptr;  // stream the last upload was queued on
+        hipEvent_t ready = nullptr;       // recorded behind it: a call on ANOTHER stream waits for this before it reads the table
     };
     ThrTable thr[2];
     uint64_t thr_clock = 0;
@@ -380,6 +383,14 @@ int rb_dibf_clone_to(const rb_dibf *src, int device, rb_dibf **out)
     return rb_dibf_clone_to_impl(src, device, out, nullptr, nullptr);
 }
 
+int rb_dibf_clone_to_ex(const rb_dibf *src, int device, rb_dibf **out, int *used_peer, double *seconds)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = rb_dibf_clone_to_impl(src, device, out, nullptr, used_peer);
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 // wait for a clone started with a stream_out (rb_pool.cpp is a host translation unit: it does not see HIP types)
 int rb_dibf_clone_finish(void *stream)
 {
@@ -613,6 +624,7 @@ void rb_engine_destroy(rb_engine *e)
     for (DevBuf &b : e->d_parts) b.release();
     for (auto &t : e->thr) {
         if (t.d) (void)hipFree(t.d);
+        if (t.ready) (void)hipEventDestroy(t.ready);
         t.host.release();
     }
     for (void *r : e->thr_retired_dev) (void)hipFree(r);
@@ -770,6 +782,8 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     }
     t->last_use = ++e->thr_clock;
     if (t->d && t->len >= need) {
+        // uploaded on another stream, possibly still queued there: order this stream behind it
+        if (t->ready && t->up_stream != st) RB_HIP(hipStreamWaitEvent(st, t->ready, 0));
         *tab_out = (const uint16_t *)t->d;
         *len_out = t->len;
         return RB_OK;
@@ -813,6 +827,9 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     t->bytes = (size_t)cap * row * 2;
     RB_HIP(hipMalloc(&t->d, (size_t)cap * row * 2));
     RB_HIP(hipMemcpyAsync(t->d, tab, (size_t)cap * row * 2, hipMemcpyHostToDevice, st));
+    if (!t->ready) RB_HIP(hipEventCreateWithFlags(&t->ready, hipEventDisableTiming));
+    RB_HIP(hipEventRecord(t->ready, st));
+    t->up_stream = st;
     t->len = cap;
     *tab_out = (const uint16_t *)t->d;
     *len_out = cap;

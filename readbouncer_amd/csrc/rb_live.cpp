@@ -190,13 +190,35 @@ int rb_live_process(rb_live *lv, const char *ids, const uint64_t *id_offsets, co
 // service (the call itself) can be told apart.  This is the reference's classification thread (adaptive_sampling.hpp:
 // 214-356 pops one read at a time) with a queue drained in micro-batches; it lives in the library so that the
 // measurement does not carry an interpreter's loop in its percentiles.
+// (spin with a pause hint: the dispatcher thread owns its core for the length of the replay, like the reference's
+// classification thread, which polls classification_queue.empty() in a tight loop -- adaptive_sampling.hpp:226-228)
+static inline void spin_pause()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+static int check_arrivals(const double *arrival_s, size_t n)
+{
+    for (size_t i = 1; i < n; ++i)
+        if (!(arrival_s[i] >= arrival_s[i - 1])) return rb::fail(RB_ERR_INVALID_ARG, "arrival times must be ascending");
+    return RB_OK;
+}
+
 int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len, size_t n, const double *arrival_s, size_t max_batch,
                        double error_rate, double significance, uint8_t *out_decision, double *out_latency_s,
                        uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap, size_t *out_calls,
                        double *out_elapsed_s)
 {
     if (!e || !seqs || !arrival_s || !out_latency_s || read_len == 0) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (out_calls) *out_calls = 0;
+    if (out_elapsed_s) *out_elapsed_s = 0.0;
+    if (n == 0) return RB_OK;
+    int rc = check_arrivals(arrival_s, n);
+    if (rc != RB_OK) return rc;
     if (max_batch == 0) max_batch = 16384;
+    max_batch = std::min(std::min(max_batch, n), (size_t)1 << 20);  // four staging vectors of this length below
     std::vector<uint64_t> offs(max_batch);
     std::vector<uint32_t> lens(max_batch, read_len);
     for (size_t i = 0; i < max_batch; ++i) offs[i] = (uint64_t)i * read_len;
@@ -208,16 +230,69 @@ int rb_replay_arrivals(rb_engine *e, const char *seqs, uint32_t read_len, size_t
     while (done < n) {
         const double now = now_s();
         while (hi < n && arrival_s[hi] <= now) ++hi;
-        if (hi <= done) continue;  // spin until the next chunk arrives
+        if (hi <= done) { spin_pause(); continue; }  // spin until the next chunk arrives
         const size_t m = std::min(hi - done, max_batch);
         const double a = now_s();
-        const int rc = rb_classify_batch(e, seqs + done * (size_t)read_len, offs.data(), lens.data(), m, error_rate, significance,
-                                         RB_MODE_CHECK_UNBLOCK, nullptr, nullptr, dec.data(), st.data());
+        rc = rb_classify_batch(e, seqs + done * (size_t)read_len, offs.data(), lens.data(), m, error_rate, significance,
+                               RB_MODE_CHECK_UNBLOCK, nullptr, nullptr, dec.data(), st.data());
         if (rc != RB_OK) return rc;
         const double b = now_s();
         for (size_t i = 0; i < m; ++i) {
             out_latency_s[done + i] = b - arrival_s[done + i];
             if (out_decision) out_decision[done + i] = dec[i];
+        }
+        if (calls < call_cap) {
+            if (out_call_reads) out_call_reads[calls] = (uint32_t)m;
+            if (out_call_service_s) out_call_service_s[calls] = b - a;
+        }
+        ++calls;
+        done += m;
+        hi = std::max(hi, done);
+    }
+    if (out_calls) *out_calls = calls;
+    if (out_elapsed_s) *out_elapsed_s = now_s();
+    return RB_OK;
+}
+
+// The same dispatcher in front of the LIVE step (rb_live_process): chunk i belongs to read read_ids[i] (its id is the four
+// bytes of that number), so an undecided read's next chunk is classified as the concatenation with what once_seen holds --
+// up to the 1500 bp cut-off, i.e. the 16-plane kernels -- exactly as the reference's classification thread does it
+// (adaptive_sampling.hpp:276-338).  Latency = action (or "keep waiting") known on the host - arrival of the chunk.
+int rb_live_replay_arrivals(rb_live *lv, const uint32_t *read_ids, const char *seqs, uint32_t read_len, size_t n,
+                            const double *arrival_s, size_t max_batch, uint8_t *out_action, double *out_latency_s,
+                            uint32_t *out_classified_len, uint32_t *out_call_reads, double *out_call_service_s, size_t call_cap,
+                            size_t *out_calls, double *out_elapsed_s)
+{
+    if (!lv || !read_ids || !seqs || !arrival_s || !out_latency_s || read_len == 0) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    if (out_calls) *out_calls = 0;
+    if (out_elapsed_s) *out_elapsed_s = 0.0;
+    if (n == 0) return RB_OK;
+    int rc = check_arrivals(arrival_s, n);
+    if (rc != RB_OK) return rc;
+    if (max_batch == 0) max_batch = 16384;
+    max_batch = std::min(std::min(max_batch, n), (size_t)1 << 20);
+    std::vector<uint64_t> offs(max_batch), id_offs(max_batch);
+    std::vector<uint32_t> lens(max_batch, read_len), id_lens(max_batch, 4u), clen(max_batch);
+    for (size_t i = 0; i < max_batch; ++i) { offs[i] = (uint64_t)i * read_len; id_offs[i] = (uint64_t)i * 4; }
+    std::vector<uint8_t> act(max_batch), st(max_batch);
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto now_s = [&] { return std::chrono::duration<double>(clk::now() - t0).count(); };
+    size_t done = 0, hi = 0, calls = 0;
+    while (done < n) {
+        const double now = now_s();
+        while (hi < n && arrival_s[hi] <= now) ++hi;
+        if (hi <= done) { spin_pause(); continue; }
+        const size_t m = std::min(hi - done, max_batch);
+        const double a = now_s();
+        rc = rb_live_process(lv, reinterpret_cast<const char *>(read_ids + done), id_offs.data(), id_lens.data(),
+                             seqs + done * (size_t)read_len, offs.data(), lens.data(), m, act.data(), st.data(), clen.data());
+        if (rc != RB_OK) return rc;
+        const double b = now_s();
+        for (size_t i = 0; i < m; ++i) {
+            out_latency_s[done + i] = b - arrival_s[done + i];
+            if (out_action) out_action[done + i] = act[i];
+            if (out_classified_len) out_classified_len[done + i] = clen[i];
         }
         if (calls < call_cap) {
             if (out_call_reads) out_call_reads[calls] = (uint32_t)m;

@@ -101,7 +101,10 @@ def make_reads_device(seed, n_reads, read_len, ref, device, positive_fraction=0.
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     acgt = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    out = acgt[torch.randint(0, 4, (n_reads, read_len), generator=g, device=device)]
+    out = torch.empty((n_reads, read_len), dtype=torch.uint8, device=device)
+    for b in range(0, n_reads, 1 << 20):  # in slabs: the index tensor of a 10 M-read batch would be 29 GB
+        m = min(1 << 20, n_reads - b)
+        out[b:b + m] = acgt[torch.randint(0, 4, (m, read_len), generator=g, device=device)]
     n_pos = int(n_reads * positive_fraction)
     if n_pos and ref is not None and len(ref) >= seg_len >= read_len:
         t_ref = torch.from_numpy(np.ascontiguousarray(ref)).to(device)

@@ -45,6 +45,33 @@ def test_gpus2_self_launch_read_sharded_cpu():
     assert abs(d["value"] - 2 * 400 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
 
 
+def test_gpus2_default_line_structure_cpu():
+    """the DEFAULT command (what the driver runs at N > 1): headline = config 3, the other BASELINE configs as sub-runs of all
+    ranks, per-rank device records -- the structure a SCALE record will carry, checked on the null engine"""
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"], CPU_HOOKS)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "c3" in d["config"]["workload"]
+    for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
+                "roofline", "cpu_baseline", "parity", "ranks", "other_configs"):
+        assert key in d, key
+    assert set(d["other_configs"]) == {"c2", "c4", "c5", "readme"}
+    for sub in d["other_configs"].values():
+        assert sub["n_gpus"] == 2 and sub["value"] > 0
+    r = d["ranks"]
+    assert "rccl_ranks" in r and "xgmi_preflight" in r and len(r["devices"]) == 2 and len(r["per_rank_reads_per_s"]) == 2
+    assert sorted(x["rank"] for x in r["devices"]) == [0, 1]
+
+
+def test_visible_gpu_count_does_not_touch_hip():
+    """the launcher counts GPUs from the environment lists / the KFD topology, never through the HIP runtime"""
+    code = ("import sys, os; sys.path.insert(0, %r); os.environ['HIP_VISIBLE_DEVICES'] = '0,1,2'; import bench; "
+            "assert bench.visible_gpu_count() == 3; assert 'torch' not in sys.modules; "
+            "del os.environ['HIP_VISIBLE_DEVICES']; n = bench.visible_gpu_count(); assert n is None or n >= 0; "
+            "assert 'torch' not in sys.modules") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
 def test_gpus2_self_launch_bin_sharded_cpu():
     p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300", "--bin-sharded"], CPU_HOOKS)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -105,3 +132,29 @@ def test_rccl_code_paths_with_a_group_of_one():
         assert d["ranks"]["backend"] == "nccl" and d["n_gpus"] == 1
         assert d["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
         assert d["scaling"] == ("strong" if extra else "weak")
+
+
+@pytest.mark.gpu
+def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
+    """The default command at N = 2 (two ranks on the one GPU of the box, gloo) against N = 1: rank 0's decisions on the
+    headline (config 3, the 8 GiB filter) and on config 4 are the 1-rank decisions; the line has the SCALE structure.
+    Batches divided by 50 (test hook) so that both runs fit a unit test."""
+    small = {"RB_BENCH_READS_DIVISOR": "50", "RB_BENCH_DUMP_DECISIONS": "1"}
+    argv = ["--steps", "2", "--warmup", "1", "--cpu-seconds", "2"]
+    p1, d1 = _run(["--gpus", "1"] + argv, small, timeout=900)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p2, d2 = _run(["--gpus", "2"] + argv, dict(GPU_HOOKS, **small), timeout=900)
+    assert p2.returncode == 0, p2.stderr[-2000:]
+    assert d1["test_reads_divisor"] == 50 and d2["n_gpus"] == 2 and "c3" in d2["config"]["workload"]
+    assert d1["cpu_baseline"]["value"] > 0 and d2["cpu_baseline"] is None  # timed at N = 1 only
+    for d in (d1, d2):
+        assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
+        assert set(d["other_configs"]) >= {"c2", "c4", "c5", "readme"}
+        assert d["other_configs"]["c4"]["parity"]["decision_mismatches"] == 0
+        assert d["other_configs"]["c5"]["latency"]["slo_met"] is True
+        assert d["other_configs"]["c5"]["parity"]["replayed_decisions_equal_one_batch"] is True
+        assert d["other_configs"]["c5"]["live_step"]["concatenated_share"] > 0.1
+    assert d2["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
+    assert d2["other_configs"]["c4"]["config"]["decisions_sha1"] == d1["other_configs"]["c4"]["config"]["decisions_sha1"]
+    assert min(d1["other_configs"]["c4"]["config"]["decisions"]) > 0
+    assert len(d2["ranks"]["devices"]) == 2 and d2["ranks"]["devices"][0]["device"] == 0

@@ -128,3 +128,46 @@ def test_replay_arrivals_dispatcher():
     assert int(call_reads.sum()) == n and call_reads.max() <= 64 and len(call_reads) == len(call_service)
     assert (lat > 0).all() and elapsed >= arrival[-1] and (call_service > 0).all()
     assert np.median(lat) < 0.005  # far from the 1 ms SLO even on a busy box
+
+
+def test_live_replay_equals_the_sequential_reference():
+    """rb_live_replay_arrivals: the work-conserving dispatcher in front of rb_live_process.  Whatever micro-batches the
+    arrival process cuts, the action per chunk equals the sequential restatement of classify_live_reads on the same stream
+    (undecided chunks concatenated with what once_seen holds, 1500 bp cut-off)."""
+    rng = np.random.default_rng(77)
+    host = H.random_dna(rng, 30000)
+    bug = H.random_dna(rng, 30000)
+    filters, views, keep = [], [], []
+    for src, n_bins in ((host, 300), (bug, 64)):
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * 120011)
+        d.add_sequence(src, 1000)
+        h = d.download()
+        keep.append(h)
+        views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+        filters.append(d)
+    L, n_reads, n_chunks = 360, 400, 5
+    mols = []
+    for m in range(n_reads):
+        kind = m % 4
+        s = int(rng.integers(0, 30000 - L * n_chunks))
+        mol = (H.mutate(rng, host[s:s + L * n_chunks], 0.1) if kind == 0 else H.mutate(rng, bug[s:s + L * n_chunks], 0.1)
+               if kind == 1 else H.random_dna(rng, L * n_chunks) if kind == 2 else H.mutate(rng, host[s:s + L * n_chunks], 0.26))
+        mols.append(mol)
+    first = np.sort(rng.uniform(0.0, 0.02, size=n_reads))
+    arr = (first[:, None] + 0.004 * np.arange(n_chunks)[None, :]).reshape(-1)
+    ids = np.repeat(np.arange(n_reads, dtype=np.uint32), n_chunks)
+    chunk_no = np.tile(np.arange(n_chunks), n_reads)
+    order = np.argsort(arr, kind="stable")
+    arr, ids, chunk_no = arr[order], ids[order], chunk_no[order]
+    chunks = [mols[i][c * L:(c + 1) * L] for i, c in zip(ids, chunk_no)]
+    buf = np.frombuffer("".join(chunks).encode(), dtype=np.uint8).copy()
+    stream = [(ids[j].tobytes(), chunks[j]) for j in range(len(chunks))]
+    exp, exp_once = reference_live(views[:1], views[1:], stream)
+    eng = capi.Engine(0, filters[:1], filters[1:])
+    live = capi.Live(eng)
+    act, lat, clen, call_reads, service, elapsed = live.replay_arrivals(ids, buf, L, arr, max_batch=97)
+    assert act.tolist() == [e[0] for e in exp]
+    assert live.pending() == len(exp_once)
+    assert int(call_reads.sum()) == len(chunks) and call_reads.max() <= 97 and (lat > 0).all() and elapsed >= arr[-1]
+    assert (clen > L).sum() > 100 and clen.max() > 1080  # concatenations up to the cut-off went through the GPU
+    assert set(act.tolist()) == {0, 1, 2}

@@ -132,6 +132,96 @@ def test_c4_sample_against_oracle(c4):
         assert np.array_equal(base[0][idx, f], po.batch_raw_max(o, buf, offs[idx], lens[idx], 8))
 
 
+def test_c3_ten_million_reads_in_one_call(c4):
+    """BASELINE configs[2] as stated: ONE call over 10 M device-resident 360 bp reads (3.6 GB of read bytes, 2.5 M
+    workgroups) against the 8 GiB filter.  Checked through what the size allows: strand symmetry of the whole batch (a
+    second 10 M-read call on the reverse complements), batch-partition invariance against separate calls on slices of it,
+    the status/decision bookkeeping, and 2 000 sampled reads against the oracle."""
+    torch = pytest.importorskip("torch")
+    dep = c4[0]
+    dev = torch.device("cuda:0")
+    n, L = 10_000_000, 360
+    ref = synth.planted_reference(40)[0]  # the segments the c4 fixture planted into this filter
+    t_seq, t_off, t_len = synth.make_reads_device(1234, n, L, ref, dev)
+    t_max = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+    t_dec = torch.zeros(n, dtype=torch.uint8, device=dev)
+    t_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
+    eng = capi.Engine(0, [dep], [])
+    torch.cuda.synchronize()
+    eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, L, d_maxcount=t_max.data_ptr(),
+                        d_decision=t_dec.data_ptr(), d_status=t_st.data_ptr())
+    torch.cuda.synchronize()
+    assert int((t_st != 0).sum()) == 0
+    n_unblock = int(t_dec.sum())
+    assert 4_500_000 < n_unblock < 5_600_000  # half of the reads are planted positives at 10 % error
+    assert 0 <= int(t_max.min()) and int(t_max.max()) <= 348  # counts never exceed the k-mers of a read
+    # strand symmetry on the whole batch
+    comp = torch.zeros(256, dtype=torch.uint8, device=dev)
+    comp[torch.tensor(list(b"ACGT"), device=dev).long()] = torch.tensor(list(b"TGCA"), dtype=torch.uint8, device=dev)
+    t_rc = torch.empty_like(t_seq)
+    for b in range(0, n, 1 << 20):
+        m = min(1 << 20, n - b)
+        t_rc[b * L:(b + m) * L] = comp[t_seq[b * L:(b + m) * L].view(m, L).flip(1).long()].reshape(-1)
+    t_max2 = torch.zeros_like(t_max)
+    t_dec2 = torch.zeros_like(t_dec)
+    torch.cuda.synchronize()
+    eng.classify_device(t_rc.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n, L, d_maxcount=t_max2.data_ptr(),
+                        d_decision=t_dec2.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(t_max, t_max2) and torch.equal(t_dec, t_dec2)
+    del t_rc, t_max2, t_dec2
+    # slices of the batch as calls of their own (first, middle, ragged tail across the last workgroup)
+    for lo, m in ((0, 100_000), (4_999_999, 70_001), (n - 33_333, 33_333)):
+        s_max = torch.zeros((m, 1), dtype=torch.int16, device=dev)
+        s_dec = torch.zeros(m, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.classify_device(t_seq.data_ptr(), t_off[lo:].data_ptr(), t_len[lo:].data_ptr(), m, L, d_maxcount=s_max.data_ptr(),
+                            d_decision=s_dec.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(s_max, t_max[lo:lo + m]) and torch.equal(s_dec, t_dec[lo:lo + m]), lo
+    # 2 000 sampled reads against the oracle
+    host = dep.download()
+    o = po.OracleIBF.wrap(host.info["n_bins"], 3, 13, host.info["n_bits"], host.words())
+    idx = np.sort(np.random.default_rng(3).choice(n, size=2000, replace=False))
+    t_idx = torch.from_numpy(idx).to(dev)
+    sample = t_seq.view(n, L)[t_idx].cpu().numpy().reshape(-1)
+    so = np.arange(2000, dtype=np.uint64) * np.uint64(L)
+    sl = np.full(2000, L, dtype=np.uint32)
+    exp_max = po.batch_raw_max(o, sample, so, sl, 8)
+    exp_dec, _ = po.batch_check_unblock([o], [], sample, so, sl, n_threads=8)
+    assert np.array_equal(t_max[t_idx, 0].cpu().numpy().view(np.uint16), exp_max)
+    assert np.array_equal(t_dec[t_idx].cpu().numpy(), exp_dec)
+
+
+def test_c5_replay_as_stated(c4):
+    """BASELINE configs[4] on one GPU: >= 150 k chunks/s for >= 1 s through rb_replay_arrivals against the 8 GiB deplete +
+    600-bin target filters; every decision equals what one big rb_classify_batch gives; p99 (arrival -> decision on the
+    host) below the 1 ms SLO."""
+    dep, tgt, eng, buf, offs, lens, base = c4
+    rate, seconds, L = 150_000.0, 1.2, 360
+    n = int(rate * seconds)
+    rng = np.random.default_rng(15)
+    arrival = np.cumsum(rng.exponential(1.0 / rate, size=n))
+    for _ in range(10):  # code objects, staging buffers, threshold table
+        eng.classify(buf[: 64 * L], offs[:64], lens[:64])
+        eng.classify(buf[: 4096 * L], offs[:4096], lens[:4096])
+    dec, lat, call_reads, call_service, elapsed = eng.replay_arrivals(buf[: n * L], L, arrival, max_batch=16384)
+    assert np.array_equal(dec, base[2][:n])  # the fixture's one-batch decisions of the same reads
+    assert len(set(dec.tolist())) == 3
+    assert elapsed >= 1.0 and n / elapsed >= 0.98 * rate  # kept up with the arrivals
+    p50, p99 = np.percentile(lat, 50), np.percentile(lat, 99)
+    assert p99 < 1e-3, "p99 %.3f ms" % (p99 * 1e3)
+    assert p50 < 0.3e-3
+    assert int(call_reads.sum()) == n
+    # unsorted arrivals are refused, an oversized max_batch is clamped
+    bad = arrival.copy()
+    bad[10] = bad[9] - 1e-3
+    with pytest.raises(capi.RBError):
+        eng.replay_arrivals(buf[: n * L], L, bad)
+    d2 = eng.replay_arrivals(buf[: 2000 * L], L, arrival[:2000], max_batch=1 << 40)[0]
+    assert np.array_equal(d2, base[2][:2000])
+
+
 @pytest.fixture(scope="module")
 def narrow():
     """the README benchmark shape (README.md:254-262): one two-word deplete filter (122 bins, 20 MB) and three one-word
