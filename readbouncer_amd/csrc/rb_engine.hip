@@ -103,6 +103,7 @@ struct rb_engine {
     // 20 MB one-word filter (360 bp reads), 5.5-6 us for the short-read kernels on 10 and 20 MB filters; flat within +-1 us.
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0, phase_short_extra_ticks = 125;
     uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
+    uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
@@ -592,6 +593,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) e->wall_clock_khz = (uint32_t)khz;
         else (void)hipGetLastError();
     }
+    if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->d_parts.resize(e->filters.size());
     const size_t n_aux = std::min<size_t>(3, e->filters.size() - 1);
@@ -864,7 +866,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     a.split_waves = 0;
     if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
         a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
-    a.phase = PhaseCfg{0, 0, 0};
+    a.phase = PhaseCfg{0, 0, 0, 0, 0};
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
     if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
@@ -883,6 +885,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.shift = sh;
             a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
+            a.phase.xcd_skew = e->phase_xcd_skew;
         } else if (a.lg == 0 && e->short_read_kernel) {
             // one-word blocks outside the phased range still take that kernel for its both-strands-in-one-tile path for
             // reads of up to 256 k-mers: one "slice" that holds every offset, no clock, no waiting

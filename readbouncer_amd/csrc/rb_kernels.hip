@@ -68,6 +68,14 @@ __device__ __forceinline__ rb_u64x2 load_word2(const uint64_t *p)
     else return *reinterpret_cast<const rb_u64x2 *>(p);
 }
 
+// number of the XCD this wave runs on (0-7): a placement fact, used for speed only
+__device__ __forceinline__ uint32_t xcc_id()
+{
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
+}
+
 // carry-save adder on bit planes: (h, l) = a + b + c per bit position
 #define RB_CSA(h, l, a, b, c)                \
     {                                        \
@@ -256,7 +264,7 @@ __device__ __forceinline__ void phased_gather8(uint64_t (&x)[8], const uint32_t 
                                                uint32_t slice_shift, const PhaseCfg ph)
 {
     const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-    uint32_t cur = w0 % ph.n_slices;
+    uint32_t cur = (w0 + ph.skew) % ph.n_slices;
 #pragma unroll 1
     for (uint32_t q = 0; q < ph.n_slices; ++q) {
         // window w0 + q: wait for it to open (bounded: the clock's 32-bit wrap, once in 43 s, must not park a wave)
@@ -296,7 +304,7 @@ __device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x
                                                  const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
 {
     const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-    uint32_t cur = w0 % ph.n_slices;
+    uint32_t cur = (w0 + ph.skew) % ph.n_slices;
 #pragma unroll 1
     for (uint32_t q = 0; q < ph.n_slices; ++q) {
         for (uint32_t guard = 0; guard < 2048; ++guard) {
@@ -346,7 +354,7 @@ template <int LG, int WPL, int NP, int H, bool NT, bool PH = false>
 __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
                                              const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
                                              uint32_t mt_first, uint32_t mt_step, int blk_first, int blk_end,
-                                             uint8_t *stage, int lane, const PhaseCfg ph = PhaseCfg{0, 0, 0})
+                                             uint8_t *stage, int lane, const PhaseCfg ph = PhaseCfg{0, 0, 0, 0, 0})
 {
     using T = TileShape<LG>;
     constexpr int NG = T::NG, SPT = T::SPT, J = T::J, ITEMS = T::ITEMS;
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     uint32_t out_read_stride)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+    if (ph.xcd_skew) ph.skew = xcc_id();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
