@@ -532,17 +532,37 @@ def replay(ctx, live_leg=True):
     if live_leg:
         # reads with four chunks each, 0.4 s apart (MinKNOW's break_reads_after_seconds, adaptive_sampling.hpp:634); the
         # chunk stream keeps the total arrival rate.  A chunk of a read already decided starts that read afresh.
+        # The stream as the sequencer would send it: a read whose first chunk is decided (unblock / stop_receiving) sends
+        # nothing more; an undecided read sends up to four chunks, 0.4 s apart (MinKNOW's break_reads_after_seconds,
+        # adaptive_sampling.hpp:634), and is re-classified on the concatenation each time -- 720, 1080, 1440 bp -- until the
+        # 1500 bp cut-off.  Which synthetic chunks are decided on their own is known from the leg above; half of the reads
+        # are of each kind, so 3 of 5 chunks are concatenations.
         n_chunks = 4
-        n_live = max(n_chunks, (n // n_chunks) * n_chunks)
-        reads = n_live // n_chunks
-        # first chunks uniform over n_live / rate seconds: once all four chunk generations overlap (from 1.2 s on) the stream
-        # runs at the nominal rate; the replay lasts 1.2 s longer than the plain one
-        first = np.sort(rng.uniform(0.0, n_live / rate, size=reads))
-        arr = (first[:, None] + 0.4 * np.arange(n_chunks)[None, :]).reshape(-1)
-        ids = np.repeat(np.arange(reads, dtype=np.uint32), n_chunks)
+        idx_dec, idx_und = np.flatnonzero(decisions != 0), np.flatnonzero(decisions == 0)
+        if len(idx_dec) == 0 or len(idx_und) == 0:
+            idx_dec = idx_und = np.arange(n)
+        reads = max(2, int(n / 2.5) // 2 * 2)
+        half = reads // 2
+        kind_und = np.zeros(reads, dtype=bool)
+        kind_und[rng.permutation(reads)[:half]] = True
+        # first chunks uniform over the replay: once all four chunk generations overlap (from 1.2 s on) the stream runs at the
+        # nominal rate; the replay lasts 1.2 s longer than the plain one
+        first = np.sort(rng.uniform(0.0, args.replay_seconds / (TEST_DIVISOR if TEST_DIVISOR > 1 else 1), size=reads))
+        rows_und = np.resize(idx_und, half * n_chunks).reshape(half, n_chunks)
+        rows_dec = np.resize(idx_dec, reads - half)
+        arr_l, ids_l, rows_l = [], [], []
+        und_no = np.cumsum(kind_und) - 1
+        dec_no = np.cumsum(~kind_und) - 1
+        for c in range(n_chunks):
+            sel = kind_und if c else np.ones(reads, dtype=bool)
+            arr_l.append(first[sel] + 0.4 * c)
+            ids_l.append(np.flatnonzero(sel).astype(np.uint32))
+            rows_l.append(np.where(kind_und[sel], rows_und[und_no[sel].clip(0), c], rows_dec[dec_no[sel].clip(0)] if c == 0 else 0))
+        arr, ids, rows = np.concatenate(arr_l), np.concatenate(ids_l), np.concatenate(rows_l)
         order = np.argsort(arr, kind="stable")
-        arr, ids = arr[order], ids[order]
-        lbuf = np.resize(buf, n_live * read_len)  # chunk j of the stream = synthetic read j (positives and negatives mixed)
+        arr, ids, rows = arr[order], ids[order], rows[order]
+        n_live = len(arr)
+        lbuf = np.ascontiguousarray(buf.reshape(n, read_len)[rows].reshape(-1))
         lv = capi.Live(eng)
         warm = capi.Live(eng)
         warm.process([b"w%d" % i for i in range(64)], [bytes(buf[i * read_len:(i + 1) * read_len]) for i in range(64)])
@@ -555,7 +575,9 @@ def replay(ctx, live_leg=True):
         if rank == 0:
             live = {"what": "the same arrival rate through rb_live_process (once_seen, concatenation of undecided chunks, 1500 bp "
                             "cut-off): 4 chunks of 360 bp per read, 0.4 s apart",
-                    "value": n_live * world / lelapsed, "unit": "chunks/s",
+                    "value": n_live * world / lelapsed, "unit": "chunks/s (whole replay, ramp-up and drain included)",
+                    "steady_arrival_chunks_per_s": 2.5 * reads / (args.replay_seconds / (TEST_DIVISOR if TEST_DIVISOR > 1 else 1)) * world,
+                    "kept_up": bool(lelapsed - float(arr[-1]) < 2e-3),
                     "p50_ms": l50 * 1e3, "p99_ms": l99 * 1e3, "p99.9_ms": l999 * 1e3, "max_ms": lmax * 1e3,
                     "slo_met": bool(l99 * 1e3 < 1.0),
                     "classified_length_share": {str(L): float((clen == L).mean()) for L in (360, 720, 1080, 1440)},

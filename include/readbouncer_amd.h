@@ -292,6 +292,12 @@ RB_API int rb_pool_create_from_files(const int *devices, size_t n_devices, const
 RB_API void rb_pool_destroy(rb_pool *p);
 RB_API size_t rb_pool_size(const rb_pool *p);
 RB_API int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device);
+/* Calls from several host threads run concurrently: each worker (engine + host thread per device) has a FIFO of its own,
+ * an unsplit micro-batch goes to the least loaded worker, and callers only meet while a call's parts are queued -- K calling
+ * threads keep K engines busy, like the reference's N classification threads behind one queue
+ * (src/main/adaptive_sampling.hpp:745-751).  Per calling thread the calls stay ordered (each returns before the next starts).
+ * rb_pool_set_serialize(p, 1) is a diagnostic: one call at a time, whoever makes it. */
+RB_API int rb_pool_set_serialize(rb_pool *p, int enabled);
 RB_API int rb_pool_classify_batch(rb_pool *p, const char *seqs, const uint64_t *offsets, const uint32_t *lens,
                                   size_t n_reads, double error_rate, double significance, int mode,
                                   uint16_t *out_maxcount, int32_t *out_best_target, uint8_t *out_decision,

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rb_last_warning": (C.c_char_p, []),
     "rb_pool_size": (_sz, [_vp]),
     "rb_pool_set_min_split": (_int, [_vp, _sz]),
+    "rb_pool_set_serialize": (_int, [_vp, _int]),
     "rb_pool_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_live_create": (_int, [_vp, _dbl, _dbl, _u32, _pp]),
     "rb_live_destroy": (None, [_vp]),
@@ -486,6 +487,9 @@ class Pool:
 
     def set_min_split(self, reads_per_device):
         _check(lib().rb_pool_set_min_split(self.h, reads_per_device), "rb_pool_set_min_split")
+
+    def set_serialize(self, on):
+        _check(lib().rb_pool_set_serialize(self.h, int(on)), "rb_pool_set_serialize")
 
     def classify(self, seqs, offsets, lens, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
         n = len(lens)

@@ -69,7 +69,7 @@ struct CountLaunch {
     int lg, wpl, planes;
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
     PhaseCfg phase;               // throughput form on narrow filters: clock-phased gathers (n_slices == 0: off)
-    int short_only;               // 1 / 2: the declared max_len gives at most 256 / 512 k-mers per read; 0: more
+    int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
     int grid_parts;               // latency form: workgroups launched per (read, slice) = max parts of the fused filters

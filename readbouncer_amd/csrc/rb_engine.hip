@@ -106,6 +106,7 @@ struct rb_engine {
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
+    int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp): one round of six tiles per strand for one-word blocks (1), two-word blocks too (2); 0: two rounds of four
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
@@ -594,6 +595,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         else (void)hipGetLastError();
     }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
+    if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->d_parts.resize(e->filters.size());
     const size_t n_aux = std::min<size_t>(3, e->filters.size() - 1);
@@ -894,6 +896,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.inv_ticks = 0;
         }
     }
+    // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
+    if (a.short_only == 2 && kmers <= 384 && (int)e->six_tile_kernel > a.lg) a.short_only = 3;
     a.split_parts = 1;
     a.split_sub = 1;
     if (a.split_waves >= 2)

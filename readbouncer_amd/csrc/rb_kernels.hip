@@ -156,6 +156,26 @@ __device__ __forceinline__ uint32_t wave_bin_counts4(uint64_t x0, uint64_t x1, u
            4u * (uint32_t)__popcll(wave_transpose64(p2, lane));
 }
 
+// the same for 6 one-bit-per-bin words per lane (sums 0..6: still three planes, three transposes)
+__device__ __forceinline__ uint32_t wave_bin_counts6(uint64_t x0, uint64_t x1, uint64_t x2, uint64_t x3, uint64_t x4,
+                                                     uint64_t x5, int lane)
+{
+    uint64_t h1, l1, h2, l2, p2, p1;
+    RB_CSA(h1, l1, x0, x1, x2);
+    RB_CSA(h2, l2, x3, x4, x5);
+    const uint64_t p0 = l1 ^ l2, c = l1 & l2;
+    RB_CSA(p2, p1, h1, h2, c);
+    return (uint32_t)__popcll(wave_transpose64(p0, lane)) + 2u * (uint32_t)__popcll(wave_transpose64(p1, lane)) +
+           4u * (uint32_t)__popcll(wave_transpose64(p2, lane));
+}
+
+template <int T>
+__device__ __forceinline__ uint32_t wave_bin_counts(const uint64_t *x, int lane)
+{
+    if constexpr (T == 6) return wave_bin_counts6(x[0], x[1], x[2], x[3], x[4], x[5], lane);
+    else return wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
+}
+
 // max over all bins held by the wave (WPL plane sets per lane), MSB plane first
 template <int NP, int WPL>
 __device__ __forceinline__ uint32_t planes_max(const Planes<NP> (&pl)[WPL], const uint64_t (&valid)[WPL])
@@ -259,10 +279,11 @@ struct BaseSrc {
 // The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the
 // window of its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  With ph = {shift 0.., n_slices 1, inv_ticks 0} and
 // a slice_shift of 31 this is one batch of predicated gathers with no waiting (tables that need no phasing).
-template <int H, bool NT>
-__device__ __forceinline__ void phased_gather8(uint64_t (&x)[8], const uint32_t (&bn)[8][H], const uint64_t *words,
-                                               uint32_t slice_shift, const PhaseCfg ph)
+template <int N, int H, bool NT, int B = N>
+__device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (&bn)[N][H], const uint64_t *words,
+                                              uint32_t slice_shift, const PhaseCfg ph)
 {
+    static_assert(N % B == 0, "the k-mers of a lane are gathered in batches of B");
     const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
     uint32_t cur = (w0 + ph.skew) % ph.n_slices;
 #pragma unroll 1
@@ -273,36 +294,40 @@ __device__ __forceinline__ void phased_gather8(uint64_t (&x)[8], const uint32_t 
             if ((int32_t)(wn - (w0 + q)) >= 0) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        uint64_t ld[8][H];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int part = 0; part < N / B; ++part) {
+            uint64_t ld[B][H];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                ld[u][h] = ~0ULL;
-                // the offset is made opaque per window: otherwise the 24 addresses are widened to 64 bits and hoisted out
-                // of the window loop (48 registers that cost the third wave per SIMD)
-                uint32_t off = bn[u][h];
-                asm volatile("" : "+v"(off));
-                if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
-                    ld[u][h] = load_word<NT>(reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(words) + off));
+            for (int uu = 0; uu < B; ++uu) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    ld[uu][h] = ~0ULL;
+                    // the offset is made opaque per window: otherwise the addresses are widened to 64 bits and hoisted out
+                    // of the window loop (two registers per lookup, which costs a wave per SIMD)
+                    uint32_t off = bn[part * B + uu][h];
+                    asm volatile("" : "+v"(off));
+                    if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
+                        ld[uu][h] = load_word<NT>(reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(words) + off));
+                }
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+            for (int uu = 0; uu < B; ++uu) {
 #pragma unroll
-            for (int h = 0; h < H; ++h) x[u] &= ld[u][h];
+                for (int h = 0; h < H; ++h) x[part * B + uu] &= ld[uu][h];
+            }
         }
         cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
     }
 }
 
-// The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's eight k-mers.
-// The twelve gathers of four k-mers go out together (48 registers of results in flight, like the 24 eight-byte ones).
-template <int H, int KB = 4>
-__device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x1)[8], const uint32_t (&bn)[8][H],
+// The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's N k-mers.
+// The gathers of KB k-mers go out together (KB = 4: 48 registers of results in flight, like the 24 eight-byte ones).
+template <int N, int H, int KB>
+__device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x1)[N], const uint32_t (&bn)[N][H],
                                                  const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
 {
+    static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
     const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
     uint32_t cur = (w0 + ph.skew) % ph.n_slices;
 #pragma unroll 1
@@ -313,7 +338,7 @@ __device__ __forceinline__ void phased_gather8x2(uint64_t (&x0)[8], uint64_t (&x
             __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
-        for (int part = 0; part < 8 / KB; ++part) {
+        for (int part = 0; part < N / KB; ++part) {
             rb_u64x2 ld[KB][H];
 #pragma unroll
             for (int uu = 0; uu < KB; ++uu) {
@@ -433,7 +458,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                         bn[u][h] = ok ? b * (S * 8u) + col_bytes : 0xFFFFFFFFu;
                     }
                 }
-                phased_gather8<H, NT>(x[0], bn, f.words, slice_shift, ph);
+                phased_gather<8, H, NT>(x[0], bn, f.words, slice_shift, ph);
             } else if constexpr (H > 0) {
                 constexpr int HALF = (WPL == 1) ? 8 : 4;  // steps per load batch
 #pragma unroll
@@ -574,10 +599,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 }
 
 // throughput form with clock-phased gathers (see count_strand): narrow filters of a few L2 sizes, one column slice
-// (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with.  SHORT != 0: the engine
-// knows that no read of the batch has more than 256 (SHORT 1) or 512 (SHORT 2, one-word blocks) k-mers: only the
-// both-strands path is compiled in, which fits five resp. four waves per SIMD for one-word blocks.  The two-round build
-// for two-word blocks needs 177 registers; held to three waves per SIMD it spills eight of them, outside the window loop.)
+// (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with).  SHORT != 0: the engine
+// knows that no read of the batch has more k-mers than one of the both-strands shapes below takes, and only that path is
+// compiled in:
+//   SHORT 1  <= 256 k-mers (the reference's default 250 bp chunk): ONE round of 4 tiles per strand -- 93 VGPRs, five waves
+//            per SIMD for one-word blocks;
+//   SHORT 3  <= 384 k-mers (360 bp reads, the length the reference recommends): ONE round of 6 tiles per strand.  Two rounds
+//            of 4 tiles left the second one 36 % dense (92 of 256 k-mers per strand) while every round costs a full turn
+//            of windows; 6 tiles are 91 % dense and the per-bin sums of six words still fit three bit planes;
+//   SHORT 2  <= 512 k-mers: two rounds of 4 tiles (the general build, SHORT 0, takes this path too and falls back to
+//            the per-strand tiles of count_strand for longer reads).
 template <int LG, int NP, int SHORT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, (SHORT && LG == 0) ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
@@ -594,14 +625,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     uint32_t best = 0;
+    constexpr int T = SHORT == 3 ? 6 : 4;                      // 64-k-mer tiles per strand and round
+    constexpr uint32_t kRound = 64u * T;                       // k-mers per strand and round
+    constexpr bool kOneRound = SHORT == 1 || SHORT == 3;       // no loop state (registers)
     if constexpr (LG == 0) {
         // One-word blocks, reads of up to 512 k-mers: a 512-k-mer macro tile per strand would leave more than half of the 24
         // lookups a lane can keep in flight unused on the reference's default 250 bp chunk (238 k-mers) -- and the windows
-        // of the phased form live on lookups held in registers.  So both strands share a macro tile: tiles 0-3 are 256
-        // forward k-mers, tiles 4-7 the k-mers of the reverse complement over the same windows (separate counts, as in
+        // of the phased form live on lookups held in registers.  So both strands share a macro tile: tiles 0..T-1 are
+        // forward k-mers, tiles T..2T-1 the k-mers of the reverse complement over the same windows (separate counts, as in
         // the reference).
-        // (SHORT 1 keeps the single round free of loop state: 93 VGPRs, five waves per SIMD; with the loop 114 and four.)
-        constexpr uint32_t kBothMax = SHORT == 1 ? 256u : 512u;  // the general build takes two rounds as well: 360 bp reads
+        constexpr uint32_t kBothMax = SHORT == 1 ? 256u : SHORT == 3 ? 384u : 512u;  // the general build takes two rounds as well
         if (n <= kBothMax) {  // len <= 512 + k - 1 <= kStageBytes: the whole read is staged once
             uint8_t *stage = s_stage[wave];
             for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
@@ -611,20 +644,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
             const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
             uint32_t cf = 0, cr = 0;  // lane b: count of bin b, forward / reverse complement
-            // rounds of 256 k-mers per strand (one for the 250 bp chunk, two for 360 bp): the counts of a round are summed
-            // across the wave at once, so no counter planes are carried
+            // the counts of a round are summed across the wave at once, so no counter planes are carried
 #pragma unroll 1
-            for (uint32_t base = 0; base < (SHORT == 1 ? 1u : n); base += 256) {
-            uint32_t bn[8][3];
-            uint64_t x[8];
+            for (uint32_t base = 0; base < (kOneRound ? 1u : n); base += kRound) {
+            uint32_t bn[2 * T][3];
+            uint64_t x[2 * T];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t p = base + (uint32_t)((j & 3) * 64 + lane);
+            for (int j = 0; j < 2 * T; ++j) {
+                const uint32_t p = base + (uint32_t)((j % T) * 64 + lane);
                 const bool ok = (p < n) && lc.colok;
                 uint64_t v = 0;
                 if (ok) {
                     const uint8_t *b = stage + p;
-                    if (j < 4) {
+                    if (j < T) {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
                     } else {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
@@ -635,12 +667,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
                     bn[j][h] = ok ? blk * (f.stride * 8u) + col_bytes : 0xFFFFFFFFu;
                 }
+                if constexpr (T == 6) __builtin_amdgcn_sched_barrier(0);  // one k-mer's hash chains at a time (registers)
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = bn[j][0] != 0xFFFFFFFFu ? lc.valid[0] : 0ULL;  // after the hashing: 16 registers less there
-            phased_gather8<3, false>(x, bn, f.words, slice_shift, ph);
-            cf += wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
-            cr += wave_bin_counts4(x[4], x[5], x[6], x[7], lane);
+            for (int j = 0; j < 2 * T; ++j) x[j] = bn[j][0] != 0xFFFFFFFFu ? lc.valid[0] : 0ULL;  // after the hashing: 16 registers less there
+            // (six tiles per strand: the 36 gathers of a window go out in two batches of 18)
+            phased_gather<2 * T, 3, false, T == 6 ? 6 : 8>(x, bn, f.words, slice_shift, ph);
+            cf += wave_bin_counts<T>(x, lane);
+            cr += wave_bin_counts<T>(x + T, lane);
             }
             uint32_t m = cf > cr ? cf : cr;  // bins beyond noOfBins count 0: the gathered words were masked with lc.valid
 #pragma unroll
@@ -657,7 +691,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // 16-byte gathers -- twice the lookups a wave holds per round of windows compared with two lanes per block, and
         // a 20 MB table has to cross the fabric once per round whatever a wave asks of it.
         // (two rounds only in the build that has nothing else in it: next to the per-strand path the loop state spills)
-        constexpr uint32_t kBothMax = SHORT == 2 ? 512u : 256u;
+        constexpr uint32_t kBothMax = SHORT == 2 ? 512u : SHORT == 3 ? 384u : 256u;
         if (n <= kBothMax && col_begin == 0 && col_end == 2 && f.stride == 2) {
             uint8_t *stage = s_stage[wave];
             for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
@@ -669,17 +703,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             const uint32_t slice_shift = min(31u, ph.shift + 4u);
             uint32_t cf = 0, cr = 0;  // lane b: counts of bins b (low half) and 64 + b (high half), forward / reverse complement
 #pragma unroll 1
-            for (uint32_t base = 0; base < (SHORT == 2 ? n : 1u); base += 256) {
-            uint32_t bn[8][3];
-            uint64_t x0[8], x1[8];
+            for (uint32_t base = 0; base < (SHORT == 2 ? n : 1u); base += kRound) {
+            uint32_t bn[2 * T][3];
+            uint64_t x0[2 * T], x1[2 * T];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t p = base + (uint32_t)((j & 3) * 64 + lane);
+            for (int j = 0; j < 2 * T; ++j) {
+                const uint32_t p = base + (uint32_t)((j % T) * 64 + lane);
                 const bool ok = p < n;
                 uint64_t v = 0;
                 if (ok) {
                     const uint8_t *b = stage + p;
-                    if (j < 4) {
+                    if (j < T) {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
                     } else {
                         for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
@@ -690,19 +724,22 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
                     bn[j][h] = ok ? blk * 16u : 0xFFFFFFFFu;
                 }
+                // six tiles: one k-mer's hash chains at a time (interleaved, the twelve of them spill 60 registers)
+                if constexpr (T == 6) __builtin_amdgcn_sched_barrier(0);
             }
             // the AND accumulators start as "every existing bin" for the k-mers that exist (set up after the hashing: 32
             // registers less while the hash chains are in flight)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 2 * T; ++j) {
                 const bool ok = bn[j][0] != 0xFFFFFFFFu;
                 x0[j] = ok ? ~0ULL : 0ULL;
                 x1[j] = ok ? valid1 : 0ULL;
             }
-            // (the two-round build sends two k-mers' gathers at a time: with four the loop state does not fit three waves per SIMD)
-            phased_gather8x2<3, SHORT == 2 ? 2 : 4>(x0, x1, bn, f.words, slice_shift, ph);
-            cf += wave_bin_counts4(x0[0], x0[1], x0[2], x0[3], lane) | (wave_bin_counts4(x1[0], x1[1], x1[2], x1[3], lane) << 16);
-            cr += wave_bin_counts4(x0[4], x0[5], x0[6], x0[7], lane) | (wave_bin_counts4(x1[4], x1[5], x1[6], x1[7], lane) << 16);
+            // (the builds with loop state or six tiles send two k-mers' gathers at a time: with four the state does not fit
+            // three waves per SIMD)
+            phased_gather_x2<2 * T, 3, SHORT == 1 ? 4 : 2>(x0, x1, bn, f.words, slice_shift, ph);
+            cf += wave_bin_counts<T>(x0, lane) | (wave_bin_counts<T>(x1, lane) << 16);
+            cr += wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
             }
             uint32_t m = max(max(cf & 0xFFFFu, cf >> 16), max(cr & 0xFFFFu, cr >> 16));  // at most 512 each: no carry between halves
 #pragma unroll
@@ -724,8 +761,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             best = m > best ? m : best;
         }
     }
-    // SHORT: a read with more k-mers than promised (256 / 512) writes 0 here; the decision kernel turns a length above the declared
-    // max_len into RB_ERR_INVALID_ARG, so the value is never used
+    // SHORT: a read with more k-mers than promised (256 / 384 / 512) writes 0 here; the decision kernel turns a length above the
+    // declared max_len into RB_ERR_INVALID_ARG, so the value is never used
     if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)best;
 }
 
@@ -1361,6 +1398,13 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
     if constexpr (LG <= 1 && NP == 10) {
         if (a.short_only == 2 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
             hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+            return hipGetLastError();
+        }
+    }
+    if constexpr (LG <= 1 && NP == 10) {
+        if (a.short_only == 3 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
+            hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 3>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
             return hipGetLastError();
         }

@@ -145,7 +145,7 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
     assert p1.returncode == 0, p1.stderr[-2000:]
     p2, d2 = _run(["--gpus", "2"] + argv, dict(GPU_HOOKS, **small), timeout=900)
     assert p2.returncode == 0, p2.stderr[-2000:]
-    assert d1["test_reads_divisor"] == 50 and d2["n_gpus"] == 2 and "c3" in d2["config"]["workload"]
+    assert d1["test_reads_divisor"] == 50 and d2["n_gpus"] == 2 and "config3" in d2["config"]["workload"]
     assert d1["cpu_baseline"]["value"] > 0 and d2["cpu_baseline"] is None  # timed at N = 1 only
     for d in (d1, d2):
         assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
@@ -153,7 +153,7 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
         assert d["other_configs"]["c4"]["parity"]["decision_mismatches"] == 0
         assert d["other_configs"]["c5"]["latency"]["slo_met"] is True
         assert d["other_configs"]["c5"]["parity"]["replayed_decisions_equal_one_batch"] is True
-        assert d["other_configs"]["c5"]["live_step"]["concatenated_share"] > 0.1
+        assert d["other_configs"]["c5"]["live_step"]["concatenated_share"] > 0.3 and d["other_configs"]["c5"]["live_step"]["kept_up"] is True
     assert d2["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
     assert d2["other_configs"]["c4"]["config"]["decisions_sha1"] == d1["other_configs"]["c4"]["config"]["decisions_sha1"]
     assert min(d1["other_configs"]["c4"]["config"]["decisions"]) > 0

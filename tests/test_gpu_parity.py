@@ -498,6 +498,20 @@ def test_pool_shards_reads_across_engines():
             mc, best, dec, st = pool.classify(buf, offs, lens)
             assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st)
             pool.destroy()
+        # the fall-back ladder of rb_pool_create_from_files, walked by an injected failure (the copies themselves cannot
+        # fail on this box): a clone refused at its start, or lost at its end, makes that device stream the file itself --
+        # the pool comes up the same and classifies the same (code that never ran before an 8-GPU node)
+        for where in ("start", "finish"):
+            os.environ["RB_POOL_TEST_FAIL_CLONE"] = where
+            try:
+                pool = capi.Pool.from_files([0, 0, 0], paths[:1], paths[1:])
+            finally:
+                del os.environ["RB_POOL_TEST_FAIL_CLONE"]
+            assert pool.size() == 3
+            pool.set_min_split(500)
+            mc, best, dec, st = pool.classify(buf, offs, lens)
+            assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), where
+            pool.destroy()
         with pytest.raises(capi.RBError):
             capi.Pool.from_files([0, 0], [os.path.join(tmp, "missing.ibf")], [])
     # a clone is a bit-identical replica
@@ -904,3 +918,75 @@ def test_bin_sharded_rank_with_odd_stride_keeps_the_plain_kernel():
                 acc = np.maximum(acc, eng.classify(buf, offs, lens)[0][:, 0])
             assert np.array_equal(acc, expect), (n_bins, forced)
         eng.set_column_shard(0, 1)
+
+
+def test_pool_runs_micro_batches_of_several_threads_concurrently():
+    """The reference's N classification threads behind one queue (adaptive_sampling.hpp:745-751): K host threads calling
+    rb_pool_classify_batch keep K engines busy.  4 threads x 500 micro-batches on a pool of four engines (one GPU, listed
+    four times): every output equals the single-engine run, and the wall time is at most 0.45 x that of the same pool with
+    the calls serialised (rb_pool_set_serialize, what round 2 did)."""
+    import threading
+    import time
+    rng = np.random.default_rng(321)
+    ref = H.random_dna(rng, 40000)
+    filters, images = [], []
+    for i, (n_bins, bits) in enumerate(((1024, 1024 * 40009), (64, 64 * 300007))):
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, bits)
+        d.add_sequence(ref[i * 20000:(i + 1) * 20000], 500)
+        filters.append(d)
+        images.append(d.download())
+    n_threads, n_batches, m = 4, 500, 24
+    work = []
+    eng = capi.Engine(0, filters[:1], filters[1:])
+    for t in range(n_threads):
+        reads = make_reads(np.random.default_rng(900 + t), ref, n_batches * m, lo=200, hi=420)
+        buf, offs, lens = H.pack_reads(reads)
+        work.append((buf, offs, lens, eng.classify(buf, offs, lens)))
+    pool = capi.Pool([0, 0, 0, 0], images[:1], images[1:])
+    pool.set_min_split(4096)  # micro-batches are never split: each goes to one engine
+
+    def run():
+        errors, outs = [], [None] * n_threads
+
+        def worker(t):
+            # straight through the C ABI with buffers made beforehand: ctypes drops the GIL for the call, and the few
+            # microseconds of interpreter around it are not what is being measured
+            try:
+                buf, offs, lens, _ = work[t]
+                n = len(lens)
+                mc = np.zeros((n, 2), dtype=np.uint16)
+                best = np.full(n, -1, dtype=np.int32)
+                dec = np.zeros(n, dtype=np.uint8)
+                st = np.zeros(n, dtype=np.uint8)
+                fn, h = capi.lib().rb_pool_classify_batch, pool.h
+                args = [(buf.ctypes.data, offs[b * m:].ctypes.data, lens[b * m:].ctypes.data, m, 0.1, 0.95, 0,
+                         mc[b * m:].ctypes.data, best[b * m:].ctypes.data, dec[b * m:].ctypes.data, st[b * m:].ctypes.data)
+                        for b in range(n_batches)]
+                for a in args:
+                    rc = fn(h, *a)
+                    assert rc == 0, rc
+                outs[t] = [mc, best, dec, st]
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        wall = time.perf_counter() - t0
+        assert not errors, errors
+        for t in range(n_threads):
+            for got, exp in zip(outs[t], work[t][3]):
+                assert np.array_equal(got, exp), t
+        return wall
+
+    run()  # warm-up: code objects, staging buffers, threshold tables of all four engines
+    pool.set_serialize(True)
+    serial = min(run(), run())
+    pool.set_serialize(False)
+    concurrent = min(run(), run())
+    print("pool: 4 threads x 500 micro-batches of %d reads: serialised %.3f s, concurrent %.3f s (%.2fx)"
+          % (m, serial, concurrent, concurrent / serial))
+    assert concurrent <= 0.45 * serial, (concurrent, serial)
+    pool.destroy()
