@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void gather(const uint64_t *__restrict__ table
 // streams the table in the background instead of serving demand misses.
 template <int S, int NBUF, int PF>
 __global__ __launch_bounds__(256) void gather_phased(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
-                                                     uint32_t dt, uint64_t *out)
+                                                     uint32_t dt, uint64_t *out, uint32_t slack = 0)
 {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t per_slice = (n_elems + S - 1) / S;
@@ -115,7 +115,9 @@ __global__ __launch_bounds__(256) void gather_phased(const uint64_t *__restrict_
 #pragma unroll 1
         for (uint32_t q = 0; q < (uint32_t)S; ++q) {
             const uint64_t w = w0 + q;
-            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            // slack > 0 (round 3): window w opens `slack` ticks early, i.e. a wave may run ahead of the clock by that much and
+            // two slices are live in L2 at a time -- the bursts at the window boundaries overlap instead of queueing
+            while (wall_clock64() + slack < w * dt) __builtin_amdgcn_s_sleep(4);
             const uint32_t p = (uint32_t)(w % S);
             uint32_t pf[PF > 0 ? PF : 1];
             if constexpr (PF > 0) {
@@ -149,6 +151,77 @@ __global__ __launch_bounds__(256) void gather_phased(const uint64_t *__restrict_
         for (int u = 0; u < NBUF / 3; ++u) acc += a[u];
     }
     if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+// "phased pump" (round 3): the prefetch of the next slice done by DEDICATED waves instead of by the gathering waves (whose
+// prefetch loads queue in the same in-order vmcnt as their gathers: the PF variants above lose 30-50 %).  The first
+// `n_pump` workgroups of the grid -- dealt round-robin over the XCDs, so n_pump / 8 of them per XCD -- never gather: during
+// window w they touch every 128-byte line of slice w+1 (their XCD's L2 then holds it when its window opens) and leave when
+// the last gathering workgroup has signed off.  The gathering workgroups are those of "phased" with PF = 0.
+template <int S, int NBUF>
+__global__ __launch_bounds__(256) void gather_phased_pump(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                          uint32_t dt, uint64_t *out, uint32_t n_pump, uint32_t *done,
+                                                          uint32_t lead)
+{
+    const uint32_t per_slice = (n_elems + S - 1) / S;
+    if (blockIdx.x < n_pump) {
+        const uint32_t lines = per_slice / 16;
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t me = (blockIdx.x / 8) * 4 + (threadIdx.x >> 6), n_me = (n_pump / 8) * 4;
+        const uint32_t n_workers = gridDim.x - n_pump;
+        uint32_t acc = 0;
+        uint64_t w = wall_clock64() / dt;
+        for (uint32_t guard = 0; guard < (1u << 22); ++guard) {
+            // `lead` = which slice to pull during window w: w + 1 (the next one), pulled from the start of window w
+            const uint32_t p1 = (uint32_t)((w + lead) % S);
+            for (uint32_t line = me * 64 + lane; line < lines; line += n_me * 64) {
+                const uint64_t e = (uint64_t)p1 * per_slice + (uint64_t)line * 16;
+                acc ^= reinterpret_cast<const uint32_t *>(table + (e < n_elems ? e : 0))[0];
+            }
+            if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_workers) break;
+            while (wall_clock64() / dt <= w) __builtin_amdgcn_s_sleep(8);
+            w = wall_clock64() / dt;
+        }
+        if (acc == 0x12345u) out[1] = acc;
+        return;
+    }
+    const uint64_t tid = (uint64_t)(blockIdx.x - n_pump) * blockDim.x + threadIdx.x;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t idx[NBUF];
+        uint32_t sl[NBUF];
+        uint64_t a[NBUF / 3];
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            idx[u] = (uint32_t)(((s >> 32) * (uint64_t)n_elems) >> 32);
+            sl[u] = idx[u] / per_slice;
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) a[u] = ~0ULL;
+        const uint64_t w0 = wall_clock64() / dt;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)S; ++q) {
+            const uint64_t w = w0 + q;
+            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            const uint32_t p = (uint32_t)(w % S);
+            uint64_t v[NBUF];
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) {
+                v[u] = ~0ULL;
+                if (sl[u] == p) v[u] = table[idx[u]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) a[u / 3] &= v[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) acc += a[u];
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // "phased dense": what the phased scheme would deliver if the lookups of a window were COMPACTED -- the same 24 lookups
@@ -282,7 +355,7 @@ static void *alloc_kind(size_t bytes, int kind);
 static void one(const char *mode, int mib, int esz, int policy, int kind, uint64_t *out);
 
 template <int S, int NBUF, int PF = 0>
-static void run_phased(int mib, uint32_t dt, uint64_t *out)
+static void run_phased(int mib, uint32_t dt, uint64_t *out, uint32_t slack = 0)
 {
     const size_t bytes = (size_t)mib << 20;
     uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
@@ -296,7 +369,7 @@ static void run_phased(int mib, uint32_t dt, uint64_t *out)
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(a);
-        hipLaunchKernelGGL((gather_phased<S, NBUF, PF>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out);
+        hipLaunchKernelGGL((gather_phased<S, NBUF, PF>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out, slack);
         (void)hipEventRecord(b);
         (void)hipEventSynchronize(b);
         float ms = 0;
@@ -304,10 +377,44 @@ static void run_phased(int mib, uint32_t dt, uint64_t *out)
         if (rep && ms < best) best = ms;
     }
     const double gathers = (double)blocks * 256 * iters * NBUF;
-    printf("phased table %4d MiB  S=%2d  %2d lookups buffered per lane  prefetch %d  window %5.2f us : %7.1f G gathers/s\n", mib, S,
-           NBUF, PF, dt / 100.0, gathers / best / 1e6);
+    printf("phased table %4d MiB  S=%2d  %2d lookups buffered per lane  prefetch %d  window %5.2f us  slack %5.2f us : %7.1f G gathers/s\n", mib, S,
+           NBUF, PF, dt / 100.0, slack / 100.0, gathers / best / 1e6);
     fflush(stdout);
     (void)hipFree(t);
+}
+
+template <int S, int NBUF>
+static void run_phased_pump(int mib, uint32_t dt, uint64_t *out, int pumps_per_xcd, uint32_t lead = 1)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+    if (!t) return;
+    uint32_t *done = nullptr;
+    (void)hipMalloc(&done, 4);
+    const uint32_t n = (uint32_t)(bytes / 8);
+    const uint32_t iters = 16 * 24 / NBUF;
+    const int blocks = 256 * 64;
+    const uint32_t n_pump = 8u * pumps_per_xcd;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipMemset(done, 0, 4);
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather_phased_pump<S, NBUF>), dim3(blocks + n_pump), dim3(256), 0, 0, t, n, iters, dt, out, n_pump, done, lead);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * NBUF;
+    printf("phased PUMP table %4d MiB  S=%2d  %2d lookups per lane  %d pump workgroups per XCD (lead %u)  window %5.2f us : %7.1f G gathers/s\n",
+           mib, S, NBUF, pumps_per_xcd, lead, dt / 100.0, gathers / best / 1e6);
+    fflush(stdout);
+    (void)hipFree(t);
+    (void)hipFree(done);
 }
 
 template <int S, int NBUF>
@@ -474,6 +581,32 @@ int main(int argc, char **argv)
         }
         for (uint32_t dt : {200u, 400u}) run_phased<4, 24>(10, dt, out);
         for (uint32_t dt : {400u, 800u}) run_phased<16, 48>(40, dt, out);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_slack")) {
+        for (uint32_t dt : {150u, 200u, 300u, 450u})
+            for (uint32_t sl : {0u, dt / 2, dt, 2 * dt}) run_phased<8, 24>(10, dt, out, sl);
+        for (uint32_t dt : {100u, 150u, 200u, 300u})
+            for (uint32_t sl : {0u, dt / 2, dt, 2 * dt}) run_phased<16, 24>(10, dt, out, sl);
+        for (uint32_t dt : {200u, 300u, 450u, 600u})
+            for (uint32_t sl : {0u, dt / 2, dt}) run_phased<8, 24>(20, dt, out, sl);
+        for (uint32_t dt : {100u, 150u, 200u, 300u})
+            for (uint32_t sl : {0u, dt / 2, dt, 2 * dt}) run_phased<16, 24>(20, dt, out, sl);
+        for (uint32_t dt : {150u, 200u, 300u})
+            for (uint32_t sl : {0u, dt}) run_phased<8, 48>(10, dt, out, sl);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_pump")) {
+        for (int mib : {10, 20}) {
+            for (uint32_t dt : {200u, 300u, 450u}) run_phased<8, 24>(mib, dt, out);  // the scheme as shipped, same box
+            for (int pumps : {1, 2, 4})
+                for (uint32_t dt : {100u, 150u, 200u, 300u, 450u}) run_phased_pump<8, 24>(mib, dt, out, pumps);
+            for (int pumps : {2, 4})
+                for (uint32_t dt : {75u, 100u, 150u, 200u, 300u}) run_phased_pump<16, 24>(mib, dt, out, pumps);
+            for (uint32_t dt : {150u, 200u, 300u}) run_phased_pump<8, 48>(mib, dt, out, 2);
+            for (uint32_t dt : {100u, 150u, 200u}) run_phased_pump<16, 48>(mib, dt, out, 2);
+            for (uint32_t dt : {150u, 200u, 300u}) run_phased_pump<8, 24>(mib, dt, out, 2, 0);  // control: pumping the CURRENT slice
+        }
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "phased_sorted")) {

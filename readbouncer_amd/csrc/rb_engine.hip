@@ -106,7 +106,7 @@ struct rb_engine {
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
-    int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp): one round of six tiles per strand for one-word blocks (1), two-word blocks too (2); 0: two rounds of four
+    int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp), one round of six tiles per strand -- 1: one-word blocks of tables <= 16 MiB (default); 2: every one-word table; 3: two-word blocks too; 0: never (two rounds of four)
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
@@ -897,7 +897,11 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         }
     }
     // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
-    if (a.short_only == 2 && kmers <= 384 && (int)e->six_tile_kernel > a.lg) a.short_only = 3;
+    // (measured, profiles/r03/six_tiles.txt: +10 % on the 10 MB one-word filters of the README shape, -4 % on a 20 MB one-word
+    // table, two-word blocks spill inside the window loop: the default takes it for one-word blocks of tables up to 16 MiB)
+    if (a.short_only == 2 && kmers <= 384 &&
+        (e->six_tile_kernel > 1 + a.lg || (e->six_tile_kernel == 1 && a.lg == 0 && table_bytes <= (16ull << 20))))
+        a.short_only = 3;
     a.split_parts = 1;
     a.split_sub = 1;
     if (a.split_waves >= 2)

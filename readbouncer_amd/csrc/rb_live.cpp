@@ -118,63 +118,60 @@ int rb_live_process(rb_live *lv, const char *ids, const uint64_t *id_offsets, co
                 else later.push_back(std::move(it));
             }
         }
-        // pass 1: the new chunk on its own
+        // ONE GPU call per round: the new chunks on their own, and -- speculatively, in the same batch -- the concatenation
+        // stored + new chunk for every read that once_seen already holds.  The reference classifies the concatenation only
+        // after the chunk alone came back undecided (adaptive_sampling.hpp:276-288); asking for both at once costs GPU work
+        // for the reads that are decided by the chunk alone (rare: a read in once_seen was undecided before) and saves the
+        // second call, i.e. half the latency of the live step.  Which answer counts is decided exactly as in the reference.
         std::vector<const char *> ptrs;
         std::vector<uint32_t> ls;
         for (const Item &it : round) { ptrs.push_back(it.seq); ls.push_back(it.len); }
+        std::vector<size_t> extra(round.size(), (size_t)-1);  // position of the read's concatenation in the batch
+        std::vector<std::string> concat;
+        concat.reserve(round.size());
+        for (size_t j = 0; j < round.size(); ++j) {
+            auto f = lv->once_seen.find(round[j].id);
+            if (f == lv->once_seen.end()) continue;
+            extra[j] = round.size() + concat.size();
+            concat.push_back(f->second.first + std::string(round[j].seq, round[j].len));
+        }
+        for (const std::string &c : concat) { ptrs.push_back(c.data()); ls.push_back((uint32_t)c.size()); }
         std::vector<uint8_t> dec, st;
         int rc = classify_strings(lv, ptrs, ls, dec, st);
         if (rc != RB_OK) return rc;
-        // pass 2: undecided chunks of reads seen before, concatenated with what is stored
-        std::vector<size_t> again;
-        std::vector<std::string> concat;
         for (size_t j = 0; j < round.size(); ++j) {
             const Item &it = round[j];
             if (st[j] != RB_OK) {  // exception path: nothing is pushed, nothing is stored
                 if (out_status) out_status[it.index] = st[j];
                 continue;
             }
-            if (dec[j] == 1) {
+            if (dec[j] == 1 || dec[j] == 2) {  // decided by the chunk alone (:241-275)
                 lv->once_seen.erase(it.id);
-                out_action[it.index] = 1;
-            } else if (dec[j] == 2) {
+                out_action[it.index] = dec[j];
+                continue;
+            }
+            if (extra[j] == (size_t)-1) {  // undecided for the first time: remember the chunk (:336)
+                lv->once_seen[it.id] = std::make_pair(std::string(it.seq, it.len), (uint8_t)1);
+                continue;
+            }
+            // undecided, seen before: the concatenation decides (:284-329)
+            const size_t a = extra[j];
+            std::string &cc = concat[a - round.size()];
+            if (out_classified_len) out_classified_len[it.index] = (uint32_t)cc.size();
+            if (st[a] != RB_OK) {
+                if (out_status) out_status[it.index] = st[a];
+                continue;
+            }
+            if (dec[a] == 1 || dec[a] == 2) {
                 lv->once_seen.erase(it.id);
-                out_action[it.index] = 2;
+                out_action[it.index] = dec[a];
+            } else if (cc.size() > lv->max_undecided_len) {
+                lv->once_seen.erase(it.id);
+                out_action[it.index] = 2;  // unblock = false -> stop_receiving_data
             } else {
                 auto f = lv->once_seen.find(it.id);
-                if (f != lv->once_seen.end()) {
-                    again.push_back(j);
-                    concat.push_back(f->second.first + std::string(it.seq, it.len));
-                } else {
-                    lv->once_seen[it.id] = std::make_pair(std::string(it.seq, it.len), (uint8_t)1);
-                }
-            }
-        }
-        if (!again.empty()) {
-            ptrs.clear();
-            ls.clear();
-            for (const std::string &s : concat) { ptrs.push_back(s.data()); ls.push_back((uint32_t)s.size()); }
-            std::vector<uint8_t> dec2, st2;
-            rc = classify_strings(lv, ptrs, ls, dec2, st2);
-            if (rc != RB_OK) return rc;
-            for (size_t a = 0; a < again.size(); ++a) {
-                const Item &it = round[again[a]];
-                if (out_classified_len) out_classified_len[it.index] = (uint32_t)concat[a].size();
-                if (st2[a] != RB_OK) {
-                    if (out_status) out_status[it.index] = st2[a];
-                    continue;
-                }
-                if (dec2[a] == 1 || dec2[a] == 2) {
-                    lv->once_seen.erase(it.id);
-                    out_action[it.index] = dec2[a];
-                } else if (concat[a].size() > lv->max_undecided_len) {
-                    lv->once_seen.erase(it.id);
-                    out_action[it.index] = 2;  // unblock = false -> stop_receiving_data
-                } else {
-                    auto f = lv->once_seen.find(it.id);
-                    const uint8_t step = f != lv->once_seen.end() ? (uint8_t)(f->second.second + 1) : (uint8_t)1;
-                    lv->once_seen[it.id] = std::make_pair(std::move(concat[a]), step);
-                }
+                const uint8_t step = f != lv->once_seen.end() ? (uint8_t)(f->second.second + 1) : (uint8_t)1;
+                lv->once_seen[it.id] = std::make_pair(std::move(cc), step);
             }
         }
         todo.swap(later);

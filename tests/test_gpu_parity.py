@@ -900,7 +900,8 @@ def test_bin_sharded_rank_with_odd_stride_keeps_the_plain_kernel():
     for n_bins in (3072, 2560):
         W = (n_bins + 63) // 64
         d = capi.DeviceIBF.create(0, n_bins, 3, 13, W * 64 * 24007)  # 9.2 / 7.7 MB: inside the phased size range
-        assert d.device_stride() == W and (W & (W - 1)) != 0
+        stride = d.device_stride()  # 48 for both: 48 words as they are, 40 words padded to the next multiple of 16
+        assert stride == (W + 15) // 16 * 16 and (stride & (stride - 1)) != 0
         d.fill_synth(17)
         d.add_sequence(ref, 50)
         o, _keep = oracle_view(d)
