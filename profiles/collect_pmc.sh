@@ -6,6 +6,7 @@ set -u
 W=$1; N=$2; OUT=$3; EXTRA=${4:-}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p "$OUT"
+echo "$N" > "$OUT/reads.txt"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--workload $W --reads $N --steps 2 --warmup 1 --no-cpu-baseline --no-latency $EXTRA"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1

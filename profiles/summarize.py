@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 if os.path.exists(os.path.join(src, "hbm_peak.txt")):
     shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
-for w in ("c2", "c3", "c4", "c5", "readme", "c1"):
+for w in ("c2", "c3", "c4", "c5", "readme", "readme360", "c1"):
     hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
@@ -52,12 +52,12 @@ def counter_means(path):
 from readbouncer_amd import synth  # noqa: E402
 
 rows, traffic = [], {}
+MOCK = ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]
 FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
-           "readme": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"], "c1_r01": ["c1"],
-           "readme_r01": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]}
-READ_LEN = {"readme": 250, "readme_r01": 250}
+           "readme": MOCK, "c1_r01": ["c1"], "readme_r01": MOCK, "readme_skew": MOCK, "readme360": MOCK, "readme360_six0": MOCK}
+READ_LEN = {"readme": 250, "readme_r01": 250, "readme_skew": 250}
 when = os.environ.get("RB_EVIDENCE_DATE", "")
-for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01"):
+for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):
         continue
@@ -72,6 +72,8 @@ for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r0
     if "FETCH_SIZE" not in m:
         continue
     reads = 500_000 if w == "grch38_f100k" else 1_000_000
+    if os.path.exists(os.path.join(d, "reads.txt")):  # written by collect_pmc.sh: reads per launch of that pass
+        reads = int(open(os.path.join(d, "reads.txt")).read().split()[0])
     wls = [synth.WORKLOADS[k] for k in FILTERS[w]]
     alg = synth.algorithmic_bytes_per_read(READ_LEN.get(w, 360), [(x["n_bins"], x["k"], x["h"]) for x in wls])
     hbm = m["FETCH_SIZE"] * 1024 * 2
@@ -96,7 +98,12 @@ with open(os.path.join(dst, "pmc_summary.csv"), "w") as fh:
     for r in rows:
         fh.write("%s,%s,%s,%d,%g,%.3f\n" % r)
 if traffic:
-    with open(os.path.join(root, "profiles", "traffic.json"), "w") as fh:
-        json.dump(traffic, fh, indent=1)
+    tpath = os.path.join(root, "profiles", "traffic.json")
+    merged = {}
+    if os.path.exists(tpath):  # workloads not collected this time keep their earlier (dated) entry
+        merged = json.load(open(tpath))
+    merged.update(traffic)
+    with open(tpath, "w") as fh:
+        json.dump(merged, fh, indent=1)
 for w, t in traffic.items():
     print(w, "traffic/algorithmic %.4f" % t["traffic_over_algorithmic"], "rdreq x128 / fetch %.4f" % (t["rdreq_x128B"] / t["hbm_bytes_per_launch"]))
