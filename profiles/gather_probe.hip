@@ -224,6 +224,84 @@ __global__ __launch_bounds__(256) void gather_phased_pump(const uint64_t *__rest
     if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// "phased buf" (round 3): the predication of the phased gathers done by the BOUNDS CHECK of a buffer resource instead of by
+// exec masks -- per window the wave points a raw buffer descriptor at the slice of the moment (base = slice start,
+// num_records = slice bytes) and issues every lookup as buffer_load_dwordx2 with offset (lookup - slice start): lanes whose
+// lookup lies in another slice are out of range, make no memory access and get 0 back.  No compare, no saveexec, no branch
+// around a load: one subtract and one load per lookup and window, and an OR to accumulate (the table would be stored
+// complemented, so that the AND over the h words becomes an OR and the zeros of out-of-range lanes are neutral).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int S, int NBUF>
+__global__ __launch_bounds__(256) void gather_phased_buf(const uint64_t *__restrict__ table, uint32_t n_elems, uint32_t iters,
+                                                         uint32_t dt, uint64_t *out)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t per_slice = (n_elems + S - 1) / S;
+    const uint32_t slice_bytes = per_slice * 8;
+    uint64_t acc = 0;
+    uint64_t s = mix(tid + 1);
+    for (uint32_t it = 0; it < iters; ++it) {
+        uint32_t off[NBUF];
+        uint64_t a[NBUF / 3];
+#pragma unroll
+        for (int u = 0; u < NBUF; ++u) {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            off[u] = (uint32_t)(((s >> 32) * (uint64_t)n_elems) >> 32) * 8u;
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) a[u] = 0;
+        const uint64_t w0 = wall_clock64() / dt;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)S; ++q) {
+            const uint64_t w = w0 + q;
+            while (wall_clock64() / dt < w) __builtin_amdgcn_s_sleep(4);
+            const uint32_t p = (uint32_t)(w % S);
+            const uint32_t start = p * slice_bytes;
+            const uint32_t recs = min(slice_bytes, n_elems * 8u - start);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)table + start), 0, (int)recs, 0x00020000);
+            u32x2_t v[NBUF];
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) v[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, off[u] - start, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < NBUF; ++u) a[u / 3] |= ((uint64_t)v[u].y << 32) | v[u].x;
+        }
+#pragma unroll
+        for (int u = 0; u < NBUF / 3; ++u) acc += a[u];
+    }
+    if (acc == 0x123456789ULL) out[0] = acc;
+}
+
+static void *alloc_kind(size_t bytes, int kind);
+template <int S, int NBUF>
+static void run_phased_buf(int mib, uint32_t dt, uint64_t *out)
+{
+    const size_t bytes = (size_t)mib << 20;
+    uint64_t *t = (uint64_t *)alloc_kind(bytes, 0);
+    if (!t) return;
+    const uint32_t n = (uint32_t)(bytes / 8);
+    const uint32_t iters = 16 * 24 / NBUF;
+    const int blocks = 256 * 64;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((gather_phased_buf<S, NBUF>), dim3(blocks), dim3(256), 0, 0, t, n, iters, dt, out);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (rep && ms < best) best = ms;
+    }
+    const double gathers = (double)blocks * 256 * iters * NBUF;
+    printf("phased BUF (bounds-checked buffer loads) table %4d MiB  S=%2d  %2d lookups per lane  window %5.2f us : %7.1f G gathers/s\n", mib, S,
+           NBUF, dt / 100.0, gathers / best / 1e6);
+    fflush(stdout);
+    (void)hipFree(t);
+}
+
 // "phased dense": what the phased scheme would deliver if the lookups of a window were COMPACTED -- the same 24 lookups
 // per lane and round, but as NBUF/S full-width load instructions per window instead of NBUF predicated ones with 1/S of
 // the lanes active each (is the texture-address path, one vector-memory instruction per ~25 cycles and CU, the limit?)
@@ -581,6 +659,16 @@ int main(int argc, char **argv)
         }
         for (uint32_t dt : {200u, 400u}) run_phased<4, 24>(10, dt, out);
         for (uint32_t dt : {400u, 800u}) run_phased<16, 48>(40, dt, out);
+        return 0;
+    }
+    if (argc >= 2 && !strcmp(argv[1], "phased_buf")) {
+        for (int mib : {10, 20}) {
+            for (uint32_t dt : {200u, 300u, 450u}) run_phased<8, 24>(mib, dt, out);  // exec-masked loads, same box
+            for (uint32_t dt : {100u, 150u, 200u, 250u, 300u, 450u, 600u}) run_phased_buf<8, 24>(mib, dt, out);
+            for (uint32_t dt : {75u, 100u, 150u, 200u, 300u}) run_phased_buf<16, 24>(mib, dt, out);
+            for (uint32_t dt : {150u, 200u, 300u, 450u}) run_phased_buf<8, 48>(mib, dt, out);
+            for (uint32_t dt : {200u, 300u, 450u, 600u}) run_phased_buf<4, 24>(mib, dt, out);
+        }
         return 0;
     }
     if (argc >= 2 && !strcmp(argv[1], "phased_slack")) {

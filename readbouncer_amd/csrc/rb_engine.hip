@@ -98,15 +98,15 @@ struct rb_engine {
     uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
     // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
     uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 32ull << 20;
-    // window length in 10 ns ticks: base + per MiB of table (+ short_extra when the both-strands-only kernel runs: it keeps
-    // four to five waves per SIMD, and more waves want longer windows).  Measured optimum: 4-5 us for the general kernel on a
-    // 20 MB one-word filter (360 bp reads), 5.5-6 us for the short-read kernels on 10 and 20 MB filters; flat within +-1 us.
-    uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0, phase_short_extra_ticks = 125;
+    // window length in 10 ns ticks.  phase_explicit: base + per MiB of table, as given to rb_engine_set_phased; otherwise the
+    // built-in rule of phase_window_ticks() below (measured per kernel shape, profiles/r03/window_sweep.txt).
+    uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0;
+    bool phase_explicit = false;
     uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
     bool short_read_kernel = true;
-    int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp), one round of six tiles per strand -- 1: one-word blocks of tables <= 16 MiB (default); 2: every one-word table; 3: two-word blocks too; 0: never (two rounds of four)
+    int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp): one round of six tiles per strand (RB_SIX_TILES=0: two rounds of four)
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
     uint32_t split_max_parts = 8, split_max_sub = 4;  // latency kernel on wide filters: workgroups per read, shares per tile
     DevBuf d_split_ws, d_split_tickets;
@@ -594,6 +594,11 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) e->wall_clock_khz = (uint32_t)khz;
         else (void)hipGetLastError();
     }
+    // RB_REVCOMP_OF_N=4: the other candidate of the recalled reverse-complement-of-N rule (ibf_spec.h) for a whole process --
+    // the CLI and the C++ mirror create their engines themselves -- without a rebuild; rb_engine_set_revcomp_of_n is the API
+    if (const char *v = std::getenv("RB_REVCOMP_OF_N")) {
+        if (std::atoi(v) == 3 || std::atoi(v) == 4) e->revcomp_of_n = (uint32_t)std::atoi(v);
+    }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
     if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -701,11 +706,11 @@ int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_ta
     if (base_ticks || ticks_per_mib) {  // an explicit window length replaces the built-in rule
         e->phase_base_ticks = base_ticks;
         e->phase_ticks_per_mib = ticks_per_mib;
-        e->phase_short_extra_ticks = 0;
+        e->phase_explicit = true;
     } else {
         e->phase_base_ticks = 450;
         e->phase_ticks_per_mib = 0;
-        e->phase_short_extra_ticks = 125;
+        e->phase_explicit = false;
     }
     e->phase_min_reads = min_reads;
     e->short_read_kernel = !(min_table_bytes == 0 && max_table_bytes == 0 && base_ticks == 0 && ticks_per_mib == 0 && min_reads == 0);
@@ -840,6 +845,30 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     return RB_OK;
 }
 
+// Window length of the clock-phased gathers in 10 ns ticks, by kernel shape and table size.  Measured on single filters
+// (profiles/r03/window_sweep.txt; K1 ms per 1 M reads at the optimum).  A window that is too short costs far more than one
+// that is too long -- waves that cannot finish a window in time fall out of step with the clock and gather from slices that
+// have left the L2 (c1: 20.7 ms at 1100 ticks, 13.5 at 1200, 13.7 at 1350) -- so the rule sits on the long side of each optimum:
+//   both strands, one round of 4 tiles (<= 256 k-mers, 250 bp): one-word 10 MB 725 (7.6 ms), two-word 20 MB 875 (10.1 ms)
+//   both strands, one round of 6 tiles (<= 384 k-mers, 360 bp): one-word 10 MB 850 (11.3 ms), one-word 20 MB 1250 (13.5 ms),
+//                                                                two-word 20 MB 1000 (15.0 ms; four waves per SIMD, the others five-six)
+//   two rounds of 4 tiles (<= 512 k-mers): 575-600;  per-strand tiles of the general build (longer reads, 3-8 word blocks):
+//   one-word blocks 600 (c1 at 600 bp 18.3 ms, a 10 MB filter at 1500 bp 11.9 ms per 200 k reads), wider blocks 450
+// Between the measured sizes the length is interpolated over the table size (the slice an XCD's L2 has to take in per window).
+static uint64_t phase_window_ticks(int short_only, int lg, uint64_t table_bytes)
+{
+    const double mib = (double)table_bytes / 1048576.0;
+    const double over = std::min(std::max(mib - 10.0, 0.0), 22.0);  // MiB above the 10 MB case
+    double t;
+    switch (short_only) {
+    case 1: t = 725.0 + 15.0 * over; break;
+    case 3: t = lg == 0 ? 850.0 + 40.0 * over : 1000.0 + 15.0 * (over - 10.0); break;
+    case 2: t = 575.0 + 2.5 * over; break;
+    default: t = lg == 0 ? 600.0 : 450.0; break;
+    }
+    return (uint64_t)std::max(t, 400.0);
+}
+
 // Kernel geometry of one filter for a batch: the rank's word columns (bin-sharded operation), lanes per block, words
 // per lane, counter planes, column slices, and the form of K1 (throughput, or latency with its waves / workgroups per
 // read).  false = this rank owns no column of the filter.
@@ -870,6 +899,10 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
     a.phase = PhaseCfg{0, 0, 0, 0, 0};
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
+    // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
+    // (profiles/r03/window_sweep.txt: with the bounds-checked gathers and its own window length the six-tile kernel takes 28 %
+    // less time than two rounds of four tiles on one-word 10 MB filters, 15 % on a one-word 20 MB table, 22 % on two-word blocks)
+    if (a.short_only == 2 && kmers <= 384 && e->six_tile_kernel) a.short_only = 3;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
     if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
         // the phased kernels take a lookup's slice from its byte offset by a shift: block strides that are a power of two
@@ -880,8 +913,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             n_reads >= e->phase_min_reads && stride_pow2) {
             uint32_t sh = 0;
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
-            uint64_t ticks = e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib;
-            if (a.planes <= 10 && a.short_only && a.lg <= 1) ticks += e->phase_short_extra_ticks;
+            uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
+                                               : phase_window_ticks(a.planes <= 10 && a.lg <= 1 ? a.short_only : 0, a.lg, table_bytes);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             ticks = std::max<uint64_t>(1, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock
             a.phase.shift = sh;
@@ -896,12 +929,6 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.inv_ticks = 0;
         }
     }
-    // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
-    // (measured, profiles/r03/six_tiles.txt: +10 % on the 10 MB one-word filters of the README shape, -4 % on a 20 MB one-word
-    // table, two-word blocks spill inside the window loop: the default takes it for one-word blocks of tables up to 16 MiB)
-    if (a.short_only == 2 && kmers <= 384 &&
-        (e->six_tile_kernel > 1 + a.lg || (e->six_tile_kernel == 1 && a.lg == 0 && table_bytes <= (16ull << 20))))
-        a.short_only = 3;
     a.split_parts = 1;
     a.split_sub = 1;
     if (a.split_waves >= 2)

@@ -279,6 +279,41 @@ struct BaseSrc {
 // The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the
 // window of its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  With ph = {shift 0.., n_slices 1, inv_ticks 0} and
 // a slice_shift of 31 this is one batch of predicated gathers with no waiting (tables that need no phasing).
+// RB_PHASED_BUF (default 1): the predication of a window's gathers is done by the BOUNDS CHECK of a raw buffer descriptor
+// instead of by exec masks.  Per window the wave points the descriptor at the slice of the moment (base = slice start,
+// num_records = slice bytes) and issues every lookup as buffer_load with the offset (lookup - slice start): a lane whose lookup
+// lies in another slice (or has no lookup: offset 0xFFFFFFFF) is out of range, makes no memory access and gets 0 back, which
+// an OR with the lane's out-of-range mask turns into the neutral all-ones.  No saveexec, no branch around a load, no scalar
+// work per lookup: the exec-masked form costs about 11 instructions per lookup and window, seven of them scalar or branches
+// (profiles/r03: waves of the 250 bp kernels wait for instruction issue 45 % of their cycles, for memory 33 %).
+#ifndef RB_PHASED_BUF
+#define RB_PHASED_BUF 1
+#endif
+// k-mers of a lane whose gathers go out together (B: one-word blocks, three 8-byte loads per k-mer; KB: two-word blocks,
+// three 16-byte loads per k-mer).  Every load in flight holds its destination registers, so the batch size sets the
+// occupancy: with ALL lookups of a window in flight (8 k-mers, 48 registers) the 250 bp one-word kernel has five waves per
+// SIMD, with two k-mers per batch six (73 VGPRs) -- four waits per window instead of one, and 7 % less time per read; the
+// six-tile kernel goes from four to five waves (93 VGPRs), the two-word 250 bp kernel from four to five (86).  Measured
+// per shape in profiles/r03/window_sweep.txt; the window lengths of rb_engine.hip belong to these values.
+#ifndef RB_GATHER_B1
+#define RB_GATHER_B1 2
+#endif
+#ifndef RB_GATHER_KB1
+#define RB_GATHER_KB1 1
+#endif
+#ifndef RB_GATHER_B3
+#define RB_GATHER_B3 2
+#endif
+#ifndef RB_GATHER_KB3
+#define RB_GATHER_KB3 2
+#endif
+#ifndef RB_GATHER_BG  // per-strand tiles of the general build (reads of more than 512 k-mers, blocks of 3-8 words)
+#define RB_GATHER_BG 2
+#endif
+typedef unsigned int rb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int rb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBufRsrcWord3 = 0x00020000;  // raw buffer, DATA_FORMAT = 32 bit (gfx9 family)
+
 template <int N, int H, bool NT, int B = N>
 __device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (&bn)[N][H], const uint64_t *words,
                                               uint32_t slice_shift, const PhaseCfg ph)
@@ -294,6 +329,42 @@ __device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (
             if ((int32_t)(wn - (w0 + q)) >= 0) break;
             __builtin_amdgcn_s_sleep(2);
         }
+#if RB_PHASED_BUF
+        {
+            const uint32_t start = cur << slice_shift;  // slice_shift == 31 goes with a single slice (cur == 0)
+            const uint32_t span = 1u << slice_shift;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
+#pragma unroll
+            for (int part = 0; part < N / B; ++part) {
+                rb_u32x2 ld[B][H];
+#pragma unroll
+                for (int uu = 0; uu < B; ++uu) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        // (the offsets are made opaque at both uses: otherwise `offset - start` of all 24 lookups is computed up
+                        // front and kept for the masks below -- 24 registers, a wave per SIMD on the 250 bp kernel)
+                        uint32_t off = bn[part * B + uu][h];
+                        asm volatile("" : "+v"(off));
+                        ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, off - start, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int uu = 0; uu < B; ++uu) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        uint32_t off = bn[part * B + uu][h];
+                        asm volatile("" : "+v"(off));
+                        const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
+                        x[part * B + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
+                    }
+                }
+            }
+            cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
+            continue;
+        }
+#endif
 #pragma unroll
         for (int part = 0; part < N / B; ++part) {
             uint64_t ld[B][H];
@@ -337,6 +408,41 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
             if ((int32_t)(wn - (w0 + q)) >= 0) break;
             __builtin_amdgcn_s_sleep(2);
         }
+#if RB_PHASED_BUF
+        {
+            const uint32_t start = cur << slice_shift;
+            const uint32_t span = 1u << slice_shift;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
+#pragma unroll
+            for (int part = 0; part < N / KB; ++part) {
+                rb_u32x4 ld[KB][H];
+#pragma unroll
+                for (int uu = 0; uu < KB; ++uu) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        uint32_t off = bn[part * KB + uu][h];
+                        asm volatile("" : "+v"(off));
+                        ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int uu = 0; uu < KB; ++uu) {
+#pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        uint32_t off = bn[part * KB + uu][h];
+                        asm volatile("" : "+v"(off));
+                        const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
+                        x0[part * KB + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
+                        x1[part * KB + uu] &= (((uint64_t)(ld[uu][h].w | out)) << 32) | (ld[uu][h].z | out);
+                    }
+                }
+            }
+            cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
+            continue;
+        }
+#endif
 #pragma unroll
         for (int part = 0; part < N / KB; ++part) {
             rb_u64x2 ld[KB][H];
@@ -458,7 +564,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                         bn[u][h] = ok ? b * (S * 8u) + col_bytes : 0xFFFFFFFFu;
                     }
                 }
-                phased_gather<8, H, NT>(x[0], bn, f.words, slice_shift, ph);
+                phased_gather<8, H, NT, RB_GATHER_BG>(x[0], bn, f.words, slice_shift, ph);
             } else if constexpr (H > 0) {
                 constexpr int HALF = (WPL == 1) ? 8 : 4;  // steps per load batch
 #pragma unroll
@@ -610,7 +716,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
 //   SHORT 2  <= 512 k-mers: two rounds of 4 tiles (the general build, SHORT 0, takes this path too and falls back to
 //            the per-strand tiles of count_strand for longer reads).
 template <int LG, int NP, int SHORT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, (SHORT && LG == 0) ? 8 : 4))) void ibf_count_max_phased_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride)
 {
@@ -672,7 +778,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int j = 0; j < 2 * T; ++j) x[j] = bn[j][0] != 0xFFFFFFFFu ? lc.valid[0] : 0ULL;  // after the hashing: 16 registers less there
             // (six tiles per strand: the 36 gathers of a window go out in two batches of 18)
-            phased_gather<2 * T, 3, false, T == 6 ? 6 : 8>(x, bn, f.words, slice_shift, ph);
+            phased_gather<2 * T, 3, false, T == 6 ? RB_GATHER_B3 : (SHORT == 1 ? RB_GATHER_B1 : 8)>(x, bn, f.words, slice_shift, ph);
             cf += wave_bin_counts<T>(x, lane);
             cr += wave_bin_counts<T>(x + T, lane);
             }
@@ -737,7 +843,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             }
             // (the builds with loop state or six tiles send two k-mers' gathers at a time: with four the state does not fit
             // three waves per SIMD)
-            phased_gather_x2<2 * T, 3, SHORT == 1 ? 4 : 2>(x0, x1, bn, f.words, slice_shift, ph);
+            phased_gather_x2<2 * T, 3, SHORT == 1 ? RB_GATHER_KB1 : (SHORT == 3 ? RB_GATHER_KB3 : 2)>(x0, x1, bn, f.words, slice_shift, ph);
             cf += wave_bin_counts<T>(x0, lane) | (wave_bin_counts<T>(x1, lane) << 16);
             cr += wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
             }

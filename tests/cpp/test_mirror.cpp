@@ -134,6 +134,17 @@ int main(int argc, char** argv)
     EXPECT_EQ(ps.first, 0);
     EXPECT_EQ(ps.second, 0);
 
+    // N on the reverse strand (TSeqRevComp = ModReverse<ModComplementDna<Dna5String>>, IBF.hpp:96-97: the four-letter functor
+    // sees N as A, so the reverse strand holds T there): the reverse complement of test.fasta[30:72] with the A that mirrors a T
+    // replaced by N shares all 30 13-mers of that window on its reverse strand -- 18 (below the threshold of 25 at r = 0.001,
+    // i.e. a count of 0) if the reverse strand saw N.  tests/test_oracle_kat.py holds the same read.
+    Read nrev("n_reverse", "ATAATATATAANATCTCCTCTCTTTTGGGGCTCTCTCTCTCC");
+    ClassifyConfig tight = cconf;
+    tight.error_rate = 0.001;
+    std::pair<int, int> pn = nrev.classify(v1, v2, tight);
+    EXPECT_EQ(pn.first, 30);
+    EXPECT_EQ(pn.second, 0);
+
     // the 35-mer of read.hpp:113: threshold -7 wraps to 65529 in production code -> no match
     Read mer("35mer", "AAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAG");
     EXPECT_EQ(mer.classify(filters, cconf), -1);

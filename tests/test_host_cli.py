@@ -293,6 +293,11 @@ def test_cpp_mirror_reads_like_the_reference_tests(tmp_path, refdata):
     p = subprocess.run([exe, refdata, str(tmp_path / "work")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "failures: 0" in p.stdout
+    # the other candidate of the reverse-complement-of-N rule, for a whole process (RB_REVCOMP_OF_N): exactly the one
+    # expectation that tells the two rules apart fails (30 shared 13-mers on the reverse strand become 18 -> count 0)
+    env = dict(os.environ, RB_REVCOMP_OF_N="4")
+    q = subprocess.run([exe, refdata, str(tmp_path / "work4")], capture_output=True, text=True, env=env)
+    assert q.returncode != 0 and "failures: 1" in q.stdout and "pn.first" in q.stderr, q.stdout + q.stderr
 
 
 @pytest.mark.gpu
