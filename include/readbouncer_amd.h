@@ -373,15 +373,17 @@ RB_API int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t 
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
 
 /* Narrow filters -- blocks of one to eight words, tables of a few L2 sizes (10-20 MB: a bacterial genome at the reference's
- * default fragment_size) -- are bound by fabric REQUESTS, not bytes: each 8-byte gather that misses the XCD's 4 MiB L2
- * costs a 128-byte request.  Two measures, both leave the results untouched:
+ * default fragment_size) -- are bound by cache and fabric REQUESTS, not bytes: each 8-byte gather that misses the XCD's 4 MiB
+ * L2 costs a 128-byte request.  Two measures, both leave the results untouched:
  *  - filters of at most `table_bytes` (default 64 MiB) never run beside another filter of the same call, so each has the
  *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
- *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads (4096) reads the
- *    throughput kernel gathers in clock-phased slices: the table is cut into <= 8 slices and the 100 MHz wall clock tells
- *    every wave which slice to gather from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns (both 0 =
- *    the built-in rule, 4.5-5.8 us), so an XCD's L2 holds one slice at a time (rb_engine_set_phased; max_table_bytes = 0 switches it off; all five arguments 0
- *    also takes one-word filters back to the plain kernel, whose 512-k-mer tiles are half empty on 250 bp reads). */
+ *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads (2049: everything
+ *    above the latency kernel's micro-batches) the throughput kernel gathers in clock-phased slices: the table is cut into
+ *    <= 8 slices and the 100 MHz wall clock tells every wave which slice to gather from, in windows of
+ *    base_ticks + ticks_per_mib * table MiB ticks of 10 ns -- both 0 = the built-in rule, 6-12.5 us by kernel shape and table
+ *    size -- so an XCD's L2 holds one slice at a time (rb_engine_set_phased; max_table_bytes = 0 switches
+ *    it off; all five arguments 0 also takes one-word filters back to the plain kernel, whose 512-k-mer tiles are half empty
+ *    on 250 bp reads). */
 RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
                                 uint32_t ticks_per_mib, uint32_t min_reads);

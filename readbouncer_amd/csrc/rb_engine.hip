@@ -104,7 +104,7 @@ struct rb_engine {
     bool phase_explicit = false;
     uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
-    uint32_t phase_min_reads = 4096;  // measured on the README shape: 4 096 reads per call 11.6 -> 15.8 M reads/s, 65 536 reads 16.1 -> 25.5 M
+    uint32_t phase_min_reads = 2049;  // everything above the latency kernel's batches: README shape at 2 049 reads per call 8.7 -> 9.2 M reads/s, 4 096: 11.6 -> 16.5 M, 65 536: 16.0 -> 28.3 M (profiles/r03/phased_batch_size.txt)
     bool short_read_kernel = true;
     int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp): one round of six tiles per strand (RB_SIX_TILES=0: two rounds of four)
     uint32_t split_threshold = 2048;  // batches up to this many (read, slice) items use the latency kernel
