@@ -364,7 +364,17 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         def phased(f):
             tb = f.info["n_blocks"] * f.device_stride() * 8
             return f.info["bin_width"] <= 8 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= (32 << 20) or f.info["bin_width"] == 1)
-        forms = {("ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel") for f in filters}
+        # filters of one hash geometry share a merged table when that pays (rb_engine.hip, plan_merged)
+        narrow = [f for f in filters if f.info["bin_width"] <= 8 and f.info["n_hash"] == 3]
+        geos = {}
+        for f in narrow:
+            geos.setdefault((f.info["n_blocks"], f.info["kmer_size"]), []).append(f)
+        merged = set()
+        for grp in geos.values():
+            if len(grp) >= 4 or (len(grp) >= 2 and sum(f.info["bin_width"] for f in grp) >= 5):
+                merged.update(id(f) for f in grp)
+        forms = {("ibf_count_max_merged_kernel" if id(f) in merged else "ibf_count_max_phased_kernel" if phased(f)
+                  else "ibf_count_max_kernel") for f in filters}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": " + ".join(sorted(forms)), "avg_kernel_ms": avg_kernel_s * 1e3,

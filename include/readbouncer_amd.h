@@ -353,6 +353,16 @@ RB_API int rb_live_replay_arrivals(rb_live *lv, const uint32_t *read_ids, const 
  * k-mers of the reverse strand that cover an N are affected. */
 RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
 
+/* Filters of one hash geometry in one table.  Every filter the reference builds with one fragment_size has noOfBits =
+ * BinSizeBits x 64 x binWidth (src/IBF/IBFBuild.cpp:404-413), i.e. the same noOfBlocks whatever its bin count; with equal k and
+ * three hash functions a k-mer then hashes to the same block number in all of them.  For such filters (blocks of at most 8
+ * words, at most 16 words together) the engine keeps a merged copy in which their blocks sit side by side, and one gather per
+ * (k-mer, hash function) serves all of them -- the narrow filters are bound by requests, not bytes.  mode 1 (default): when it
+ * pays (four or more such filters, or five or more words together); 2: whenever two or more filters qualify; 0: never.  Large
+ * batches only (micro-batches keep the latency kernels); the copy follows changes of its members (rb_dibf_insert ...).
+ * Results are identical. */
+RB_API int rb_engine_set_merge(rb_engine *e, int mode);
+
 /* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
  * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
  * run the throughput form (one wave per read).  Results are identical.  0 disables; default 2048. */

@@ -107,6 +107,7 @@ SIGNATURES = {
                                        C.POINTER(_dbl)]),
     "rb_dibf_clone_to_ex": (_int, [_vp, _int, _pp, C.POINTER(_int), C.POINTER(_dbl)]),
     "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
+    "rb_engine_set_merge": (_int, [_vp, _int]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
@@ -409,6 +410,10 @@ class Engine:
     def set_revcomp_of_n(self, ordinal):
         """3 (default): the reverse strand sees T where the read has N (ModComplementDna on a Dna5String); 4: N stays N"""
         _check(lib().rb_engine_set_revcomp_of_n(self.h, ordinal), "rb_engine_set_revcomp_of_n")
+
+    def set_merge(self, mode):
+        """filters of one hash geometry in one merged table: 0 never, 1 when it pays (default), 2 whenever two qualify"""
+        _check(lib().rb_engine_set_merge(self.h, mode), "rb_engine_set_merge")
 
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")

@@ -60,6 +60,16 @@ struct FilterSet {
     IbfDev f[kMaxFused];
 };
 
+// Filters of one hash geometry merged into ONE table (rb_engine.hip, MergedGroup): which word columns of a merged block belong
+// to which filter.  By-value kernel argument of ibf_count_max_merged_kernel.
+constexpr unsigned kMaxMerged = 16;
+struct MergeMap {
+    uint32_t n;                       // filters in the merged table
+    uint32_t col_end[kMaxMerged];     // filter g owns the columns [col_end[g-1], col_end[g]) of every block
+    uint32_t rem[kMaxMerged];         // noOfBins & 63 of filter g (0: its last word is full)
+    uint32_t out_offset[kMaxMerged];  // element offset of filter g's column in a row of the output
+};
+
 struct CountLaunch {
     IbfDev f;
     ReadSrc src;
@@ -100,6 +110,9 @@ struct DecideParams {
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
+hipError_t launch_ibf_count_max_merged(const CountLaunch &a, const MergeMap &map, hipStream_t st);
+hipError_t launch_merge_columns(const uint64_t *src, uint32_t s_src, uint32_t width, uint64_t *dst, uint32_t s_dst, uint32_t dst_col,
+                                uint64_t n_blocks, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
 int split_waves_cap(int wpl, int planes, int lg);
 int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n_items, uint32_t max_parts, uint32_t max_sub,

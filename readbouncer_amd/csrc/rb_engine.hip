@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,8 @@ struct rb_dibf {
     uint64_t *d_words = nullptr;
     uint64_t stride = 0;  // words between consecutive blocks in HBM (>= geo.bin_width)
     IbfDev dev{};
+    std::atomic<uint64_t> version{0};  // bumped by everything that changes the bits (insert, synthetic fill): engines that keep a
+                                       // merged copy of several filters (MergedGroup) rebuild it when a member has moved on
 };
 
 // growable device buffer
@@ -82,6 +85,26 @@ struct PinnedBuf {
     }
 };
 
+// Several narrow filters of ONE hash geometry merged into one table.  Every filter the reference builds with one
+// fragment_size has noOfBits = BinSizeBits x 64 x binWidth (src/IBF/IBFBuild.cpp:404-413), i.e. noOfBlocks = BinSizeBits
+// whatever its bin count: with equal k and h a k-mer hashes to the SAME block number in all of them.  The engine then keeps a
+// copy in which block b holds the blocks b of all members side by side (deplete 2 words + three targets of 1 word = 5 words,
+// padded to 8: one 64-byte gather), and ONE lookup per (k-mer, hash function) serves every member -- the path is bound by
+// requests, so a read costs 1 428 requests instead of 5 712 on the reference's README shape.  The copy belongs to the engine
+// (the filters are borrowed); it is rebuilt when a member's bits have changed since it was made.
+struct MergedGroup {
+    std::vector<uint32_t> members;  // filter indices, engine order
+    uint64_t *d_words = nullptr;
+    uint64_t stride = 0, width = 0, n_blocks = 0;
+    IbfDev dev{};
+    MergeMap map{};
+    std::vector<uint64_t> versions;  // rb_dibf::version of each member when the copy was made
+    ~MergedGroup()
+    {
+        if (d_words) (void)hipFree(d_words);
+    }
+};
+
 struct rb_engine {
     int device = 0;
     std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
@@ -93,6 +116,11 @@ struct rb_engine {
     bool timing = false;
     std::mutex host_mu;
     int shard_rank = 0, shard_world = 1;
+    // Filters of one hash geometry merged into one table (see MergedGroup below): 0 = never, 1 = when it pays (default), 2 = always
+    int merge_mode = 1;
+    std::vector<struct MergedGroup *> merged;
+    std::vector<int> merged_of;  // per filter: index into `merged`, or -1
+    bool merged_planned = false;
     uint32_t revcomp_of_n = rbspec::kRevCompOfN;  // see ibf_spec.h: what the reverse strand holds for an N of the read
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
@@ -485,6 +513,7 @@ int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
     const uint64_t used = f->geo.n_blocks * f->geo.bin_width;
     const uint64_t rem = f->geo.n_bins & 63;
     const uint64_t last_mask = rem ? ((1ULL << rem) - 1) : ~0ULL;
+    f->version.fetch_add(1);
     RB_HIP(hipMemset(f->d_words, 0, dibf_device_words(f) * 8));
     RB_HIP(launch_fill_synth(f->d_words, used, (uint32_t)f->geo.bin_width, (uint32_t)f->stride, last_mask, seed, nullptr));
     RB_HIP(hipDeviceSynchronize());
@@ -538,6 +567,7 @@ int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_t *star
     const uint64_t total = prefix[n_fragments];
     if (total == 0) return RB_OK;
     if ((total + 255) / 256 >= (1ULL << 31)) return rb::fail(RB_ERR_INVALID_ARG, "too many k-mers in one call");
+    f->version.fetch_add(1);
     DevBuf d_seq, d_tab;
     st = d_seq.ensure(len ? len : 1);
     if (st == RB_OK) st = d_tab.ensure((4 * n_fragments + 1) * 8);
@@ -599,6 +629,9 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     if (const char *v = std::getenv("RB_REVCOMP_OF_N")) {
         if (std::atoi(v) == 3 || std::atoi(v) == 4) e->revcomp_of_n = (uint32_t)std::atoi(v);
     }
+    if (const char *v = std::getenv("RB_MERGE")) {  // A/B switch for measurements; rb_engine_set_merge is the API
+        if (std::atoi(v) >= 0 && std::atoi(v) <= 2) e->merge_mode = std::atoi(v);
+    }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
     if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -631,6 +664,7 @@ void rb_engine_destroy(rb_engine *e)
     if (e->copy_stream) { (void)hipStreamSynchronize(e->copy_stream); (void)hipStreamDestroy(e->copy_stream); }
     for (hipEvent_t ev : e->copy_ev) (void)hipEventDestroy(ev);
     for (DevBuf &b : e->d_parts) b.release();
+    for (MergedGroup *g : e->merged) delete g;
     for (auto &t : e->thr) {
         if (t.d) (void)hipFree(t.d);
         if (t.ready) (void)hipEventDestroy(t.ready);
@@ -652,7 +686,7 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
     std::lock_guard<std::mutex> lock(e->mu);
     e->shard_rank = rank;
     e->shard_world = world;
-    return RB_OK;
+    return RB_OK;  // (a bin-sharded rank never uses merged tables: use_merged checks shard_world per call)
 }
 
 int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal)
@@ -660,6 +694,21 @@ int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal)
     if (!e || (ordinal != 3 && ordinal != 4)) return rb::fail(RB_ERR_INVALID_ARG, "the reverse strand's image of N is ordinal 3 (T) or 4 (N)");
     std::lock_guard<std::mutex> lock(e->mu);
     e->revcomp_of_n = ordinal;
+    return RB_OK;
+}
+
+int rb_engine_set_merge(rb_engine *e, int mode)
+{
+    if (!e || mode < 0 || mode > 2) return rb::fail(RB_ERR_INVALID_ARG, "merge mode is 0 (never), 1 (when it pays) or 2 (always)");
+    std::lock_guard<std::mutex> lock(e->mu);
+    if (mode != e->merge_mode) {
+        e->merge_mode = mode;
+        (void)hipDeviceSynchronize();  // a queued kernel may still read a merged copy
+        for (MergedGroup *g : e->merged) delete g;
+        e->merged.clear();
+        e->merged_of.clear();
+        e->merged_planned = false;
+    }
     return RB_OK;
 }
 
@@ -1068,6 +1117,76 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
 
 }  // extern "C"
 
+// Which filters share a merged table.  Candidates: three hash functions, blocks of at most 8 words, equal noOfBlocks and k.
+// "When it pays" (mode 1): a merged lookup costs one request whatever it serves (~58 G/s from a table beyond the L2s: 24.6 ms
+// per 1 M reads of 250 bp), against 7.6 ms per one-word and 10.1 ms per two-word member with the phased kernels on their own
+// (profiles/r03): four or more members, or five or more words.  At most 16 words (one 128-byte line) per merged block.
+static void plan_merged(rb_engine *e)
+{
+    e->merged_planned = true;
+    e->merged_of.assign(e->filters.size(), -1);
+    if (e->merge_mode == 0 || e->shard_world != 1) return;
+    for (size_t i = 0; i < e->filters.size(); ++i) {
+        if (e->merged_of[i] >= 0) continue;
+        const rb_ibf_info &gi = e->filters[i]->geo;
+        if (gi.n_hash != 3 || gi.bin_width > 8) continue;
+        std::vector<uint32_t> members{(uint32_t)i};
+        uint64_t width = gi.bin_width;
+        for (size_t j = i + 1; j < e->filters.size() && members.size() < kMaxMerged; ++j) {
+            const rb_ibf_info &gj = e->filters[j]->geo;
+            if (e->merged_of[j] >= 0 || gj.n_hash != 3 || gj.bin_width > 8 || gj.n_blocks != gi.n_blocks || gj.kmer_size != gi.kmer_size ||
+                width + gj.bin_width > 16)
+                continue;
+            members.push_back((uint32_t)j);
+            width += gj.bin_width;
+        }
+        const bool pays = members.size() >= 4 || (members.size() >= 2 && width >= 5);
+        if (members.size() < 2 || (e->merge_mode == 1 && !pays)) continue;
+        MergedGroup *g = new (std::nothrow) MergedGroup();
+        if (!g) return;
+        g->members = members;
+        g->width = width;
+        g->n_blocks = gi.n_blocks;
+        for (uint32_t m : members) e->merged_of[m] = (int)e->merged.size();
+        e->merged.push_back(g);
+    }
+}
+
+// the merged copy of a group, made (or made again after a member changed) on `st`
+static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
+{
+    bool fresh = g->d_words != nullptr && g->versions.size() == g->members.size();
+    for (size_t i = 0; fresh && i < g->members.size(); ++i) fresh = g->versions[i] == e->filters[g->members[i]]->version.load();
+    if (fresh) return RB_OK;
+    if (!g->d_words) {
+        g->stride = hbm_stride(g->width);
+        RB_HIP(hipMalloc((void **)&g->d_words, (g->n_blocks * g->stride + 8) * 8));
+    }
+    RB_HIP(hipMemsetAsync(g->d_words, 0, (g->n_blocks * g->stride + 8) * 8, st));
+    g->versions.assign(g->members.size(), 0);
+    uint32_t col = 0;
+    g->map = MergeMap{};
+    g->map.n = (uint32_t)g->members.size();
+    for (size_t i = 0; i < g->members.size(); ++i) {
+        rb_dibf *f = e->filters[g->members[i]];
+        g->versions[i] = f->version.load();
+        RB_HIP(launch_merge_columns(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, g->d_words, (uint32_t)g->stride, col,
+                                    g->n_blocks, st));
+        col += (uint32_t)f->geo.bin_width;
+        g->map.col_end[i] = col;
+        g->map.rem[i] = (uint32_t)(f->geo.n_bins & 63);
+        g->map.out_offset[i] = g->members[i];
+    }
+    rb_ibf_info geo = e->filters[g->members[0]]->geo;  // noOfBlocks, k, h of the members
+    geo.bin_width = g->width;
+    geo.n_bins = g->width * 64;
+    int rc = make_dev_desc(geo, g->d_words, g->stride, &g->dev);
+    if (rc != RB_OK) return rc;
+    // made once per engine (and again when a member changed): wait here, so that calls on other streams find it complete
+    RB_HIP(hipStreamSynchronize(st));
+    return RB_OK;
+}
+
 // host_maxcount: optional pinned host destination for a copy of the maxcount rows, written by the decision kernel
 static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
                                 void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream,
@@ -1129,6 +1248,35 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         RB_HIP(hipEventRecord(e->fork_ev, st));
         for (size_t k = 0; k < e->aux.size(); ++k) RB_HIP(hipStreamWaitEvent(e->aux[k], e->fork_ev, 0));
     }
+    // filters of one hash geometry that share a merged table: one launch per group (throughput form only; micro-batches
+    // keep the latency kernels, which already put every filter of a call into one launch)
+    if (!e->merged_planned) plan_merged(e);
+    const bool use_merged = !e->merged.empty() && n_reads > e->split_threshold && e->shard_world == 1;
+    if (use_merged) {
+        for (MergedGroup *g : e->merged) {
+            if ((rc = ensure_merged_table(e, g, st)) != RB_OK) return rc;
+            CountLaunch a{};
+            a.f = g->dev;
+            a.f.comp_n = e->revcomp_of_n;
+            a.src.seqs = (const uint8_t *)d_seqs;
+            a.src.offsets = (const uint64_t *)d_offsets;
+            a.src.lens = (const uint32_t *)d_lens;
+            a.src.nmask = (const uint8_t *)desc->d_nmask;
+            a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
+            a.src.ids = (const uint32_t *)desc->d_read_ids;
+            a.src.base_off = desc->chunk_start;
+            a.n_reads = (uint32_t)n_reads;
+            a.wpl = 1;
+            a.lg = 0;
+            while ((1u << a.lg) < g->width) ++a.lg;
+            const uint32_t kmers = max_len >= g->dev.k ? max_len - g->dev.k + 1 : 0;
+            a.planes = kmers <= 1023 ? 10 : 16;
+            a.nt = g->n_blocks * g->stride * 8 > e->nt_threshold_bytes;
+            a.out = maxcount;
+            a.out_read_stride = (uint32_t)nf;
+            RB_HIP(launch_ibf_count_max_merged(a, g->map, st));
+        }
+    }
     std::vector<CountLaunch> pending;
     std::vector<uint32_t> pending_fi;
     // Which filters may run side by side?  A table of a few tens of MB lives partly in the 4 MiB L2 of each XCD (hit rate
@@ -1141,6 +1289,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     size_t next_aux = 0;
     bool big_on_main = false;
     for (size_t fi = 0; fi < nf; ++fi) {
+        if (use_merged && e->merged_of[fi] >= 0) continue;  // counted by its group's launch above
         const rb_dibf *f = e->filters[fi];
         hipStream_t fs = st;
         if (fan_out && !l2_sensitive(f)) {

@@ -704,6 +704,69 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
     if (lane == 0) out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)best;
 }
 
+// Throughput form over a MERGED table: several narrow filters of one hash geometry (same noOfBlocks, k and h -- every filter
+// the reference builds with one fragment_size has them: noOfBits = BinSizeBits x 64 x binWidth, so noOfBlocks = BinSizeBits
+// whatever the bin count, src/IBF/IBFBuild.cpp:404-413) hash a k-mer to the SAME block number, so their blocks can sit side
+// by side in one table and ONE gather per (k-mer, hash function) serves all of them.  The path is bound by requests, not
+// bytes: 1 deplete + 3 target filters of 2 + 1 + 1 + 1 words become one 64-byte gather instead of four lookups.  Counting is
+// unchanged (one word column per lane, bit-sliced planes); the max over bins is taken per filter, over the lanes that hold
+// that filter's columns, and lane g of the wave carries filter g's result across the strands.
+template <int LG, int NP, bool NT>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_merged_kernel(IbfDev f, MergeMap map, ReadSrc src, uint32_t n_reads,
+                                                                                   uint16_t *__restrict__ out, uint32_t out_read_stride)
+{
+    __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
+    if (read >= n_reads) return;  // wave-uniform; no block-level barriers below
+    LaneCols<1> lc = make_lane_cols<LG, 1>(f, lane, 0u, f.bin_width, 0u);
+    // which filter this lane's word column belongs to, and which of its bins exist
+    const uint32_t col = (uint32_t)lane & ((1u << LG) - 1u);
+    uint32_t fid = 0xFFFFFFFFu, begin = 0;
+    uint64_t valid = 0;
+    for (uint32_t g = 0; g < map.n; ++g) {
+        const uint32_t end = map.col_end[g];
+        if (col >= begin && col < end) {
+            fid = g;
+            valid = (col == end - 1 && map.rem[g]) ? ((1ULL << map.rem[g]) - 1) : ~0ULL;
+        }
+        begin = end;
+    }
+    lc.valid[0] = valid;
+    lc.colok = fid != 0xFFFFFFFFu;
+    lc.safe_base = lc.colok ? lc.lane_base : f.words;
+    uint32_t len;
+    const BaseSrc seq = make_base_src(src, read, &len);
+    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
+    uint32_t best = 0;  // lane g: filter g
+    for (int strand = 0; strand < 2; ++strand) {
+        Planes<NP> pl[1];
+        pl[0].clear();
+        count_strand<LG, 1, NP, 3, NT>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0, TileShape<LG>::STEPS / 8,
+                                       s_stage[wave], lane);
+        for (uint32_t g = 0; g < map.n; ++g) {
+            const uint64_t mine[1] = {fid == g ? valid : 0ULL};
+            const uint32_t m = planes_max<NP, 1>(pl, mine);
+            if ((uint32_t)lane == g) best = m > best ? m : best;
+        }
+    }
+    if ((uint32_t)lane < map.n) out[(size_t)read * out_read_stride + map.out_offset[lane]] = (uint16_t)best;
+}
+
+// merged table: block b of a filter (width words at stride s_src) -> columns [dst_col, dst_col + width) of block b of dst
+__global__ void merge_columns_kernel(const uint64_t *__restrict__ src, uint32_t s_src, uint32_t width, uint64_t *__restrict__ dst,
+                                     uint32_t s_dst, uint32_t dst_col, uint64_t n_blocks)
+{
+    const uint64_t total = n_blocks * width;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t b = i / width;
+        const uint32_t c = (uint32_t)(i - b * width);
+        dst[b * s_dst + dst_col + c] = src[b * s_src + c];
+    }
+}
+
 // throughput form with clock-phased gathers (see count_strand): narrow filters of a few L2 sizes, one column slice
 // (three waves per SIMD: the lookups a CU holds in registers are what a window has to work with).  SHORT != 0: the engine
 // knows that no read of the batch has more k-mers than one of the both-strands shapes below takes, and only that path is
@@ -1549,6 +1612,48 @@ hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
         return dispatch_geometry<16, 3>(a, st);
     }
     return dispatch_geometry<16, 0>(a, st);
+}
+
+template <int LG, int NP>
+static hipError_t launch_merged_nt(const CountLaunch &a, const MergeMap &map, hipStream_t st)
+{
+    dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (a.nt)
+        hipLaunchKernelGGL((ibf_count_max_merged_kernel<LG, NP, true>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, map, a.src, a.n_reads,
+                           a.out, a.out_read_stride);
+    else
+        hipLaunchKernelGGL((ibf_count_max_merged_kernel<LG, NP, false>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, map, a.src, a.n_reads,
+                           a.out, a.out_read_stride);
+    return hipGetLastError();
+}
+
+template <int NP>
+static hipError_t launch_merged_lg(const CountLaunch &a, const MergeMap &map, hipStream_t st)
+{
+    switch (a.lg) {
+    case 1: return launch_merged_nt<1, NP>(a, map, st);
+    case 2: return launch_merged_nt<2, NP>(a, map, st);
+    case 3: return launch_merged_nt<3, NP>(a, map, st);
+    case 4: return launch_merged_nt<4, NP>(a, map, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_ibf_count_max_merged(const CountLaunch &a, const MergeMap &map, hipStream_t st)
+{
+    if (a.n_reads == 0) return hipSuccess;
+    if (a.f.n_hash != 3 || a.wpl != 1 || map.n == 0 || map.n > kMaxMerged || map.col_end[map.n - 1] > (1u << a.lg)) return hipErrorInvalidValue;
+    return a.planes <= 10 ? launch_merged_lg<10>(a, map, st) : launch_merged_lg<16>(a, map, st);
+}
+
+hipError_t launch_merge_columns(const uint64_t *src, uint32_t s_src, uint32_t width, uint64_t *dst, uint32_t s_dst, uint32_t dst_col,
+                                uint64_t n_blocks, hipStream_t st)
+{
+    if (n_blocks == 0 || width == 0) return hipSuccess;
+    uint64_t blocks = (n_blocks * width + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(merge_columns_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, width, dst, s_dst, dst_col, n_blocks);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_t n_reads, uint16_t *maxcount,

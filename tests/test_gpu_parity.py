@@ -991,3 +991,84 @@ def test_pool_runs_micro_batches_of_several_threads_concurrently():
           % (m, serial, concurrent, concurrent / serial))
     assert concurrent <= 0.45 * serial, (concurrent, serial)
     pool.destroy()
+
+
+@pytest.mark.parametrize("widths", [(122, 43, 29, 49), (64, 64, 64, 64, 10), (130, 200), (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64)])
+def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
+    """Filters built with one fragment_size have the same noOfBlocks whatever their bin count (IBFBuild.cpp:404-413), so a k-mer
+    hashes to the same block in all of them: the engine merges their blocks into one table and serves every member with ONE
+    gather per (k-mer, hash function).  Same maxima and decisions as the filters on their own (merge off) and as the oracle, for
+    the reference's README shape (122 + 43/29/49 bins), five filters, two wide-ish ones, twelve filters (two groups: the
+    16-word limit); N-containing and reverse-strand reads, long reads (16 counter planes), packed reads with on-GPU chunking; and
+    the merged copy follows a member that changes."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(sum(widths))
+    n_blocks = 30011
+    ref = H.random_dna(rng, 60000)
+    filters, views, keep = [], [], []
+    for i, bins in enumerate(widths):
+        W = (bins + 63) // 64
+        d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks + int(rng.integers(0, 64 * W)))
+        assert d.info["n_blocks"] == n_blocks
+        d.fill_synth(100 + i)
+        lo = (i * 4000) % 50000
+        d.add_sequence(ref[lo:lo + 9000], 9000 // min(bins, 40) + 1)
+        if i == 0:  # one long fragment in one bin: counts beyond 1023 (16 counter planes)
+            d.insert(ref, np.array([3000], dtype=np.uint64), np.array([5400], dtype=np.uint64), np.array([0], dtype=np.uint64))
+        filters.append(d)
+    def views_now():
+        vs, ks = [], []
+        for d in filters:
+            h = d.download()
+            ks.append(h)
+            vs.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+        return vs, ks
+    views, keep = views_now()
+    nd = 1 if len(widths) != 2 else 1
+    reads = make_reads(rng, ref, 2600, lo=5, hi=420, err=0.1, n_frac=0.2) + [ref[100:1700], ref[3000:5300], "", "ACGT", "N" * 300]
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, filters[:nd], filters[nd:])
+    exp_max = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    exp_dec, exp_st = po.batch_check_unblock(views[:nd], views[nd:], buf, offs, lens, n_threads=8)
+    results = {}
+    for mode in (0, 1, 2):
+        eng.set_merge(mode)
+        mc, best, dec, st = eng.classify(buf, offs, lens)  # > 2048 reads: throughput form
+        assert np.array_equal(mc, exp_max), mode
+        assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), mode
+        results[mode] = (mc, best, dec, st)
+    assert np.array_equal(results[0][1], results[2][1])
+    assert len(set(exp_dec.tolist())) >= 2 and exp_max.max() > 1023
+    # micro-batch of the same engine (latency kernels, no merged table) still agrees
+    sub = eng.classify(buf, offs[:300], lens[:300])
+    assert np.array_equal(sub[0], exp_max[:300])
+    # packed reads + on-GPU chunking through the merged kernel
+    packed, p_off, nmask, n_off = capi.pack_reads(buf, offs, lens)
+    dev = torch.device("cuda:0")
+    up = lambda a, dt: torch.from_numpy(a.view(dt)).to(dev)
+    t_pk, t_poff, t_nm, t_noff, t_lens = up(packed, np.uint8), up(p_off, np.int64), up(nmask, np.uint8), up(n_off, np.int64), up(lens, np.int32)
+    n = len(reads)
+    t_mc = torch.zeros((n, len(widths)), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    eng.classify_device_ex(t_pk.data_ptr(), t_poff.data_ptr(), t_lens.data_ptr(), n, int(lens.max()), d_nmask=t_nm.data_ptr(),
+                           d_nmask_offsets=t_noff.data_ptr(), chunk_start=7, chunk_length=250, d_maxcount=t_mc.data_ptr())
+    torch.cuda.synchronize()
+    frags = [r[7:257] if len(r) >= 7 else "" for r in reads]
+    fb, fo, fl = H.pack_reads(frags)
+    ok = np.array([len(r) >= 7 for r in reads])
+    exp_chunk = np.stack([po.batch_raw_max(v, fb, fo, fl, 8) for v in views], axis=1)
+    assert np.array_equal(t_mc.cpu().numpy().view(np.uint16)[ok], exp_chunk[ok])
+    # a member changes: the merged copy is made again
+    filters[-1].add_sequence(ref[55000:59000], 4000 // min(widths[-1], 40) + 1)
+    views, keep = views_now()
+    exp2 = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    assert not np.array_equal(exp2, exp_max)
+    assert np.array_equal(eng.classify(buf, offs, lens)[0], exp2)
+    # the other candidate of the N rule goes through the merged kernel as well
+    prev = po.set_revcomp_of_n(4)
+    try:
+        eng.set_revcomp_of_n(4)
+        exp4 = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+        assert np.array_equal(eng.classify(buf, offs, lens)[0], exp4) and not np.array_equal(exp4, exp2)
+    finally:
+        po.set_revcomp_of_n(prev)
