@@ -895,15 +895,13 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 }
 
 // Window length of the clock-phased gathers in 10 ns ticks, by kernel shape and table size.  Measured on single filters
-// (profiles/r03/window_sweep.txt; K1 ms per 1 M reads at the optimum).  A window that is too short costs far more than one
-// that is too long -- waves that cannot finish a window in time fall out of step with the clock and gather from slices that
-// have left the L2 (c1: 20.7 ms at 1100 ticks, 13.5 at 1200, 13.7 at 1350; c1 at 250 bp: 14.7 ms at 900, 9.2 at 1000, 9.4 at
-// 1100) -- so the rule sits 8-12 % on the long side of each cliff (cost: 1-2 % of the optimum):
-//   both strands, one round of 4 tiles (<= 256 k-mers, 250 bp): one-word 10 MB 760 (optimum 700: 7.6 ms), one-word 20 MB 1100
-//                                                                (1000: 9.2 ms), two-word 20 MB 875 (850: 10.1 ms; narrow valley)
-//   both strands, one round of 6 tiles (<= 384 k-mers, 360 bp): one-word 10 MB 880 (825: 11.3 ms), one-word 20 MB 1300 (1200:
-//                                                                13.5 ms), two-word 20 MB 1000 (975-1025: 15.0 ms; four waves
-//                                                                per SIMD, the others five-six)
+// (profiles/r03/window_sweep.txt, session 20; K1 ms per 1 M reads).  Since the waves serve the slices in the order of the
+// clock (phase_next_slice: a wave that fell behind joins the current slice instead of working through the windows it missed)
+// the optima are flat -- +-100 ticks cost 1-3 %, where the fixed slice order of round 2 lost a factor of two just below them:
+//   both strands, one round of 4 tiles (<= 256 k-mers, 250 bp): one-word 10 MB 750 (7.7 ms), one-word 20 MB 900 (9.1 ms),
+//                                                                two-word 20 MB 800 (10.2 ms)
+//   both strands, one round of 6 tiles (<= 384 k-mers, 360 bp): one-word 10 MB 850 (11.4 ms), one-word 20 MB 1150 (13.1 ms),
+//                                                                two-word 20 MB 800-1000 (15.1 ms)
 //   two rounds of 4 tiles (<= 512 k-mers): 575-600;  per-strand tiles of the general build (longer reads, 3-8 word blocks):
 //   one-word blocks 600 (c1 at 600 bp 18.3 ms, a 10 MB filter at 1500 bp 11.9 ms per 200 k reads), wider blocks 450
 // Between the measured sizes the length is interpolated over the table size (the slice an XCD's L2 has to take in per window).
@@ -913,8 +911,8 @@ static uint64_t phase_window_ticks(int short_only, int lg, uint64_t table_bytes)
     const double over = std::min(std::max(mib - 10.0, 0.0), 22.0);  // MiB above the 10 MB case
     double t;
     switch (short_only) {
-    case 1: t = lg == 0 ? 760.0 + 34.0 * over : 725.0 + 15.0 * over; break;
-    case 3: t = lg == 0 ? 880.0 + 42.0 * over : 850.0 + 15.0 * over; break;
+    case 1: t = (lg == 0 ? 750.0 : 650.0) + 15.0 * over; break;
+    case 3: t = 850.0 + (lg == 0 ? 30.0 : 5.0) * over; break;
     case 2: t = 575.0 + 2.5 * over; break;
     default: t = lg == 0 ? 600.0 : 450.0; break;
     }

@@ -279,16 +279,6 @@ struct BaseSrc {
 // The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the
 // window of its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  With ph = {shift 0.., n_slices 1, inv_ticks 0} and
 // a slice_shift of 31 this is one batch of predicated gathers with no waiting (tables that need no phasing).
-// RB_PHASED_BUF (default 1): the predication of a window's gathers is done by the BOUNDS CHECK of a raw buffer descriptor
-// instead of by exec masks.  Per window the wave points the descriptor at the slice of the moment (base = slice start,
-// num_records = slice bytes) and issues every lookup as buffer_load with the offset (lookup - slice start): a lane whose lookup
-// lies in another slice (or has no lookup: offset 0xFFFFFFFF) is out of range, makes no memory access and gets 0 back, which
-// an OR with the lane's out-of-range mask turns into the neutral all-ones.  No saveexec, no branch around a load, no scalar
-// work per lookup: the exec-masked form costs about 11 instructions per lookup and window, seven of them scalar or branches
-// (profiles/r03: waves of the 250 bp kernels wait for instruction issue 45 % of their cycles, for memory 33 %).
-#ifndef RB_PHASED_BUF
-#define RB_PHASED_BUF 1
-#endif
 // k-mers of a lane whose gathers go out together (B: one-word blocks, three 8-byte loads per k-mer; KB: two-word blocks,
 // three 16-byte loads per k-mer).  Every load in flight holds its destination registers, so the batch size sets the
 // occupancy: with ALL lookups of a window in flight (8 k-mers, 48 registers) the 250 bp one-word kernel has five waves per
@@ -314,148 +304,107 @@ typedef unsigned int rb_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int rb_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBufRsrcWord3 = 0x00020000;  // raw buffer, DATA_FORMAT = 32 bit (gfx9 family)
 
+// Which slice a wave gathers next: the one the wall clock names NOW, if the wave has not served it yet; otherwise the wave
+// sleeps until the clock has moved on.  A wave that is ahead of the clock therefore waits for its next window, and a wave
+// that has fallen behind does NOT work through the windows it missed -- their slices have left the L2 -- but joins the chip on
+// the current slice and picks the missed ones up when they come round again (round 2 walked the slices in a fixed order:
+// a window that was too short for the waves then cost a factor of two, profiles/r03/window_sweep.txt).  Bounded: if the
+// clock does not move for ~0.1 ms (its 32-bit wrap, a window length of 0) the lowest slice still open is taken.
+__device__ __forceinline__ uint32_t phase_next_slice(uint32_t done, const PhaseCfg &ph)
+{
+    for (;;) {
+        const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+        const uint32_t cur = (wn + ph.skew) % ph.n_slices;
+        if (!((done >> cur) & 1u)) return cur;
+        bool moved = false;
+        for (uint32_t guard = 0; guard < 2048; ++guard) {
+            __builtin_amdgcn_s_sleep(2);
+            const uint32_t w2 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+            if (w2 != wn) { moved = true; break; }
+        }
+        if (!moved) return (uint32_t)__builtin_ctz(~done);  // done has a zero bit below n_slices: the caller loops while it does
+    }
+}
+
+// The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the window of
+// its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  The predication is done by the BOUNDS CHECK of a raw buffer
+// descriptor, not by exec masks: per window the wave points the descriptor at the slice of the moment (base = slice start,
+// num_records = slice bytes) and issues every lookup as buffer_load with the offset (lookup - slice start): a lane whose lookup
+// lies in another slice (or that has none) is out of range, makes no memory access and gets 0 back, which an OR with the
+// lane's out-of-range mask turns into the neutral all-ones.  No saveexec, no branch around a load, no scalar work per lookup
+// (the exec-masked loads of round 2: ~11 instructions per lookup and window, seven of them scalar or branches, every
+// destination register kept initialised across the window loop).  With ph = {n_slices 1, inv_ticks 0} and a slice_shift of 31
+// this is one batch of gathers with no waiting (tables that need no phasing).
 template <int N, int H, bool NT, int B = N>
 __device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (&bn)[N][H], const uint64_t *words,
                                               uint32_t slice_shift, const PhaseCfg ph)
 {
     static_assert(N % B == 0, "the k-mers of a lane are gathered in batches of B");
-    const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-    uint32_t cur = (w0 + ph.skew) % ph.n_slices;
+    const uint32_t all = (1u << ph.n_slices) - 1u;  // n_slices <= 8
+    uint32_t done = 0;
 #pragma unroll 1
-    for (uint32_t q = 0; q < ph.n_slices; ++q) {
-        // window w0 + q: wait for it to open (bounded: the clock's 32-bit wrap, once in 43 s, must not park a wave)
-        for (uint32_t guard = 0; guard < 2048; ++guard) {
-            const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-            if ((int32_t)(wn - (w0 + q)) >= 0) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-#if RB_PHASED_BUF
-        {
-            const uint32_t start = cur << slice_shift;  // slice_shift == 31 goes with a single slice (cur == 0)
-            const uint32_t span = 1u << slice_shift;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
-#pragma unroll
-            for (int part = 0; part < N / B; ++part) {
-                rb_u32x2 ld[B][H];
-#pragma unroll
-                for (int uu = 0; uu < B; ++uu) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        // (the offsets are made opaque at both uses: otherwise `offset - start` of all 24 lookups is computed up
-                        // front and kept for the masks below -- 24 registers, a wave per SIMD on the 250 bp kernel)
-                        uint32_t off = bn[part * B + uu][h];
-                        asm volatile("" : "+v"(off));
-                        ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, off - start, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int uu = 0; uu < B; ++uu) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        uint32_t off = bn[part * B + uu][h];
-                        asm volatile("" : "+v"(off));
-                        const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
-                        x[part * B + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
-                    }
-                }
-            }
-            cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
-            continue;
-        }
-#endif
+    while (done != all) {
+        const uint32_t cur = phase_next_slice(done, ph);
+        done |= 1u << cur;
+        const uint32_t start = cur << slice_shift;  // slice_shift == 31 goes with a single slice (cur == 0)
+        const uint32_t span = 1u << slice_shift;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
         for (int part = 0; part < N / B; ++part) {
-            uint64_t ld[B][H];
+            rb_u32x2 ld[B][H];
 #pragma unroll
             for (int uu = 0; uu < B; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    ld[uu][h] = ~0ULL;
-                    // the offset is made opaque per window: otherwise the addresses are widened to 64 bits and hoisted out
-                    // of the window loop (two registers per lookup, which costs a wave per SIMD)
+                    // (the offsets are made opaque at both uses: otherwise `offset - start` of all 24 lookups is computed up
+                    // front and kept for the masks below -- 24 registers, a wave per SIMD on the 250 bp kernel)
                     uint32_t off = bn[part * B + uu][h];
                     asm volatile("" : "+v"(off));
-                    if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
-                        ld[uu][h] = load_word<NT>(reinterpret_cast<const uint64_t *>(reinterpret_cast<const char *>(words) + off));
+                    ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, off - start, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int uu = 0; uu < B; ++uu) {
 #pragma unroll
-                for (int h = 0; h < H; ++h) x[part * B + uu] &= ld[uu][h];
+                for (int h = 0; h < H; ++h) {
+                    uint32_t off = bn[part * B + uu][h];
+                    asm volatile("" : "+v"(off));
+                    const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
+                    x[part * B + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
+                }
             }
         }
-        cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
     }
 }
 
 // The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's N k-mers.
-// The gathers of KB k-mers go out together (KB = 4: 48 registers of results in flight, like the 24 eight-byte ones).
 template <int N, int H, int KB>
 __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x1)[N], const uint32_t (&bn)[N][H],
                                                  const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
 {
     static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
-    const uint32_t w0 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-    uint32_t cur = (w0 + ph.skew) % ph.n_slices;
+    const uint32_t all = (1u << ph.n_slices) - 1u;
+    uint32_t done = 0;
 #pragma unroll 1
-    for (uint32_t q = 0; q < ph.n_slices; ++q) {
-        for (uint32_t guard = 0; guard < 2048; ++guard) {
-            const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
-            if ((int32_t)(wn - (w0 + q)) >= 0) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-#if RB_PHASED_BUF
-        {
-            const uint32_t start = cur << slice_shift;
-            const uint32_t span = 1u << slice_shift;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
-#pragma unroll
-            for (int part = 0; part < N / KB; ++part) {
-                rb_u32x4 ld[KB][H];
-#pragma unroll
-                for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        uint32_t off = bn[part * KB + uu][h];
-                        asm volatile("" : "+v"(off));
-                        ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                    for (int h = 0; h < H; ++h) {
-                        uint32_t off = bn[part * KB + uu][h];
-                        asm volatile("" : "+v"(off));
-                        const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
-                        x0[part * KB + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
-                        x1[part * KB + uu] &= (((uint64_t)(ld[uu][h].w | out)) << 32) | (ld[uu][h].z | out);
-                    }
-                }
-            }
-            cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
-            continue;
-        }
-#endif
+    while (done != all) {
+        const uint32_t cur = phase_next_slice(done, ph);
+        done |= 1u << cur;
+        const uint32_t start = cur << slice_shift;
+        const uint32_t span = 1u << slice_shift;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
         for (int part = 0; part < N / KB; ++part) {
-            rb_u64x2 ld[KB][H];
+            rb_u32x4 ld[KB][H];
 #pragma unroll
             for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    ld[uu][h].x = ~0ULL;
-                    ld[uu][h].y = ~0ULL;
                     uint32_t off = bn[part * KB + uu][h];
                     asm volatile("" : "+v"(off));
-                    if (off != 0xFFFFFFFFu && (off >> slice_shift) == cur)
-                        ld[uu][h] = *reinterpret_cast<const rb_u64x2 *>(reinterpret_cast<const char *>(words) + off);
+                    ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -463,12 +412,14 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
             for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    x0[part * KB + uu] &= ld[uu][h].x;
-                    x1[part * KB + uu] &= ld[uu][h].y;
+                    uint32_t off = bn[part * KB + uu][h];
+                    asm volatile("" : "+v"(off));
+                    const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
+                    x0[part * KB + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
+                    x1[part * KB + uu] &= (((uint64_t)(ld[uu][h].w | out)) << 32) | (ld[uu][h].z | out);
                 }
             }
         }
-        cur = cur + 1 == ph.n_slices ? 0 : cur + 1;
     }
 }
 
@@ -566,7 +517,13 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 }
                 phased_gather<8, H, NT, RB_GATHER_BG>(x[0], bn, f.words, slice_shift, ph);
             } else if constexpr (H > 0) {
-                constexpr int HALF = (WPL == 1) ? 8 : 4;  // steps per load batch
+#ifndef RB_HALF1
+#define RB_HALF1 8
+#endif
+#ifndef RB_HALF2
+#define RB_HALF2 4
+#endif
+                constexpr int HALF = (WPL == 1) ? RB_HALF1 : RB_HALF2;  // steps per load batch
 #pragma unroll
                 for (int half = 0; half < 8 / HALF; ++half) {
                     uint64_t ld[HALF][H][WPL];
