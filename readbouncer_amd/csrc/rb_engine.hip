@@ -703,6 +703,8 @@ int rb_engine_set_merge(rb_engine *e, int mode)
     std::lock_guard<std::mutex> lock(e->mu);
     if (mode != e->merge_mode) {
         e->merge_mode = mode;
+        int rc = check_device(e->device);
+        if (rc != RB_OK) return rc;
         (void)hipDeviceSynchronize();  // a queued kernel may still read a merged copy
         for (MergedGroup *g : e->merged) delete g;
         e->merged.clear();
