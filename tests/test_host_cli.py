@@ -369,6 +369,69 @@ def test_pipeline_settings_do_not_change_the_outputs(tmp_path):
 
 
 @pytest.mark.gpu
+def test_cli_with_one_deplete_and_three_targets_uses_the_merged_table(tmp_path):
+    """The reference's README shape through the CLI: 1 deplete + 3 target FASTA files built with ONE fragment_size have the same
+    noOfBlocks (IBFBuild.cpp:404-413), so the engine serves them from a merged table when the batch is large and from the
+    latency kernels when it is small -- RESULT line, per-target FASTA files and unclassified.fasta are byte-identical either
+    way and equal to the oracle's chunk driver, credited target included."""
+    rng = np.random.default_rng(71)
+    genomes = {"dep": H.random_dna(rng, 100000), "ta": H.random_dna(rng, 40000), "tb": H.random_dna(rng, 25000),
+               "tc": H.random_dna(rng, 45000)}
+    for name, seq in genomes.items():
+        (tmp_path / (name + ".fasta")).write_text(">" + name + "\n" + seq + "\n")
+    names = list(genomes)
+    reads = []
+    for i in range(6000):
+        kind = i % 6
+        L = int(rng.integers(260, 700))
+        if kind < 4:
+            g = genomes[names[kind]]
+            p = int(rng.integers(0, len(g) - L))
+            s = H.mutate(rng, g[p:p + L], 0.06)
+        elif kind == 4:
+            s = H.random_dna(rng, L)
+        else:  # chimera: target on the first chunk, deplete on the second
+            a, b = genomes["tb"], genomes["dep"]
+            pa, pb = int(rng.integers(0, len(a) - 250)), int(rng.integers(0, len(b) - 300))
+            s = a[pa:pa + 250] + b[pb:pb + 300]
+        reads.append(("r%d" % i, s))
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "w") as fh:
+        for n, s in reads:
+            fh.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    outputs = []
+    for tag, batch in (("big", "100000"), ("small", "64")):
+        out = tmp_path / ("out_" + tag)
+        cfg = tmp_path / (tag + ".toml")
+        write_config(cfg, "classify", out, kmer_size=13, fragment_size=1000, deplete_files=[tmp_path / "dep.fasta"],
+                     target_files=[tmp_path / "ta.fasta", tmp_path / "tb.fasta", tmp_path / "tc.fasta"], read_files=[fq],
+                     chunk_length=250, max_chunks=2)
+        stdout = run_cli("--config", str(cfg), "--batch-reads", batch).stdout
+        line = [l for l in stdout.splitlines() if l.startswith("RESULT")][0]
+        files = {p.name: p.read_bytes() for p in sorted(out.glob("*.fasta"))}
+        outputs.append((line, files))
+    assert outputs[0] == outputs[1]
+    line, files = outputs[0]
+    views = {k: H.build_filter_like_reference([v], k=13, fragment_length=1000) for k, v in genomes.items()}
+    assert len({v.n_blocks for v in views.values()}) == 1  # one fragment_size -> one noOfBlocks: what the merged table needs
+    assert [v.bin_width for v in views.values()] == [2, 1, 1, 1]
+    targets = [views["ta"], views["tb"], views["tc"]]
+    found, per_target = 0, {0: [], 1: [], 2: []}
+    for n, s in reads:
+        r = po.classify_read_chunks([views["dep"]], targets, s, 250, 2)
+        assert r["status"] == po.OK and not r["too_short"]
+        found += r["classified"]
+        if r["classified"]:
+            per_target[r["best_target"]].append(n)
+    assert line == "RESULT found=%d failed=0 too_short=0 readCounter=%d" % (found, len(reads))
+    for i, tname in enumerate(("ta", "tb", "tc")):
+        got = [n for n, _ in H.read_fasta(str(tmp_path / "out_big" / (tname + ".fasta")))]
+        assert got == per_target[i], tname
+        assert len(got) > 700
+    assert 3700 < found < 4100  # the three target kinds + the chimeras whose first chunk is target 'tb'
+
+
+@pytest.mark.gpu
 def test_verify_ibf_first_contact_check(tmp_path):
     """--verify-ibf: re-inserting the reference a filter was built from must set no new bit.  A file written by
     the oracle builder passes; the same sequences hashed under another seedValue -- a stand-in for "the recalled SeqAn
