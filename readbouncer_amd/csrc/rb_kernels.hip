@@ -20,8 +20,10 @@
 //     Harley-Seal carry-save tree (7 CSAs per 8 gathered words) -- no atomics, no LDS traffic,
 //     10 or 16 planes (16 planes wrap at 65536 exactly like the reference's uint16_t counters);
 //   * the max over bins is taken on the bit-sliced form with 64-wide ballots, MSB plane first.
-// Two forms share that body (count_strand): the throughput form (one wave per read and column slice, both strands in
-// sequence; slices of a read sit side by side in a workgroup) and the latency form for micro-batches (one or several
+// Forms that share that body (count_strand): the throughput form (one wave per read and column slice, both strands in
+// sequence; slices of a read sit side by side in a workgroup), its MERGED variant (several narrow filters of one hash geometry
+// in one table, one gather per lookup for all of them), the PHASED variant for narrow filters on their own (clock-phased
+// slices of the table, bounds-checked buffer gathers, both strands in one round) and the latency form for micro-batches (one or several
 // workgroups per read; their waves split strands and k-mer tiles, add their bit-sliced counters through LDS and -- across
 // workgroups -- through a workspace and an arrival counter; one launch serves filters of different geometries).  Gathers are
 // issued in batches of 12-24 per wave with no control flow around them and a schedule fence before the first use;
@@ -201,6 +203,16 @@ __device__ __forceinline__ uint32_t planes_max(const Planes<NP> (&pl)[WPL], cons
     }
     return res;
 }
+
+// steps of the plain kernels whose gathers go out together (8-byte lanes / 16-byte lanes).  The wide kernels are HBM bound
+// and do not care: 4 waves per SIMD with half the loads in flight run at the same 0.864-0.866 of 8 TB/s on config 3
+// (profiles/r03/window_sweep.txt, session 19)
+#ifndef RB_HALF1
+#define RB_HALF1 8
+#endif
+#ifndef RB_HALF2
+#define RB_HALF2 4
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // K1.  LG: log2(lanes per block); WPL: 64-bit word columns per lane (1 or 2); NP: counter planes;
@@ -517,12 +529,6 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 }
                 phased_gather<8, H, NT, RB_GATHER_BG>(x[0], bn, f.words, slice_shift, ph);
             } else if constexpr (H > 0) {
-#ifndef RB_HALF1
-#define RB_HALF1 8
-#endif
-#ifndef RB_HALF2
-#define RB_HALF2 4
-#endif
                 constexpr int HALF = (WPL == 1) ? RB_HALF1 : RB_HALF2;  // steps per load batch
 #pragma unroll
                 for (int half = 0; half < 8 / HALF; ++half) {
