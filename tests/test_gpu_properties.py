@@ -244,6 +244,7 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
     rng = np.random.default_rng(8)
     for read_len in (250, 360):
         buf, offs, lens = synth.make_reads(90 + read_len, 100_000, read_len, ref)
+        eng.set_merge(0)                        # every filter on its own first (the merged table comes last)
         eng.set_phased(0, 0, 0, 0, 0)           # plain kernels, one-word filters on the round-1 tiles
         eng.set_serial_table_bytes(0)
         base = eng.classify(buf, offs, lens)
@@ -270,6 +271,13 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
         rc = comp[buf.reshape(-1, read_len)[:, ::-1]].reshape(-1).copy()
         got = eng.classify(rc, offs, lens)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2])
+        # the four filters share noOfBlocks, k and h: one merged table, one gather per lookup (the default for this shape)
+        for mode in (1, 2):
+            eng.set_merge(mode)
+            got = eng.classify(buf, offs, lens)
+            assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2]) and np.array_equal(got[1], base[1]), mode
+        got = eng.classify(rc, offs, lens)      # strand symmetry through the merged kernel
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2])
         # oracle sample
         keep = [f.download() for f in deplete + target]
