@@ -31,4 +31,9 @@ g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer $R/te
 $T/seqio_asan
 g++ -O1 -g -std=c++17 -fsanitize=thread $R/tests/cpp/test_seqio.cpp -o $T/seqio_tsan -lpthread
 TSAN_OPTIONS="halt_on_error=1" $T/seqio_tsan
+# the pool's work queues (per-worker FIFOs, jobs on the callers' stacks, least-loaded pick) under TSan and ASan+UBSan
+g++ -O1 -g -std=c++17 -fsanitize=thread $R/tests/cpp/test_workq.cpp -o $T/workq_tsan -lpthread
+TSAN_OPTIONS="halt_on_error=1" $T/workq_tsan
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer $R/tests/cpp/test_workq.cpp -o $T/workq_asan -lpthread
+$T/workq_asan
 echo "sanitizers: clean"

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -16,88 +17,39 @@
 
 #include "rb_internal.h"
 
+#include "rb_workq.h"
+
 namespace {
 
-// one rb_pool_classify_batch call: its parts run on one or several workers; the caller sleeps on `cv` until all are done
-struct Job {
-    std::mutex mu;
-    std::condition_variable cv;
-    size_t pending = 0;
-    int rc = RB_OK;
-    std::string error;
-};
-
-struct Task {
-    std::function<int()> fn;
-    Job *job;
-};
-
-// One engine, one host thread, one FIFO of tasks per device.  Callers on different host threads only meet in the short
-// critical section that picks a worker: their micro-batches run on different engines at the same time, which is the
-// reference's N classification threads behind one queue (src/main/adaptive_sampling.hpp:745-751).
-struct Worker {
+// One engine, one host thread (rbq::Worker) and one FIFO of tasks per device.  Callers on different host threads only meet in
+// the short critical section that picks a worker (rbq::Dispatcher): their micro-batches run on different engines at the same
+// time, which is the reference's N classification threads behind one queue (src/main/adaptive_sampling.hpp:745-751).
+struct Device {
     int device = 0;
     std::vector<rb_dibf *> filters;  // owned replicas, deplete first
     rb_engine *engine = nullptr;
-    std::thread thread;
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Task> queue;
-    size_t load = 0;  // queued + running tasks (guarded by mu; read under the pool's pick lock as a hint)
-    bool stop = false;
-
-    void loop()
-    {
-        for (;;) {
-            Task t;
-            {
-                std::unique_lock<std::mutex> lock(mu);
-                cv.wait(lock, [&] { return !queue.empty() || stop; });
-                if (queue.empty()) return;  // stop requested and nothing left to run
-                t = std::move(queue.front());
-                queue.pop_front();
-            }
-            const int rc = t.fn();
-            const std::string err = rc == RB_OK ? std::string() : std::string(rb_last_error());
-            {
-                std::lock_guard<std::mutex> lock(mu);
-                --load;
-            }
-            {
-                std::lock_guard<std::mutex> lock(t.job->mu);
-                if (rc != RB_OK && t.job->rc == RB_OK) { t.job->rc = rc; t.job->error = err; }
-                --t.job->pending;
-                // notify under the lock: the Job lives on the caller's stack and goes away as soon as pending hits zero
-                t.job->cv.notify_all();
-            }
-        }
-    }
-    void submit(Task t)
-    {
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            queue.push_back(std::move(t));
-            ++load;
-        }
-        cv.notify_one();
-    }
-    size_t current_load()
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        return load;
-    }
+    rbq::Worker worker{[] { return std::string(rb_last_error()); }};
 };
 
 }  // namespace
 
 struct rb_pool {
-    std::vector<Worker *> workers;
+    std::vector<Device *> workers;
+    std::unique_ptr<rbq::Dispatcher> dispatcher;
     size_t nd = 0, nt = 0;
-    size_t next = 0;              // round-robin cursor: breaks ties between equally loaded workers
     size_t min_split_reads = 4096;  // per-device slice below which splitting does not pay
-    bool serialize = false;       // diagnostic: one call at a time (what round 2 did)
-    std::mutex pick_mu;           // worker selection + enqueueing of one call's parts (short)
-    std::mutex call_mu;           // held for a whole call only when `serialize` is set
+    bool serialize = false;         // diagnostic: one call at a time (what round 2 did)
+    std::mutex cfg_mu;              // guards the two settings above
+    std::mutex call_mu;             // held for a whole call only when `serialize` is set
+    void start()
+    {
+        std::vector<rbq::Worker *> ws;
+        for (Device *d : workers) {
+            d->worker.start();
+            ws.push_back(&d->worker);
+        }
+        dispatcher.reset(new rbq::Dispatcher(ws));
+    }
 };
 
 extern "C" {
@@ -105,15 +57,8 @@ extern "C" {
 void rb_pool_destroy(rb_pool *p)
 {
     if (!p) return;
-    for (Worker *w : p->workers) {
-        if (w->thread.joinable()) {
-            {
-                std::lock_guard<std::mutex> lock(w->mu);
-                w->stop = true;
-            }
-            w->cv.notify_all();
-            w->thread.join();
-        }
+    for (Device *w : p->workers) {
+        w->worker.stop();  // queued tasks are still run
         if (w->engine) rb_engine_destroy(w->engine);
         for (rb_dibf *f : w->filters) rb_dibf_free(f);
         delete w;
@@ -131,7 +76,7 @@ int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *de
     p->nd = n_deplete;
     p->nt = n_target;
     for (size_t d = 0; d < n_devices; ++d) {
-        Worker *w = new (std::nothrow) Worker();
+        Device *w = new (std::nothrow) Device();
         if (!w) { rb_pool_destroy(p); return rb::fail(RB_ERR_NOMEM, "alloc"); }
         p->workers.push_back(w);
         w->device = devices[d];
@@ -145,8 +90,8 @@ int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *const *de
         const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target,
                                         &w->engine);
         if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
-        w->thread = std::thread([w] { w->loop(); });
     }
+    p->start();
     *out = p;
     return RB_OK;
 }
@@ -161,7 +106,7 @@ int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *
     p->nd = n_deplete;
     p->nt = n_target;
     for (size_t d = 0; d < n_devices; ++d) {
-        Worker *w = new (std::nothrow) Worker();
+        Device *w = new (std::nothrow) Device();
         if (!w) { rb_pool_destroy(p); return rb::fail(RB_ERR_NOMEM, "alloc"); }
         w->device = devices[d];
         p->workers.push_back(w);
@@ -206,12 +151,12 @@ int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *
             p->workers[d]->filters.push_back(f);
         }
     }
-    for (Worker *w : p->workers) {
+    for (Device *w : p->workers) {
         const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target,
                                         &w->engine);
         if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
-        w->thread = std::thread([w] { w->loop(); });
     }
+    p->start();
     if (replication_seconds) *replication_seconds = copy_s;
     *out = p;
     return RB_OK;
@@ -222,6 +167,7 @@ size_t rb_pool_size(const rb_pool *p) { return p ? p->workers.size() : 0; }
 int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device)
 {
     if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    std::lock_guard<std::mutex> lock(p->cfg_mu);
     p->min_split_reads = reads_per_device ? reads_per_device : 1;
     return RB_OK;
 }
@@ -229,7 +175,7 @@ int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device)
 int rb_pool_set_serialize(rb_pool *p, int enabled)
 {
     if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
-    std::lock_guard<std::mutex> lock(p->pick_mu);
+    std::lock_guard<std::mutex> lock(p->cfg_mu);
     p->serialize = enabled != 0;
     return RB_OK;
 }
@@ -240,50 +186,32 @@ int rb_pool_classify_batch(rb_pool *p, const char *seqs, const uint64_t *offsets
 {
     if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
     if (n_reads == 0) return RB_OK;
+    size_t min_split;
+    bool serialize;
+    {
+        std::lock_guard<std::mutex> lock(p->cfg_mu);
+        min_split = p->min_split_reads;
+        serialize = p->serialize;
+    }
     std::unique_lock<std::mutex> whole_call(p->call_mu, std::defer_lock);
+    if (serialize) whole_call.lock();
     const size_t nf = p->nd + p->nt;
-    Job job;
-    {
-        // Callers only meet here: pick the workers, queue the parts, go.  An unsplit micro-batch goes to the least loaded
-        // worker (ties: round-robin), so K calling threads keep K engines busy; a large batch is cut into contiguous slices
-        // over all workers, each slice behind whatever that worker still has queued (FIFO per worker).
-        std::unique_lock<std::mutex> pick(p->pick_mu);
-        if (p->serialize) {
-            pick.unlock();
-            whole_call.lock();
-            pick.lock();
-        }
-        const size_t nw = p->workers.size();
-        const size_t parts = std::min(nw, std::max<size_t>(1, n_reads / p->min_split_reads));
-        const size_t per = (n_reads + parts - 1) / parts;  // contiguous slices of ceil(n/parts) reads
-        size_t first = p->next % nw;
-        if (parts == 1) {
-            size_t best_load = ~(size_t)0;
-            for (size_t k = 0; k < nw; ++k) {
-                const size_t i = (p->next + k) % nw;
-                const size_t l = p->workers[i]->current_load();
-                if (l < best_load) { best_load = l; first = i; }
-            }
-            p->next = (first + 1) % nw;
-        }
-        for (size_t k = 0; k < parts; ++k)  // count first: no worker sees `job` before the first submit
-            if (std::min(n_reads, k * per) < n_reads) ++job.pending;
-        for (size_t k = 0; k < parts; ++k) {
-            const size_t b = std::min(n_reads, k * per), e = std::min(n_reads, b + per);
-            if (b == e) continue;
-            Worker *w = p->workers[(first + k) % nw];
-            w->submit(Task{[=] {
-                return rb_classify_batch(w->engine, seqs, offsets + b, lens + b, e - b, error_rate, significance, mode,
-                                         out_maxcount ? out_maxcount + b * nf : nullptr,
-                                         out_best_target ? out_best_target + b : nullptr,
-                                         out_decision ? out_decision + b : nullptr, out_status ? out_status + b : nullptr);
-            }, &job});
-        }
-    }
-    {
-        std::unique_lock<std::mutex> lock(job.mu);
-        job.cv.wait(lock, [&] { return job.pending == 0; });
-    }
+    // an unsplit micro-batch goes to the least loaded worker, so K calling threads keep K engines busy; a large batch is cut
+    // into contiguous slices of ceil(n/parts) reads over consecutive workers
+    size_t parts = std::min(p->workers.size(), std::max<size_t>(1, n_reads / min_split));
+    const size_t per = (n_reads + parts - 1) / parts;
+    parts = (n_reads + per - 1) / per;  // no empty slices
+    rbq::Job job;
+    p->dispatcher->dispatch(parts, job, [&](size_t k, size_t w) -> std::function<int()> {
+        const size_t b = k * per, e = std::min(n_reads, b + per);
+        rb_engine *eng = p->workers[w]->engine;
+        return [=] {
+            return rb_classify_batch(eng, seqs, offsets + b, lens + b, e - b, error_rate, significance, mode,
+                                     out_maxcount ? out_maxcount + b * nf : nullptr, out_best_target ? out_best_target + b : nullptr,
+                                     out_decision ? out_decision + b : nullptr, out_status ? out_status + b : nullptr);
+        };
+    });
+    job.wait();
     if (job.rc != RB_OK) return rb::fail(job.rc, job.error);
     return RB_OK;
 }

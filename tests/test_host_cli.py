@@ -503,6 +503,16 @@ def test_ingest_worker_failures_do_not_terminate():
     assert p.returncode == 0, p.stdout + p.stderr
 
 
+def test_pool_work_queue_on_cpu():
+    """tests/cpp/test_workq.cpp (CPU only): the host-thread machinery of the one-process pool -- per-worker FIFOs, jobs, the
+    least-loaded pick -- with six client threads on four workers: every part runs once, errors reach their caller, calls of
+    different clients overlap, shutdown drains the queues"""
+    exe = os.path.join(ROOT, "readbouncer_amd", "test_workq")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "failures: 0" in p.stdout, p.stdout + p.stderr
+
+
 @pytest.mark.gpu
 def test_usage_target_replays_chunks_through_the_live_step(tmp_path):
     """usage = "target" on the TOML surface (main.cpp:365-378) as an offline replay: pre-basecalled chunks in arrival order
