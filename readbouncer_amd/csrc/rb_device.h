@@ -39,7 +39,7 @@ struct ReadSrc {
 // gather from.  n_slices == 0: off.
 struct PhaseCfg {
     uint32_t shift;      // log2 blocks per slice
-    uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 8
+    uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 32 (the engine plans <= 8)
     uint32_t inv_ticks;  // floor(2^32 / window length in 10 ns ticks)
     uint32_t skew;       // added to the window number: 0, or this wave's XCD number when xcd_skew is set (experiment)
     uint32_t xcd_skew;   // 1: every XCD works on a different slice at any time (slice = (window + XCD) mod n_slices)

@@ -131,6 +131,7 @@ struct rb_engine {
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0;
     bool phase_explicit = false;
     uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
+    uint32_t phase_max_slices = 8;    // slices a table is cut into (<= 32: a wave keeps a bit per slice); RB_PHASE_MAX_SLICES for experiments
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 2049;  // everything above the latency kernel's batches: README shape at 2 049 reads per call 8.7 -> 9.2 M reads/s, 4 096: 11.6 -> 16.5 M, 65 536: 16.0 -> 28.3 M (profiles/r03/phased_batch_size.txt)
     bool short_read_kernel = true;
@@ -632,6 +633,9 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     if (const char *v = std::getenv("RB_MERGE")) {  // A/B switch for measurements; rb_engine_set_merge is the API
         if (std::atoi(v) >= 0 && std::atoi(v) <= 2) e->merge_mode = std::atoi(v);
     }
+    if (const char *v = std::getenv("RB_PHASE_MAX_SLICES")) {
+        if (std::atoi(v) >= 1 && std::atoi(v) <= 32) e->phase_max_slices = (uint32_t)std::atoi(v);
+    }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
     if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -964,7 +968,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
             n_reads >= e->phase_min_reads && stride_pow2) {
             uint32_t sh = 0;
-            while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > 8) ++sh;
+            while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > e->phase_max_slices) ++sh;
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
                                                : phase_window_ticks(a.planes <= 10 && a.lg <= 1 ? a.short_only : 0, a.lg, table_bytes);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);

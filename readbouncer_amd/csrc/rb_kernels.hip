@@ -352,7 +352,7 @@ __device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (
                                               uint32_t slice_shift, const PhaseCfg ph)
 {
     static_assert(N % B == 0, "the k-mers of a lane are gathered in batches of B");
-    const uint32_t all = (1u << ph.n_slices) - 1u;  // n_slices <= 8
+    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;  // one bit per slice
     uint32_t done = 0;
 #pragma unroll 1
     while (done != all) {
@@ -397,7 +397,7 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
                                                  const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
 {
     static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
-    const uint32_t all = (1u << ph.n_slices) - 1u;
+    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
     uint32_t done = 0;
 #pragma unroll 1
     while (done != all) {
