@@ -807,7 +807,10 @@ def main():
     else:
         name = args.workload or "c3"
         extras = not args.workload and not args.reads and not args.read_len and not args.no_extras and not bin_sharded
-        pre = xgmi_preflight(ctx) if (rank == 0 and extras) else {"ran": False, "why": "default run on rank 0 only"}
+        if os.environ.get("RB_BENCH_NO_PREFLIGHT") == "1":
+            pre = {"ran": False, "why": "RB_BENCH_NO_PREFLIGHT=1"}
+        else:
+            pre = xgmi_preflight(ctx) if (rank == 0 and extras) else {"ran": False, "why": "default run on rank 0 only"}
         result = run_throughput(ctx, name, n_reads=args.reads, read_len=args.read_len, latency=True, bin_sharded=bin_sharded)
         infos = rank_diagnostics(ctx, time.time() - t_start)
         if rank == 0:
