@@ -984,9 +984,9 @@ def test_pool_runs_micro_batches_of_several_threads_concurrently():
 
     run()  # warm-up: code objects, staging buffers, threshold tables of all four engines
     pool.set_serialize(True)
-    serial = min(run(), run())
+    serial = min(run(), run(), run())
     pool.set_serialize(False)
-    concurrent = min(run(), run())
+    concurrent = min(run(), run(), run())
     print("pool: 4 threads x 500 micro-batches of %d reads: serialised %.3f s, concurrent %.3f s (%.2fx)"
           % (m, serial, concurrent, concurrent / serial))
     assert concurrent <= 0.45 * serial, (concurrent, serial)
