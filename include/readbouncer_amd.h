@@ -358,10 +358,18 @@ RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
  * three hash functions a k-mer then hashes to the same block number in all of them.  For such filters (blocks of at most 8
  * words, at most 16 words together) the engine keeps a merged copy in which their blocks sit side by side, and one gather per
  * (k-mer, hash function) serves all of them -- the narrow filters are bound by requests, not bytes.  mode 1 (default): when it
- * pays (four or more such filters, or five or more words together); 2: whenever two or more filters qualify; 0: never.  Large
+ * pays -- the members one after the other are estimated to take longer than one pass over the merged table: the reference's README
+ * shape (a two-word deplete filter and three one-word targets), any two filters too large for the clock-phased kernels, small
+ * ones whose merged copy still fits an L2; not two or three filters of 10-30 MiB, which the phased kernels serve as fast --;
+ * 2: whenever two or more filters qualify; 0: never.  Large
  * batches only (micro-batches keep the latency kernels); the copy follows changes of its members (rb_dibf_insert ...).
  * Results are identical. */
 RB_API int rb_engine_set_merge(rb_engine *e, int mode);
+/* What the engine has merged (or will, at its next large batch): the number of merged tables, the filters they serve and the HBM
+ * bytes of the copies, which the engine owns beside the members.  A copy larger than 16 GiB (RB_MERGE_MAX_BYTES) is not made,
+ * and a group whose copy the device has no room for dissolves at its first call: its members are then served one by one.
+ * Any out pointer may be NULL. */
+RB_API int rb_engine_merge_info(rb_engine *e, uint32_t *n_tables, uint32_t *n_filters, uint64_t *copy_bytes);
 
 /* Micro-batch latency: batches of at most max_reads reads (x column slices) run the latency form of the
  * count kernel (one workgroup per read, its waves share the read's k-mers and strands); larger batches
@@ -385,18 +393,23 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
 /* Narrow filters -- blocks of one to eight words, tables of a few L2 sizes (10-20 MB: a bacterial genome at the reference's
  * default fragment_size) -- are bound by cache and fabric REQUESTS, not bytes: each 8-byte gather that misses the XCD's 4 MiB
  * L2 costs a 128-byte request.  Two measures, both leave the results untouched:
- *  - filters of at most `table_bytes` (default 64 MiB) never run beside another filter of the same call, so each has the
+ *  - filters of at most `table_bytes` (default 128 MiB) never run beside another filter of the same call, so each has the
  *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
- *  - for tables of [min_table_bytes, max_table_bytes] (default 6-32 MiB) and batches of at least min_reads (2049: everything
- *    above the latency kernel's micro-batches) the throughput kernel gathers in clock-phased slices: the table is cut into
- *    <= 8 slices and the 100 MHz wall clock tells every wave which slice to gather from, in windows of
- *    base_ticks + ticks_per_mib * table MiB ticks of 10 ns -- both 0 = the built-in rule, 6-12.5 us by kernel shape and table
- *    size -- so an XCD's L2 holds one slice at a time (rb_engine_set_phased; max_table_bytes = 0 switches
- *    it off; all five arguments 0 also takes one-word filters back to the plain kernel, whose 512-k-mer tiles are half empty
- *    on 250 bp reads). */
+ *  - for one- and two-word tables of [min_table_bytes, max_table_bytes] (default 6-128 MiB) and batches of at least min_reads
+ *    (2049: everything above the latency kernel's micro-batches) the throughput kernel gathers in clock-phased slices: the
+ *    table is cut into slices of 2 or 4 MiB (at most 32) and the 100 MHz wall clock tells every wave which slice to gather
+ *    from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns -- both 0 = the built-in rule, a whole cycle
+ *    over the table of 33-60 us by kernel shape -- so an XCD's L2 holds one slice at a time
+ *    (rb_engine_set_phased; max_table_bytes = 0 switches it off; all five arguments 0 also takes one-word filters back to
+ *    the plain kernel, whose 512-k-mer tiles are half empty on 250 bp reads).  Wider blocks gain nothing from phases and
+ *    keep the plain kernel. */
 RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
                                 uint32_t ticks_per_mib, uint32_t min_reads);
+/* How the phased form cuts a table, for tests and experiments: slices of 2^slice_log2 bytes (0 = the built-in rule, 2 or 4 MiB
+ * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and
+ * never more than max_slices (1-32, default 32; a table that would need more gets larger slices).  Results are identical. */
+RB_API int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_slices);
 
 /* Host batches above 8 MB of read bytes cross PCIe in slices of about slice_bytes (default 32 MiB): slice i+1 is
  * copied on a copy stream while slice i is counted.  0 = one slice (no overlap).  Results are identical. */

@@ -108,12 +108,14 @@ SIGNATURES = {
     "rb_dibf_clone_to_ex": (_int, [_vp, _int, _pp, C.POINTER(_int), C.POINTER(_dbl)]),
     "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
     "rb_engine_set_merge": (_int, [_vp, _int]),
+    "rb_engine_merge_info": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_serial_table_bytes": (_int, [_vp, _u64]),
+    "rb_engine_set_phase_slices": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -415,6 +417,12 @@ class Engine:
         """filters of one hash geometry in one merged table: 0 never, 1 when it pays (default), 2 whenever two qualify"""
         _check(lib().rb_engine_set_merge(self.h, mode), "rb_engine_set_merge")
 
+    def merge_info(self):
+        """(merged tables, filters they serve, HBM bytes of the copies)"""
+        t, f, b = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _check(lib().rb_engine_merge_info(self.h, C.byref(t), C.byref(f), C.byref(b)), "rb_engine_merge_info")
+        return t.value, f.value, b.value
+
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")
 
@@ -430,9 +438,13 @@ class Engine:
     def set_serial_table_bytes(self, table_bytes):
         _check(lib().rb_engine_set_serial_table_bytes(self.h, table_bytes), "rb_engine_set_serial_table_bytes")
 
-    def set_phased(self, min_table_bytes=6 << 20, max_table_bytes=32 << 20, base_ticks=0, ticks_per_mib=0, min_reads=2049):
+    def set_phased(self, min_table_bytes=6 << 20, max_table_bytes=128 << 20, base_ticks=0, ticks_per_mib=0, min_reads=2049):
         _check(lib().rb_engine_set_phased(self.h, min_table_bytes, max_table_bytes, base_ticks, ticks_per_mib, min_reads),
                "rb_engine_set_phased")
+
+    def set_phase_slices(self, slice_log2=0, max_slices=32):
+        """slices of 2^slice_log2 bytes (0: built-in rule; 1-5: as small as max_slices allows), at most max_slices"""
+        _check(lib().rb_engine_set_phase_slices(self.h, slice_log2, max_slices), "rb_engine_set_phase_slices")
 
     def set_host_slice_bytes(self, slice_bytes):
         _check(lib().rb_engine_set_host_slice_bytes(self.h, slice_bytes), "rb_engine_set_host_slice_bytes")

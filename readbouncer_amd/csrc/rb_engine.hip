@@ -121,17 +121,20 @@ struct rb_engine {
     std::vector<struct MergedGroup *> merged;
     std::vector<int> merged_of;  // per filter: index into `merged`, or -1
     bool merged_planned = false;
+    uint64_t merge_max_bytes = 16ull << 30;  // a merged copy costs HBM beside its members: larger groups stay apart (RB_MERGE_MAX_BYTES)
     uint32_t revcomp_of_n = rbspec::kRevCompOfN;  // see ibf_spec.h: what the reverse strand holds for an N of the read
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
-    uint64_t serial_table_bytes = 64ull << 20;   // filters up to this size never run beside another filter (L2 share)
+    uint64_t serial_table_bytes = 128ull << 20;  // filters up to this size never run beside another filter (L2 share)
     // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
-    uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 32ull << 20;
+    uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 128ull << 20;
     // window length in 10 ns ticks.  phase_explicit: base + per MiB of table, as given to rb_engine_set_phased; otherwise the
     // built-in rule of phase_window_ticks() below (measured per kernel shape, profiles/r03/window_sweep.txt).
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0;
     bool phase_explicit = false;
     uint32_t wall_clock_khz = 100000;  // rate of the device's wall clock (s_memrealtime): windows are given in 10 ns ticks
-    uint32_t phase_max_slices = 8;    // slices a table is cut into (<= 32: a wave keeps a bit per slice); RB_PHASE_MAX_SLICES for experiments
+    // rb_engine_set_phase_slices (RB_PHASE_MAX_SLICES, RB_PHASE_SLICE_LOG2 for whole processes): tests and experiments
+    uint32_t phase_max_slices = 32;   // slices a table is cut into (<= 32: a wave keeps a bit per slice)
+    uint32_t phase_slice_log2 = 0;    // slices of 2^n bytes instead of the rule of phase_slice_log2(); 1-5: as small as phase_max_slices allows
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     uint32_t phase_min_reads = 2049;  // everything above the latency kernel's batches: README shape at 2 049 reads per call 8.7 -> 9.2 M reads/s, 4 096: 11.6 -> 16.5 M, 65 536: 16.0 -> 28.3 M (profiles/r03/phased_batch_size.txt)
     bool short_read_kernel = true;
@@ -633,8 +636,12 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     if (const char *v = std::getenv("RB_MERGE")) {  // A/B switch for measurements; rb_engine_set_merge is the API
         if (std::atoi(v) >= 0 && std::atoi(v) <= 2) e->merge_mode = std::atoi(v);
     }
+    if (const char *v = std::getenv("RB_MERGE_MAX_BYTES")) e->merge_max_bytes = std::strtoull(v, nullptr, 10);
     if (const char *v = std::getenv("RB_PHASE_MAX_SLICES")) {
         if (std::atoi(v) >= 1 && std::atoi(v) <= 32) e->phase_max_slices = (uint32_t)std::atoi(v);
+    }
+    if (const char *v = std::getenv("RB_PHASE_SLICE_LOG2")) {
+        if (std::atoi(v) >= 1 && std::atoi(v) <= 26) e->phase_slice_log2 = (uint32_t)std::atoi(v);
     }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
     if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
@@ -688,9 +695,10 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
 {
     if (!e || world < 1 || rank < 0 || rank >= world) return rb::fail(RB_ERR_INVALID_ARG, "bad shard");
     std::lock_guard<std::mutex> lock(e->mu);
+    if (world != e->shard_world) e->merged_planned = false;  // a bin-sharded rank never uses merged tables: planned again at the next call
     e->shard_rank = rank;
     e->shard_world = world;
-    return RB_OK;  // (a bin-sharded rank never uses merged tables: use_merged checks shard_world per call)
+    return RB_OK;
 }
 
 int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal)
@@ -701,6 +709,18 @@ int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal)
     return RB_OK;
 }
 
+static void plan_merged(rb_engine *e);
+
+// forgets every merged copy; the next call plans again
+static void drop_merged(rb_engine *e)
+{
+    if (!e->merged.empty()) (void)hipDeviceSynchronize();  // a queued kernel may still read a merged copy
+    for (MergedGroup *g : e->merged) delete g;
+    e->merged.clear();
+    e->merged_of.clear();
+    e->merged_planned = false;
+}
+
 int rb_engine_set_merge(rb_engine *e, int mode)
 {
     if (!e || mode < 0 || mode > 2) return rb::fail(RB_ERR_INVALID_ARG, "merge mode is 0 (never), 1 (when it pays) or 2 (always)");
@@ -709,12 +729,29 @@ int rb_engine_set_merge(rb_engine *e, int mode)
         e->merge_mode = mode;
         int rc = check_device(e->device);
         if (rc != RB_OK) return rc;
-        (void)hipDeviceSynchronize();  // a queued kernel may still read a merged copy
-        for (MergedGroup *g : e->merged) delete g;
-        e->merged.clear();
-        e->merged_of.clear();
-        e->merged_planned = false;
+        drop_merged(e);
     }
+    return RB_OK;
+}
+
+int rb_engine_merge_info(rb_engine *e, uint32_t *n_tables, uint32_t *n_filters, uint64_t *copy_bytes)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    if (!e->merged_planned) plan_merged(e);
+    uint32_t t = 0, f = 0;
+    uint64_t b = 0;
+    for (const MergedGroup *g : e->merged) {
+        if (g->members.empty()) continue;  // dissolved: no room on the device
+        t += 1;
+        f += (uint32_t)g->members.size();
+        b += (g->n_blocks * hbm_stride(g->width) + 8) * 8;
+    }
+    if (n_tables) *n_tables = t;
+    if (n_filters) *n_filters = f;
+    if (copy_bytes) *copy_bytes = b;
     return RB_OK;
 }
 
@@ -769,6 +806,15 @@ int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_ta
     }
     e->phase_min_reads = min_reads;
     e->short_read_kernel = !(min_table_bytes == 0 && max_table_bytes == 0 && base_ticks == 0 && ticks_per_mib == 0 && min_reads == 0);
+    return RB_OK;
+}
+
+int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_slices)
+{
+    if (!e || slice_log2 > 26 || max_slices < 1 || max_slices > 32) return rb::fail(RB_ERR_INVALID_ARG, "slices of 2^0..26 bytes, 1..32 of them");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->phase_slice_log2 = slice_log2;
+    e->phase_max_slices = max_slices;
     return RB_OK;
 }
 
@@ -900,29 +946,64 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     return RB_OK;
 }
 
-// Window length of the clock-phased gathers in 10 ns ticks, by kernel shape and table size.  Measured on single filters
-// (profiles/r03/window_sweep.txt, session 20; K1 ms per 1 M reads).  Since the waves serve the slices in the order of the
-// clock (phase_next_slice: a wave that fell behind joins the current slice instead of working through the windows it missed)
-// the optima are flat -- +-100 ticks cost 1-3 %, where the fixed slice order of round 2 lost a factor of two just below them:
-//   both strands, one round of 4 tiles (<= 256 k-mers, 250 bp): one-word 10 MB 750 (7.7 ms), one-word 20 MB 900 (9.1 ms),
-//                                                                two-word 20 MB 800 (10.2 ms)
-//   both strands, one round of 6 tiles (<= 384 k-mers, 360 bp): one-word 10 MB 850 (11.4 ms), one-word 20 MB 1150 (13.1 ms),
-//                                                                two-word 20 MB 800-1000 (15.1 ms)
-//   two rounds of 4 tiles (<= 512 k-mers): 575-600;  per-strand tiles of the general build (longer reads, 3-8 word blocks):
-//   one-word blocks 600 (c1 at 600 bp 18.3 ms, a 10 MB filter at 1500 bp 11.9 ms per 200 k reads), wider blocks 450
-// Between the measured sizes the length is interpolated over the table size (the slice an XCD's L2 has to take in per window).
-static uint64_t phase_window_ticks(int short_only, int lg, uint64_t table_bytes)
+// Slice size and window length of the clock-phased gathers, by kernel shape, block width and table size.  Measured on
+// single filters of 7-96 MiB (profiles/r03/slice_size.txt, sessions 25-26; K1 ms per 1 M reads) after the waves had learnt to
+// serve the slices in the order of the clock (phase_next_slice), which made the optima flat (+-100 ticks cost 1-3 %):
+//  - the best window length falls with the number of slices n as CYCLE / n: what is constant is the length of a whole cycle
+//    over the table, 33-60 us -- the time the resident waves need for one round of their lookups -- so a lookup of any slice
+//    waits at most one cycle whatever n is (best windows, one-word blocks, 250 bp, 4 MiB slices: n = 3: 1500 ticks, 4: 1000-1200,
+//    5: 850-1000, 6: 850, 8: 700, 10-12: 500, 16: 400, 24: 250);
+//  - a slice of 4 MiB (one XCD's whole L2) is the better cut from 10 MiB on for one-word blocks, from 19 / 26 MiB on for
+//    two-word blocks (<= 256 / <= 384 k-mers per read); smaller tables do better with 2 MiB slices.  1 MiB slices always lose
+//    (more passes over a read's lookups, nothing gained in the L2);
+//  - with that the phased form wins over the plain kernel up to 64-128 MiB (32 slices are the kernels' limit): one-word blocks at
+//    250 bp 7.3-7.8 ms up to 10 MiB, 9.4 at 20, 10.9 at 32, 14.8 at 64, 18.3 at 96 MiB, where the plain kernel takes 10.4-24.8.
+//    Rounds 1-2 and the first half of round 3 cut every table into at most 8 slices by a shift alone (1 MiB slices at 8 MiB,
+//    2 MiB at 16 MiB) with a window length fitted at 10 and 20 MB only: 10.5 / 11.1 / 14.1 ms at 8 / 16 / 32 MiB.
+//  - blocks of four and eight words gain nothing from phases at any size (every pass over the slices issues four / eight
+//    times the load instructions per lookup of the one-word kernel: 8 MiB table 12.4 against 12.1 ms plain, 32 MiB 26.7 against
+//    21.6) and keep the plain kernel.
+static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes)
 {
     const double mib = (double)table_bytes / 1048576.0;
-    const double over = std::min(std::max(mib - 10.0, 0.0), 22.0);  // MiB above the 10 MB case
-    double t;
-    switch (short_only) {
-    case 1: t = (lg == 0 ? 750.0 : 650.0) + 15.0 * over; break;
-    case 3: t = 850.0 + (lg == 0 ? 30.0 : 5.0) * over; break;
-    case 2: t = 575.0 + 2.5 * over; break;
-    default: t = lg == 0 ? 600.0 : 450.0; break;
+    const double two_mib_below = lg == 0 ? 10.0 : shape == 1 ? 19.0 : shape == 3 ? 26.0 : 10.0;
+    return mib < two_mib_below ? 21 : 22;
+}
+
+// shape: 1 = both strands in one round of four tiles (<= 256 k-mers), 3 = one round of six tiles (<= 384), 2 = two rounds of
+// four tiles (<= 512), 0 = the general build.  base + cycle / n, fitted to the best windows of the sweep (for n = 3 ... 24:
+// one-word 250 bp 1500 ... 250-325, 360 bp 1800-2000 ... 250-325; two-word 250 bp 1500 ... 250-325, 360 bp 1800 ... 400;
+// 500 / 1000 bp 1000 ... 450; two-word blocks with 2 MiB slices have one flat optimum, 325 / 450, for every n).
+static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices)
+{
+    double base, cycle;
+    if (slice_log2 >= 22) {
+        switch (shape) {
+        case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 4000.0 : 3700.0; break;
+        case 3: base = lg == 0 ? 100.0 : 150.0; cycle = lg == 0 ? 5200.0 : 4400.0; break;
+        case 2: base = 200.0; cycle = 2500.0; break;
+        default: base = lg == 0 ? 200.0 : 100.0; cycle = lg == 0 ? 2500.0 : 2000.0; break;
+        }
+    } else {
+        switch (shape) {
+        case 1: base = lg == 0 ? 0.0 : 325.0; cycle = lg == 0 ? 3600.0 : 0.0; break;
+        case 3: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 4400.0 : 0.0; break;
+        default: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 2400.0 : 0.0; break;
+        }
     }
-    return (uint64_t)std::max(t, 400.0);
+    return (uint64_t)(base + cycle / std::max(n_slices, 1u));
+}
+
+// Up to which table size the phased form beats the plain kernel (which sits at the fabric-request wall from about 64 MiB on),
+// profiles/r03/slice_size.txt: one-word blocks and short reads 127 MiB (22.1 against 25.2 ms at 250 bp, 32.5 against 36.7 at
+// 360 bp); two-word blocks 96 MiB at 250 bp (20.2 / 24.8; even at 127 MiB), 64 MiB at 360 bp (22.2 / 35.1; at 96 MiB the
+// optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
+// 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).
+static uint64_t phase_shape_max_bytes(int shape, int lg)
+{
+    if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
+    if (shape == 3) return (lg == 0 ? 128ull : 64ull) << 20;
+    return (lg == 0 ? 64ull : 48ull) << 20;
 }
 
 // Kernel geometry of one filter for a batch: the rank's word columns (bin-sharded operation), lanes per block, words
@@ -960,21 +1041,26 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     // less time than two rounds of four tiles on one-word 10 MB filters, 15 % on a one-word 20 MB table, 22 % on two-word blocks)
     if (a.short_only == 2 && kmers <= 384 && e->six_tile_kernel) a.short_only = 3;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
-    if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 3 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
+    if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 1 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
         // the phased kernels take a lookup's slice from its byte offset by a shift: block strides that are a power of two
-        // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 3 on a wider
-        // filter, e.g. 3072 bins over 6 ranks -- stride 48 -- and keeps the plain kernel)
+        // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 1 on a wider
+        // filter, e.g. 3072 bins over 24 ranks -- stride 48 -- and keeps the plain kernel)
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
-            n_reads >= e->phase_min_reads && stride_pow2) {
+            n_reads >= e->phase_min_reads && stride_pow2 &&
+            (e->phase_explicit || table_bytes <= phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg))) {
+            const int shape = a.planes <= 10 ? a.short_only : 0;
+            const uint32_t slice_log2 = e->phase_slice_log2 ? e->phase_slice_log2 : phase_slice_log2(shape, a.lg, table_bytes);
             uint32_t sh = 0;
+            while (slice_log2 >= 6 && (f->stride * 8) << (sh + 1) <= (1ull << slice_log2)) ++sh;  // (< 6: as small as max_slices allows)
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > e->phase_max_slices) ++sh;
+            const uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
-                                               : phase_window_ticks(a.planes <= 10 && a.lg <= 1 ? a.short_only : 0, a.lg, table_bytes);
+                                               : phase_window_ticks(shape, a.lg, slice_log2, n_sl);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             ticks = std::max<uint64_t>(1, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock
             a.phase.shift = sh;
-            a.phase.n_slices = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
+            a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
             a.phase.xcd_skew = e->phase_xcd_skew;
         } else if (a.lg == 0 && e->short_read_kernel) {
@@ -1124,12 +1210,41 @@ int rb_classify_batch_device(rb_engine *e, const void *d_seqs, const void *d_off
 
 }  // extern "C"
 
-// Which filters share a merged table.  Candidates: three hash functions, blocks of at most 8 words, equal noOfBlocks and k.
-// "When it pays" (mode 1): a merged lookup costs one request whatever it serves (~58 G/s from a table beyond the L2s: 24.6 ms
-// per 1 M reads of 250 bp), against 7.6 ms per one-word and 10.1 ms per two-word member with the phased kernels on their own
-// (profiles/r03): four or more members, or five or more words.  At most 16 words (one 128-byte line) per merged block.
+// K1 time estimates behind the "when it pays" rule of plan_merged, in ms per 1 M reads of 250 bp (238 k-mers, three hash
+// functions), from profiles/r03/slice_size.txt and merged_tables.txt: what a table of `mib` MiB costs
+//  - with the plain gathers (also the merged kernel's): L2-resident up to 4 MiB, then the hit rate falls with 4 MiB / table
+//    until the kernel sits at the chip's fabric-request wall (~56 G requests/s) from about 64 MiB on, whatever the block width;
+//  - with the clock-phased gathers (one- and two-word blocks, 6-128 MiB): 6.6 + 0.125 per MiB (two-word 7.0 + 0.15).
+static double est_plain_ms(double mib)
+{
+    static const double pts[][2] = {{0, 6.1}, {4, 6.5}, {6, 8.7}, {8, 12.0}, {12, 15.8}, {16, 17.9}, {24, 19.9}, {32, 21.5}, {48, 23.2}, {64, 24.0}, {128, 25.0}};
+    const int n = (int)(sizeof(pts) / sizeof(pts[0]));
+    if (mib >= pts[n - 1][0]) return pts[n - 1][1];
+    int i = 1;
+    while (pts[i][0] < mib) ++i;
+    return pts[i - 1][1] + (pts[i][1] - pts[i - 1][1]) * (mib - pts[i - 1][0]) / (pts[i][0] - pts[i - 1][0]);
+}
+
+static double est_filter_ms(const rb_engine *e, const rb_dibf *f)
+{
+    const uint64_t bytes = f->geo.n_blocks * f->stride * 8;
+    const double mib = (double)bytes / 1048576.0;
+    const bool phased = f->geo.n_hash == 3 && f->geo.bin_width <= 2 && e->phase_max_bytes && bytes >= e->phase_min_bytes &&
+                        bytes <= std::min<uint64_t>(e->phase_max_bytes, phase_shape_max_bytes(1, f->geo.bin_width == 1 ? 0 : 1));
+    if (!phased) return est_plain_ms(mib);
+    return f->geo.bin_width == 1 ? 6.6 + 0.125 * mib : 7.0 + 0.15 * mib;
+}
+
+// Which filters share a merged table.  Candidates: three hash functions, blocks of at most 8 words, equal noOfBlocks and k; at
+// most 16 words (one 128-byte line) per merged block.  "When it pays" (mode 1): when the members one after the other are
+// estimated to take longer than ONE pass of the merged kernel over the merged table (+ 0.3 ms per member for its maxima):
+//   README shape (three one-word targets of 10 MiB + a two-word deplete filter of 20 MiB): 33.6 against 25.5 -> merged (measured
+//   29.9 -> 40.8 M reads/s); three one-word filters of 10 MiB: 23.7 against 23.6 -> apart; two filters of 12 or 24 MB: apart
+//   (measured 0.88 x merged); two filters beyond the phased range (each at the request wall on its own): merged (1.9-2.0 x
+//   measured at 48-540 MB per table, 3.0 x for three); two filters of 1-2 MB whose merged copy still fits an L2: merged (1.65 x).
 static void plan_merged(rb_engine *e)
 {
+    drop_merged(e);
     e->merged_planned = true;
     e->merged_of.assign(e->filters.size(), -1);
     if (e->merge_mode == 0 || e->shard_world != 1) return;
@@ -1147,8 +1262,12 @@ static void plan_merged(rb_engine *e)
             members.push_back((uint32_t)j);
             width += gj.bin_width;
         }
-        const bool pays = members.size() >= 4 || (members.size() >= 2 && width >= 5);
-        if (members.size() < 2 || (e->merge_mode == 1 && !pays)) continue;
+        if (members.size() < 2) continue;
+        double apart = 0.0;
+        for (uint32_t m : members) apart += est_filter_ms(e, e->filters[m]);
+        const double together = est_plain_ms((double)(gi.n_blocks * hbm_stride(width) * 8) / 1048576.0) + 0.3 * (double)members.size();
+        if (e->merge_mode == 1 && apart <= 1.05 * together) continue;
+        if ((gi.n_blocks * hbm_stride(width) + 8) * 8 > e->merge_max_bytes) continue;
         MergedGroup *g = new (std::nothrow) MergedGroup();
         if (!g) return;
         g->members = members;
@@ -1159,7 +1278,9 @@ static void plan_merged(rb_engine *e)
     }
 }
 
-// the merged copy of a group, made (or made again after a member changed) on `st`
+// the merged copy of a group, made (or made again after a member changed) on `st`.  kMergeNoMemory: the device has no room
+// for the copy -- the caller dissolves the group and its members are served one by one as before.
+static constexpr int kMergeNoMemory = -1000;
 static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
 {
     bool fresh = g->d_words != nullptr && g->versions.size() == g->members.size();
@@ -1167,7 +1288,13 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
     if (fresh) return RB_OK;
     if (!g->d_words) {
         g->stride = hbm_stride(g->width);
-        RB_HIP(hipMalloc((void **)&g->d_words, (g->n_blocks * g->stride + 8) * 8));
+        if (hipMalloc((void **)&g->d_words, (g->n_blocks * g->stride + 8) * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            g->d_words = nullptr;
+            return kMergeNoMemory;
+        }
+    } else {
+        RB_HIP(hipDeviceSynchronize());  // made again: a kernel of an earlier call (on any stream) may still read the old copy
     }
     RB_HIP(hipMemsetAsync(g->d_words, 0, (g->n_blocks * g->stride + 8) * 8, st));
     g->versions.assign(g->members.size(), 0);
@@ -1260,8 +1387,15 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     if (!e->merged_planned) plan_merged(e);
     const bool use_merged = !e->merged.empty() && n_reads > e->split_threshold && e->shard_world == 1;
     if (use_merged) {
-        for (MergedGroup *g : e->merged) {
-            if ((rc = ensure_merged_table(e, g, st)) != RB_OK) return rc;
+        for (size_t gi = 0; gi < e->merged.size(); ++gi) {
+            MergedGroup *g = e->merged[gi];
+            if (g->members.empty()) continue;  // dissolved
+            if ((rc = ensure_merged_table(e, g, st)) == kMergeNoMemory) {
+                for (uint32_t m : g->members) e->merged_of[m] = -1;
+                g->members.clear();
+                continue;
+            }
+            if (rc != RB_OK) return rc;
             CountLaunch a{};
             a.f = g->dev;
             a.f.comp_n = e->revcomp_of_n;

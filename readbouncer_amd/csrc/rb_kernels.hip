@@ -1549,19 +1549,15 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
 template <int NP>
 static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
 {
-    switch (a.lg) {
-    case 0: return launch_phased<0, NP>(a, st);
-    case 1: return launch_phased<1, NP>(a, st);
-    case 2: return launch_phased<2, NP>(a, st);
-    default: return launch_phased<3, NP>(a, st);
-    }
+    // blocks of one and two words only: wider blocks gain nothing from phases (rb_engine.hip, phase_slice_log2)
+    return a.lg == 0 ? launch_phased<0, NP>(a, st) : launch_phased<1, NP>(a, st);
 }
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
 {
     if (a.n_reads == 0) return hipSuccess;
-    if (a.phase.n_slices && a.split_waves < 2) {  // planned by the engine for: 3 hash functions, one slice, lg <= 3, wpl 1, n_fused 0
-        if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 3 || a.n_slices != 1 || a.n_fused > 0) return hipErrorInvalidValue;
+    if (a.phase.n_slices && a.split_waves < 2) {  // planned by the engine for: 3 hash functions, one slice, lg <= 1, wpl 1, n_fused 0
+        if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 1 || a.n_slices != 1 || a.n_fused > 0 || a.phase.n_slices > 32) return hipErrorInvalidValue;
         // slice of a lookup = byte offset >> (shift + 3 + log2 stride): more than one slice needs a power-of-two block stride
         if (a.phase.n_slices > 1 && (a.f.stride & (a.f.stride - 1)) != 0) return hipErrorInvalidValue;
         return a.planes <= 10 ? dispatch_phased<10>(a, st) : dispatch_phased<16>(a, st);

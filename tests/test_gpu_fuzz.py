@@ -70,8 +70,9 @@ def _random_geometry(seed, n_rule):
         mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
         assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, split)
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, split)
-    # throughput form with clock-phased gathers (forced; serves blocks of up to 8 words with three hash functions)
+    # throughput form with clock-phased gathers (forced; serves blocks of one and two words with three hash functions)
     eng.set_phased(0, 1 << 40, int(rng.choice([0, 100, 1500])), int(rng.choice([1, 30])), 1)
+    eng.set_phase_slices(1, int(rng.choice([2, 5, 8, 32])))  # as many slices as that, however small the table
     mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
     assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, "phased")
     assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, "phased")

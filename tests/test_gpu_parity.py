@@ -92,14 +92,17 @@ def test_raw_max_matches_oracle(n_bins, n_blocks, k, h):
     eng.set_split_threshold(2048)
     assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], expect)
     eng.set_nt_threshold(512 << 20)
-    # throughput form with clock-phased gathers (planned for narrow filters of 6-32 MiB only; forced here for every
-    # geometry it can serve: blocks of up to 8 words): windows from far shorter to far longer than a wave needs
+    # throughput form with clock-phased gathers (planned for one- and two-word tables of 6-128 MiB only; forced here on every
+    # geometry -- wider blocks keep the plain kernel): windows from far shorter to far longer than a wave needs, the table cut
+    # into as many as 8 / 32 / 3 slices (the built-in rule would give a test-sized table one slice)
     eng.set_split_threshold(0)
-    for base_ticks in (1, 300, 2000):
+    for base_ticks, max_slices in ((1, 8), (300, 32), (2000, 3)):
         eng.set_phased(0, 1 << 40, base_ticks, 3, 1)
+        eng.set_phase_slices(1, max_slices)
         mc3, _, dec3, st3 = eng.classify(buf, offs, lens)
         assert np.array_equal(mc3[:, 0], expect) and np.array_equal(dec3, decision) and np.array_equal(st3, status), base_ticks
-    eng.set_phased(6 << 20, 32 << 20, 0, 0, 4096)  # the built-in window rule
+    eng.set_phased()  # the built-in rules
+    eng.set_phase_slices()
     eng.set_split_threshold(2048)
     # latency form with several workgroups per read (wide filters only; a no-op setting for the narrow ones):
     # workgroups per read x shares per 64-k-mer tile, twice each (the arrival counters must come back to zero)
@@ -351,6 +354,7 @@ def test_device_pointer_api_and_column_shards():
     eng5 = capi.Engine(0, [d5], [])
     eng5.set_split_threshold(0)
     eng5.set_phased(0, 1 << 40, 200, 0, 1)
+    eng5.set_phase_slices(1, 8)
     for world in (1, 2, 3):
         acc = np.zeros(n, dtype=np.uint16)
         for rank in range(world):
@@ -619,6 +623,7 @@ def test_packed_reads_and_on_gpu_chunking(form):
         eng.set_split_threshold(0)
         if form == "phased":
             eng.set_phased(0, 1 << 40, 200, 0, 1)
+            eng.set_phase_slices(1, 32)
         else:
             eng.set_phased(0, 0, 0, 0, 0)
     packed, p_off, nmask, n_off = capi.pack_reads(buf, offs, lens)
@@ -868,6 +873,7 @@ def test_n_reads_under_both_revcomp_rules(refdata, n_rule):
                 eng.set_split_threshold(2048 if form == "latency" else 0)
                 if form == "phased":
                     eng.set_phased(0, 1 << 40, 200, 0, 1)
+                    eng.set_phase_slices(1, 8)
                 else:
                     eng.set_phased(0, 0, 0, 0, 0) if form == "throughput" else eng.set_phased()
                 mc, _, dec, st = eng.classify(buf, offs, lens)
@@ -913,6 +919,7 @@ def test_bin_sharded_rank_with_odd_stride_keeps_the_plain_kernel():
         for forced in (False, True):
             if forced:
                 eng.set_phased(0, 1 << 40, 300, 0, 1)
+                eng.set_phase_slices(1, 32)
             acc = np.zeros(len(reads), dtype=np.uint16)
             for rank in range(6):
                 eng.set_column_shard(rank, 6)
@@ -1031,8 +1038,13 @@ def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
     exp_max = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
     exp_dec, exp_st = po.batch_check_unblock(views[:nd], views[nd:], buf, offs, lens, n_threads=8)
     results = {}
+    # what merges: at most 16 words per merged block, so the twelve filters make a table of ten and a pair; tables as small as
+    # these (L2-resident on their own and merged) always pay, so mode 1 merges what mode 2 does
+    expect = {(122, 43, 29, 49): (1, 4), (64, 64, 64, 64, 10): (1, 5), (130, 200): (1, 2),
+              (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64): (2, 12)}[widths]
     for mode in (0, 1, 2):
         eng.set_merge(mode)
+        assert eng.merge_info()[:2] == ((0, 0) if mode == 0 else expect), (mode, eng.merge_info())
         mc, best, dec, st = eng.classify(buf, offs, lens)  # > 2048 reads: throughput form
         assert np.array_equal(mc, exp_max), mode
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), mode
@@ -1072,3 +1084,60 @@ def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
         assert np.array_equal(eng.classify(buf, offs, lens)[0], exp4) and not np.array_equal(exp4, exp2)
     finally:
         po.set_revcomp_of_n(prev)
+
+
+def test_a_merged_copy_beyond_the_cap_is_not_made(monkeypatch):
+    """The merged copy costs HBM beside its members: a group whose copy would exceed RB_MERGE_MAX_BYTES (default 16 GiB) is not
+    made -- a smaller group of the remaining filters may be -- and what stays apart is served by the per-filter kernels: same
+    results."""
+    rng = np.random.default_rng(77)
+    n_blocks = 20011
+    ref = H.random_dna(rng, 30000)
+    filters, views, keep = [], [], []
+    for i, bins in enumerate((100, 30, 30, 30)):
+        W = (bins + 63) // 64
+        d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks)
+        d.fill_synth(7 + i)
+        d.add_sequence(ref[i * 5000:i * 5000 + 8000], 300)
+        filters.append(d)
+        h = d.download()
+        keep.append(h)
+        views.append(po.OracleIBF.wrap(bins, 3, 13, h.info["n_bits"], h.words()))
+    reads = make_reads(rng, ref, 2300, lo=20, hi=400, err=0.08, n_frac=0.1)
+    buf, offs, lens = H.pack_reads(reads)
+    exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    copy_bytes = (n_blocks * 8 + 8) * 8  # five words, padded to eight
+    small_copy = (n_blocks * 4 + 8) * 8  # the three one-word targets alone: three words, padded to four
+    for cap, expect in ((copy_bytes, (1, 4, copy_bytes)), (copy_bytes - 1, (1, 3, small_copy)), (1000, (0, 0, 0))):
+        monkeypatch.setenv("RB_MERGE_MAX_BYTES", str(cap))
+        eng = capi.Engine(0, filters[:1], filters[1:])
+        assert eng.merge_info() == expect
+        assert np.array_equal(eng.classify(buf, offs, lens)[0], exp)
+        eng.destroy()
+
+
+@pytest.mark.parametrize("shape,merged", [
+    ([(122, 20.0), (43, 10.4), (29, 10.4), (49, 10.4)], True),   # the reference's README shape: 33.6 against 25.5 ms estimated
+    ([(40, 10.4), (50, 10.4), (60, 10.4)], False),              # three one-word filters of 10 MiB: the phased kernels are as fast
+    ([(64, 12.0), (64, 12.0)], False),                         # measured 0.88 x
+    ([(64, 24.0), (64, 24.0), (64, 24.0)], True),               # measured 1.24 x
+    ([(64, 160.0), (128, 320.0)], True),                        # beyond the phased range each sits at the request wall: 2 x
+    ([(64, 1.0), (64, 1.0)], True),                             # the merged copy still fits an L2: 1.65 x
+])
+def test_merge_when_it_pays(shape, merged):
+    """Mode 1 of rb_engine_set_merge compares K1 time estimates (rb_engine.hip, est_filter_ms): the members one after the other
+    against one pass over the merged table.  The cases are the measured ones of profiles/r03/merged_tables.txt."""
+    n_blocks = None
+    filters = []
+    for bins, mib in shape:
+        W = (bins + 63) // 64
+        if n_blocks is None:
+            n_blocks = int(mib * (1 << 20) / (8 * W))
+        filters.append(capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks))
+    eng = capi.Engine(0, filters[:1], filters[1:])
+    assert eng.merge_info()[:2] == ((1, len(shape)) if merged else (0, 0)), eng.merge_info()
+    eng.set_merge(2)
+    assert eng.merge_info()[:2] == (1, len(shape))
+    eng.destroy()
+    for f in filters:
+        f.free()

@@ -249,14 +249,14 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         eng.set_serial_table_bytes(0)
         base = eng.classify(buf, offs, lens)
         assert len(set(base[2].tolist())) == 3
-        eng.set_serial_table_bytes(64 << 20)
-        for args in ((6 << 20, 32 << 20, 0, 0, 4096), (6 << 20, 32 << 20, 120, 0, 1024), (6 << 20, 32 << 20, 1500, 0, 1024),
+        eng.set_serial_table_bytes(128 << 20)
+        for args in ((6 << 20, 128 << 20, 0, 0, 4096), (6 << 20, 128 << 20, 120, 0, 1024), (6 << 20, 128 << 20, 1500, 0, 1024),
                      (0, 0, 450, 0, 1024)):     # the last one: short-read tiles without windows
             eng.set_phased(*args)
             got = eng.classify(buf, offs, lens)
             assert np.array_equal(got[0], base[0]) and np.array_equal(got[2], base[2]) and np.array_equal(got[1], base[1]), args
         # ragged lengths around the 256-k-mer switch, in one batch (both paths of one launch)
-        eng.set_phased(6 << 20, 32 << 20, 0, 0, 1024)
+        eng.set_phased(6 << 20, 128 << 20, 0, 0, 1024)
         m = 40_000
         rl = rng.integers(200, 330, size=m).astype(np.uint32)
         ro = (np.arange(m, dtype=np.uint64) * np.uint64(read_len))
@@ -265,7 +265,7 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         eng.set_phased(0, 0, 0, 0, 0)
         g0 = eng.classify(buf, ro, rl)
         assert np.array_equal(g1[0], g0[0]) and np.array_equal(g1[2], g0[2])
-        eng.set_phased(6 << 20, 32 << 20, 0, 0, 4096)
+        eng.set_phased(6 << 20, 128 << 20, 0, 0, 4096)
         # strand symmetry through the phased kernels
         comp = np.zeros(256, dtype=np.uint8)
         comp[np.frombuffer(b"ACGT", dtype=np.uint8)] = np.frombuffer(b"TGCA", dtype=np.uint8)
@@ -285,3 +285,32 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         n = 3000
         exp_dec, exp_st = po.batch_check_unblock(views[:1], views[1:], buf, offs[:n], lens[:n], n_threads=8)
         assert np.array_equal(base[2][:n], exp_dec) and np.array_equal(base[3][:n], exp_st)
+
+
+@pytest.mark.parametrize("bins,mib", [(64, 8.0), (64, 100.0), (128, 60.0), (100, 30.0)])
+def test_phased_form_over_its_whole_range_agrees_with_the_plain_kernel(bins, mib):
+    """The phased form serves one- and two-word tables of 6-128 MiB in slices of 2 or 4 MiB, up to 32 of them (rb_engine.hip,
+    phase_slice_log2 / phase_window_ticks): same maxima as the plain kernel on 10^5 reads of 250, 360 and 600 bp at the ends of
+    that range (8 MiB: four slices of 2 MiB; 100 MiB: 25 slices of 4 MiB; two-word 60 and 30 MiB), and a sample against the
+    oracle."""
+    W = (bins + 63) // 64
+    n_blocks = int(mib * (1 << 20) / (8 * W)) - 5
+    d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks)
+    d.fill_synth(int(mib))
+    ref, starts, ends = synth.planted_reference(500 + bins, 256, 2000)
+    d.insert(ref, starts, ends, (np.arange(256, dtype=np.uint64) * np.uint64(7)) % np.uint64(bins))
+    eng = capi.Engine(0, [d], [])
+    h = d.download()
+    view = po.OracleIBF.wrap(bins, 3, 13, h.info["n_bits"], h.words())
+    for read_len in (250, 360, 600):
+        buf, offs, lens = synth.make_reads(read_len + bins, 100_000, read_len, ref)
+        eng.set_phased(0, 0, 0, 0, 0)
+        plain = eng.classify(buf, offs, lens)
+        eng.set_phased()
+        phased = eng.classify(buf, offs, lens)
+        assert np.array_equal(plain[0], phased[0]) and np.array_equal(plain[2], phased[2]), read_len
+        assert phased[0].max() > 100
+        n = 1500
+        assert np.array_equal(phased[0][:n, 0], po.batch_raw_max(view, buf, offs[:n], lens[:n], 8)), read_len
+    eng.destroy()
+    d.free()
