@@ -186,14 +186,14 @@ class Ctx:
         self.filter_setup_s = 0.0
 
     SEEDS = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60), "grch38_f100k": (8, 80),
-             "zymo16": (6, 60), "mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113)}
+             "zymo16": (6, 60), "mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113), "w1_64mib": (15, 114)}
 
     def filter(self, key):
         from readbouncer_amd import synth
         if key not in self.filters:
             t = time.time()
             fs, ps = self.SEEDS[key]
-            seg = 512 if key.startswith("mock_") else 2048
+            seg = 512 if key.startswith("mock_") or key.startswith("w1_") else 2048
             self.filters[key] = synth.build_device_filter(self.dev_index, synth.WORKLOADS[key], fill_seed=fs, plant_seed=ps,
                                                           n_segments=seg)
             self.torch.cuda.synchronize()
@@ -359,22 +359,22 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         probe = load_json("ceilings.json").get(name, {})
         decisions = t_dec.cpu().numpy()
 
-        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- to eight-word blocks with a
-        # table of 6-32 MiB (or one-word blocks of any size) take the phased kernel, everything else the plain one
+        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- and two-word blocks with a
+        # table of 6 MiB up to 48-128 MiB by kernel shape (or one-word blocks of any size: the no-clock form of that kernel) take
+        # the phased kernel, everything else the plain one; merged tables as the engine reports them
+        kmers = max(0, read_len - int(filters[0].info["kmer_size"]) + 1)
+        short = kmers <= 384
+
         def phased(f):
-            tb = f.info["n_blocks"] * f.device_stride() * 8
-            return f.info["bin_width"] <= 8 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= (32 << 20) or f.info["bin_width"] == 1)
-        # filters of one hash geometry share a merged table when that pays (rb_engine.hip, plan_merged)
-        narrow = [f for f in filters if f.info["bin_width"] <= 8 and f.info["n_hash"] == 3]
-        geos = {}
-        for f in narrow:
-            geos.setdefault((f.info["n_blocks"], f.info["kmer_size"]), []).append(f)
-        merged = set()
-        for grp in geos.values():
-            if len(grp) >= 4 or (len(grp) >= 2 and sum(f.info["bin_width"] for f in grp) >= 5):
-                merged.update(id(f) for f in grp)
-        forms = {("ibf_count_max_merged_kernel" if id(f) in merged else "ibf_count_max_phased_kernel" if phased(f)
-                  else "ibf_count_max_kernel") for f in filters}
+            W, tb = f.info["bin_width"], f.info["n_blocks"] * f.device_stride() * 8
+            cap = ((128 if W == 1 else 96 if kmers <= 256 else 64) if short else (64 if W == 1 else 48)) << 20
+            return W <= 2 and f.info["n_hash"] == 3 and ((6 << 20) <= tb <= cap or W == 1)
+        n_merged = eng.merge_info()[1] if not bin_sharded else 0
+        forms = set()
+        if n_merged:
+            forms.add("ibf_count_max_merged_kernel")
+        if n_merged < len(filters):  # (which filters a partial merge leaves out is the engine's business: name both forms then)
+            forms |= {"ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel" for f in filters}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": " + ".join(sorted(forms)), "avg_kernel_ms": avg_kernel_s * 1e3,

@@ -14,6 +14,8 @@ run readme360 60 --workload readme --read-len 360
 run readme600 40 --workload readme --read-len 600 --reads 500000
 run c1 60 --workload c1
 run c1_250 40 --workload c1 --read-len 250
+run w1_64mib_250 40 --workload w1_64mib
+run w1_64mib_360 40 --workload w1_64mib --read-len 360
 run c2 60 --workload c2
 run c4 90 --workload c4
 run c3 90 --workload c3 --reads 2000000

@@ -2,7 +2,7 @@
 """A/B of the merged table on pairs of LARGE filters (the fuse rule of plan_merged was measured on the README shape's narrow
 tables): two filters of one hash geometry, far beyond the L2s and the Infinity Cache; 1 M reads of 360 bp per launch, hipEvent
 time of the count kernels (rb_engine_kernel_time), merge off against merge on; maxima compared.
-Usage (GPU box): python profiles/r03/merged_big_tables.py"""
+Usage (GPU box): python profiles/r03/merged_tables.py"""
 import os
 import sys
 

@@ -3,5 +3,5 @@
 set -u
 O=gpurun_out/r03
 mkdir -p $O
-timeout 800 python profiles/r03/merged_big_tables.py sweep > $O/merged_sweep.txt 2>&1
+timeout 800 python profiles/r03/merged_tables.py sweep > $O/merged_sweep.txt 2>&1
 cat $O/merged_sweep.txt

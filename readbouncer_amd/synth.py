@@ -38,6 +38,10 @@ WORKLOADS = {
     "mock_t1": dict(name="4.2 Mbp genome (43 bins)", n_bins=43, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
     "mock_t2": dict(name="2.8 Mbp genome (29 bins)", n_bins=29, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
     "mock_t3": dict(name="4.8 Mbp genome (49 bins)", n_bins=49, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=250),
+    # a one-word filter at a large fragment_size (64 bins of 615 kbp: a 39 Mbp genome), 64 MiB: the upper half of the range the
+    # clock-phased gathers serve since round 3 (16 slices of 4 MiB)
+    "w1_64mib": dict(name="64-bin IBF of 64 MiB (one-word blocks, 8 388 605 of them)", n_bins=64, k=13, h=3, fragment=None,
+                     n_bits=64 * 8388605, reads=1_000_000, read_len=250),
 }
 
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
