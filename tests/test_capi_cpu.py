@@ -206,3 +206,36 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "RB_BENCH_SAME_GPU", "RB_BENCH_ENGINE")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 2 and "GPU(s) visible" in p.stderr and p.stdout.strip() == ""
+
+
+ZERO_SWEEP = r"""
+import ctypes as C, sys
+from readbouncer_amd import capi
+L = capi.lib()
+ok_allowed = {"rb_device_count", "rb_is_ibf_file", "rb_calculate_ci", "rb_pack_reads"}   # fine with zeros (an empty batch packs to nothing)
+report = []
+for name, (restype, argtypes) in sorted(capi.SIGNATURES.items()):
+    args = []
+    for t in argtypes:
+        if t in (C.c_double,):
+            args.append(0.0)
+        elif t in (C.c_int, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64, C.c_size_t):
+            args.append(0)
+        else:
+            args.append(None)
+    r = getattr(L, name)(*args)
+    report.append((name, r if restype is not None else None))
+    if restype is C.c_int and name not in ok_allowed and r == 0:
+        print("RETURNED_OK", name); sys.exit(3)
+print("SWEPT", len(report))
+"""
+
+
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """Every function of the C ABI called with NULL for each pointer and 0 for each scalar: no crash (the sweep runs in a child
+    process, a segfault would show as its exit code), and every status-returning function refuses (nothing reports RB_OK for a
+    NULL handle).  Runs with or without a GPU."""
+    import sys
+    r = subprocess.run([sys.executable, "-c", ZERO_SWEEP], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "SWEPT %d" % len(capi.SIGNATURES) in r.stdout

@@ -1141,3 +1141,55 @@ def test_merge_when_it_pays(shape, merged):
     eng.destroy()
     for f in filters:
         f.free()
+
+
+HANDLE_SWEEP = r"""
+import ctypes as C, sys
+import numpy as np
+from readbouncer_amd import capi
+L = capi.lib()
+d = capi.DeviceIBF.create(0, 100, 3, 13, 128 * 4099)
+eng = capi.Engine(0, [d], [])
+live = capi.Live(eng, 0.1, 0.95, 2000)
+handles = {"rb_engine_": eng.h, "rb_classify_": eng.h, "rb_decide_": eng.h, "rb_replay_": eng.h, "rb_dibf_": d.h, "rb_live_": live.h}
+skip = {"rb_engine_create", "rb_engine_destroy", "rb_dibf_create", "rb_dibf_upload", "rb_dibf_open", "rb_dibf_free", "rb_live_create",
+        "rb_live_destroy", "rb_dibf_clone_to", "rb_dibf_clone_to_ex"}
+must_refuse = {"rb_classify_batch", "rb_classify_batch_ptrs", "rb_classify_batch_device", "rb_classify_batch_device_ex", "rb_decide_device",
+               "rb_decide_device_parts", "rb_live_process", "rb_replay_arrivals", "rb_live_replay_arrivals", "rb_dibf_insert",
+               "rb_dibf_add_sequence", "rb_dibf_download", "rb_dibf_resize_bins", "rb_dibf_compare", "rb_dibf_get_info"}
+n_called = 0
+for name, (restype, argtypes) in sorted(capi.SIGNATURES.items()):
+    h = next((v for k, v in handles.items() if name.startswith(k)), None)
+    if h is None or name in skip:
+        continue
+    args = [h]
+    for t in argtypes[1:]:
+        if t is C.c_double:
+            args.append(0.1)
+        elif t is C.c_size_t:
+            args.append(5)            # five items behind NULL buffers
+        elif t in (C.c_int, C.c_uint8, C.c_uint16, C.c_uint32, C.c_uint64):
+            args.append(0)
+        else:
+            args.append(None)
+    r = getattr(L, name)(*args)
+    n_called += 1
+    if name in must_refuse and r == 0:
+        print("ACCEPTED", name); sys.exit(3)
+# the engine still works afterwards
+buf = np.frombuffer(b"ACGTACGTACGTACGTACGTACGTACGTACGT", dtype=np.uint8).copy()
+mc, best, dec, st = eng.classify(buf, np.array([0], dtype=np.uint64), np.array([32], dtype=np.uint32))
+assert st[0] == 0
+print("CALLED", n_called)
+"""
+
+
+def test_c_abi_refuses_null_buffers_behind_valid_handles():
+    """Every engine / filter / live-step entry point called with a VALID handle, five items and NULL for every buffer: no crash (child
+    process), the batch and build functions refuse, and the engine classifies normally afterwards."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", HANDLE_SWEEP], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "CALLED" in r.stdout
