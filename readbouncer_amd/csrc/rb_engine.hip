@@ -1006,6 +1006,17 @@ static uint64_t phase_shape_max_bytes(int shape, int lg)
     return (lg == 0 ? 64ull : 48ull) << 20;
 }
 
+// A read needs at least one whole cycle over its table's slices, and a cycle is not shorter than the refill of the table: small
+// batches of a large table are served faster by the plain kernel (profiles/r03/phased_batch_size.txt, second part: 64 MiB
+// one-word, 250 bp, 2 049 reads per call 78 us phased against 65 plain, 4 096: 105 / 116; 120 MiB: even at 16 384 reads, 1.11-1.17 x
+// at 65 536).  Tables of up to 32 MiB pay from the first batch above the latency kernel's (rb_engine::phase_min_reads).
+static size_t phase_min_reads_for(uint64_t table_bytes)
+{
+    if (table_bytes > (64ull << 20)) return 32768;
+    if (table_bytes > (32ull << 20)) return 4096;
+    return 0;
+}
+
 // Kernel geometry of one filter for a batch: the rank's word columns (bin-sharded operation), lanes per block, words
 // per lane, counter planes, column slices, and the form of K1 (throughput, or latency with its waves / workgroups per
 // read).  false = this rank owns no column of the filter.
@@ -1048,7 +1059,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
             n_reads >= e->phase_min_reads && stride_pow2 &&
-            (e->phase_explicit || table_bytes <= phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg))) {
+            (e->phase_explicit || (table_bytes <= phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg) &&
+                                   n_reads >= phase_min_reads_for(table_bytes)))) {
             const int shape = a.planes <= 10 ? a.short_only : 0;
             const uint32_t slice_log2 = e->phase_slice_log2 ? e->phase_slice_log2 : phase_slice_log2(shape, a.lg, table_bytes);
             uint32_t sh = 0;
