@@ -38,7 +38,7 @@ with open(fq, "wb") as fh:
 print("setup %.1fs: 4 filters %.0f MB, fastq %.2f GB (%d reads of %d bp)" % (time.time() - t0, sum(os.path.getsize(p) for p in paths) / 1e6,
                                                                               os.path.getsize(fq) / 1e9, n_reads, L))
 cli = os.path.join(ROOT, "readbouncer_amd", "readbouncer_amd_cli")
-for chunk, max_chunks in ((250, 1), (250, 5)):
+for chunk, max_chunks in ((250, 1), (250, 5)):  # RB_CLI_ARGS="--ingest-threads 8 ..." passes pipeline knobs through
     cfg = os.path.join(work, "c.toml")
     open(cfg, "w").write('usage = "classify"\noutput_directory = "%s/out"\nlog_directory = "%s/out/logs"\n[IBF]\n'
                          'deplete_files = ["%s"]\ntarget_files = ["%s", "%s", "%s"]\nread_files = ["%s"]\nchunk_length = %d\nmax_chunks = %d\n'
@@ -46,7 +46,7 @@ for chunk, max_chunks in ((250, 1), (250, 5)):
     for rep in range(2):
         subprocess.run(["rm", "-rf", os.path.join(work, "out")])
         a = time.time()
-        p = subprocess.run([cli, "--config", cfg], capture_output=True, text=True)
+        p = subprocess.run([cli, "--config", cfg] + os.environ.get("RB_CLI_ARGS", "").split(), capture_output=True, text=True)
         wall = time.time() - a
         lines = [l for l in p.stdout.splitlines() if l.startswith(("RESULT", "THROUGHPUT"))]
         print("chunk_length %d max_chunks %d: process wall %.2f s (%.2f M reads/s incl. loading 4 filters) | %s %s"

@@ -953,8 +953,10 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 //    over the table, 33-60 us -- the time the resident waves need for one round of their lookups -- so a lookup of any slice
 //    waits at most one cycle whatever n is (best windows, one-word blocks, 250 bp, 4 MiB slices: n = 3: 1500 ticks, 4: 1000-1200,
 //    5: 850-1000, 6: 850, 8: 700, 10-12: 500, 16: 400, 24: 250);
-//  - a slice of 4 MiB (one XCD's whole L2) is the better cut from 10 MiB on for one-word blocks, from 19 / 26 MiB on for
-//    two-word blocks (<= 256 / <= 384 k-mers per read); smaller tables do better with 2 MiB slices.  1 MiB slices always lose
+//  - a slice of 4 MiB (one XCD's whole L2) is the better cut from 10 MiB on for one-word blocks, from 18.5 MiB on for two-word
+//    blocks (with 2 MiB slices their optimum is a narrow dip that moves with the table, with 4 MiB slices a flat region: the
+//    README deplete filter, 122 bins = 18.9 MiB, 360 bp: 15.1-15.5 ms at 800-1000 ticks against 14.6 / 15.2 / 16.1 at 350 / 400 / 450);
+//    smaller tables do better with 2 MiB slices.  1 MiB slices always lose
 //    (more passes over a read's lookups, nothing gained in the L2);
 //  - with that the phased form wins over the plain kernel up to 64-128 MiB (32 slices are the kernels' limit): one-word blocks at
 //    250 bp 7.3-7.8 ms up to 10 MiB, 9.4 at 20, 10.9 at 32, 14.8 at 64, 18.3 at 96 MiB, where the plain kernel takes 10.4-24.8.
@@ -966,14 +968,14 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes)
 {
     const double mib = (double)table_bytes / 1048576.0;
-    const double two_mib_below = lg == 0 ? 10.0 : shape == 1 ? 19.0 : shape == 3 ? 26.0 : 10.0;
+    const double two_mib_below = lg == 0 ? 10.0 : (shape == 1 || shape == 3) ? 18.5 : 10.0;
     return mib < two_mib_below ? 21 : 22;
 }
 
 // shape: 1 = both strands in one round of four tiles (<= 256 k-mers), 3 = one round of six tiles (<= 384), 2 = two rounds of
 // four tiles (<= 512), 0 = the general build.  base + cycle / n, fitted to the best windows of the sweep (for n = 3 ... 24:
 // one-word 250 bp 1500 ... 250-325, 360 bp 1800-2000 ... 250-325; two-word 250 bp 1500 ... 250-325, 360 bp 1800 ... 400;
-// 500 / 1000 bp 1000 ... 450; two-word blocks with 2 MiB slices have one flat optimum, 325 / 450, for every n).
+// 500 / 1000 bp 1000 ... 450; two-word blocks with 2 MiB slices have one optimum, 325 / 400, for every n).
 static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices)
 {
     double base, cycle;
@@ -987,7 +989,7 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
     } else {
         switch (shape) {
         case 1: base = lg == 0 ? 0.0 : 325.0; cycle = lg == 0 ? 3600.0 : 0.0; break;
-        case 3: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 4400.0 : 0.0; break;
+        case 3: base = lg == 0 ? 0.0 : 400.0; cycle = lg == 0 ? 4400.0 : 0.0; break;
         default: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 2400.0 : 0.0; break;
         }
     }
