@@ -319,3 +319,40 @@ def test_phased_form_over_its_whole_range_agrees_with_the_plain_kernel(bins, mib
         assert np.array_equal(phased[0][:n, 0], po.batch_raw_max(view, buf, offs[:n], lens[:n], 8)), read_len
     eng.destroy()
     d.free()
+
+
+def test_large_filters_of_one_geometry_merge_and_agree():
+    """Two filters too large for their members to be served faster one by one (70 MiB one-word + 140 MiB two-word, one noOfBlocks):
+    the cost model merges them (profiles/r03/merged_tables.txt: 1.9-2.0 x measured on such pairs); merged, apart and the oracle
+    (sample) give the same maxima and decisions on 10^5 reads of 250 and 360 bp."""
+    n_blocks = int(70 * (1 << 20) / 8) - 11
+    ref, starts, ends = synth.planted_reference(321, 256, 2000)
+    filters = []
+    for i, bins in enumerate((64, 100)):
+        W = (bins + 63) // 64
+        d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks)
+        d.fill_synth(40 + i)
+        d.insert(ref, starts, ends, (np.arange(256, dtype=np.uint64) * np.uint64(5 + i)) % np.uint64(bins))
+        filters.append(d)
+    eng = capi.Engine(0, filters[:1], filters[1:])
+    assert eng.merge_info()[:2] == (1, 2)
+    views, keep = [], []
+    for d in filters:
+        h = d.download()
+        keep.append(h)
+        views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+    for read_len in (250, 360):
+        buf, offs, lens = synth.make_reads(700 + read_len, 100_000, read_len, ref)
+        eng.set_merge(1)
+        merged = eng.classify(buf, offs, lens)
+        eng.set_merge(0)
+        apart = eng.classify(buf, offs, lens)
+        for a, b in zip(merged, apart):
+            assert np.array_equal(a, b), read_len
+        assert len(set(merged[2].tolist())) >= 2 and merged[0].max() > 100
+        n = 1200
+        exp_dec, exp_st = po.batch_check_unblock(views[:1], views[1:], buf, offs[:n], lens[:n], n_threads=8)
+        assert np.array_equal(merged[2][:n], exp_dec) and np.array_equal(merged[3][:n], exp_st)
+    eng.destroy()
+    for d in filters:
+        d.free()
