@@ -1072,7 +1072,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
                                                : phase_window_ticks(shape, a.lg, slice_log2, n_sl);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
-            ticks = std::max<uint64_t>(1, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock
+            ticks = std::max<uint64_t>(2, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock (>= 2: 2^32 / ticks must fit 32 bits)
             a.phase.shift = sh;
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
