@@ -965,10 +965,20 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 //  - blocks of four and eight words gain nothing from phases at any size (every pass over the slices issues four / eight
 //    times the load instructions per lookup of the one-word kernel: 8 MiB table 12.4 against 12.1 ms plain, 32 MiB 26.7 against
 //    21.6) and keep the plain kernel.
-static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes)
+// The rules below were fitted with reads that fill their kernel shape (238 k-mers in four tiles, 348 in six, 488 in two rounds of
+// four); a wave with fewer k-mers is through its round sooner, and the best cycle shrinks with it (session 38: 150 bp reads,
+// one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp; 32 MiB: 400 against 700).  Factor on the cycle, 0.5 ... 1.
+static double phase_fill(int shape, uint32_t kmers)
+{
+    const double fit = shape == 1 ? 238.0 : shape == 3 ? 348.0 : shape == 2 ? 488.0 : 0.0;
+    if (fit == 0.0) return 1.0;  // per-strand tiles of the general build: the work of a round does not depend on the read length
+    return std::min(1.0, std::max(0.5, (double)kmers / fit));
+}
+
+static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32_t kmers)
 {
     const double mib = (double)table_bytes / 1048576.0;
-    const double two_mib_below = lg == 0 ? 10.0 : (shape == 1 || shape == 3) ? 18.5 : 10.0;
+    const double two_mib_below = (lg == 0 ? 10.0 : (shape == 1 || shape == 3) ? 18.5 : 10.0) * phase_fill(shape, kmers);
     return mib < two_mib_below ? 21 : 22;
 }
 
@@ -976,7 +986,7 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes)
 // four tiles (<= 512), 0 = the general build.  base + cycle / n, fitted to the best windows of the sweep (for n = 3 ... 24:
 // one-word 250 bp 1500 ... 250-325, 360 bp 1800-2000 ... 250-325; two-word 250 bp 1500 ... 250-325, 360 bp 1800 ... 400;
 // 500 / 1000 bp 1000 ... 450; two-word blocks with 2 MiB slices have one optimum, 325 / 400, for every n).
-static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices)
+static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
 {
     double base, cycle;
     if (slice_log2 >= 22) {
@@ -993,14 +1003,18 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
         default: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 2400.0 : 0.0; break;
         }
     }
-    return (uint64_t)(base + cycle / std::max(n_slices, 1u));
+    const double t = (base + cycle / std::max(n_slices, 1u)) * phase_fill(shape, kmers);
+    // two-word blocks: below 325 / 400 ticks the times get erratic (64 MiB, 300 bp: 26.0 ms at 352 ticks, 21.5 at 400)
+    const double lo = lg == 0 ? 0.0 : shape == 1 ? 325.0 : shape == 3 ? 400.0 : 0.0;
+    return (uint64_t)std::max(t, lo);
 }
 
 // Up to which table size the phased form beats the plain kernel (which sits at the fabric-request wall from about 64 MiB on),
 // profiles/r03/slice_size.txt: one-word blocks and short reads 127 MiB (22.1 against 25.2 ms at 250 bp, 32.5 against 36.7 at
 // 360 bp); two-word blocks 96 MiB at 250 bp (20.2 / 24.8; even at 127 MiB), 64 MiB at 360 bp (22.2 / 35.1; at 96 MiB the
 // optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
-// 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).
+// 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).  Scaled by phase_fill() like the cycle:
+// with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain).
 static uint64_t phase_shape_max_bytes(int shape, int lg)
 {
     if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
@@ -1061,16 +1075,17 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
             n_reads >= e->phase_min_reads && stride_pow2 &&
-            (e->phase_explicit || (table_bytes <= phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg) &&
+            (e->phase_explicit || ((double)table_bytes <= (double)phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg) *
+                                                            phase_fill(a.planes <= 10 ? a.short_only : 0, kmers) &&
                                    n_reads >= phase_min_reads_for(table_bytes)))) {
             const int shape = a.planes <= 10 ? a.short_only : 0;
-            const uint32_t slice_log2 = e->phase_slice_log2 ? e->phase_slice_log2 : phase_slice_log2(shape, a.lg, table_bytes);
+            const uint32_t slice_log2 = e->phase_slice_log2 ? e->phase_slice_log2 : phase_slice_log2(shape, a.lg, table_bytes, kmers);
             uint32_t sh = 0;
             while (slice_log2 >= 6 && (f->stride * 8) << (sh + 1) <= (1ull << slice_log2)) ++sh;  // (< 6: as small as max_slices allows)
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > e->phase_max_slices) ++sh;
             const uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
-                                               : phase_window_ticks(shape, a.lg, slice_log2, n_sl);
+                                               : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             ticks = std::max<uint64_t>(2, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock (>= 2: 2^32 / ticks must fit 32 bits)
             a.phase.shift = sh;
