@@ -40,7 +40,7 @@ for L in LENS:
             row = []
             for ticks in ((0,) if lg2 <= 0 else TICKS):
                 if ticks:
-                    eng.set_phased(6 << 20, 1 << 30, ticks, 0)
+                    eng.set_phased(1 << 20, 1 << 30, ticks, 0)
                 for it in range(4):
                     if it == 1:
                         eng.kernel_time()
@@ -52,6 +52,6 @@ for L in LENS:
                     ref = mc.clone()
                 assert torch.equal(ref, mc)
             eng.destroy()
-            label = "rule" if lg2 == 0 else "plain kernel" if lg2 == -1 else "slices of %d MiB" % (1 << (lg2 - 20))
+            label = "rule" if lg2 == 0 else "plain kernel" if lg2 == -1 else ("slices of %d MiB" % (1 << (lg2 - 20)) if lg2 >= 20 else "slices of %d KiB" % (1 << (lg2 - 10)))
             print("%4d bp %d-word %6.1f MiB %-15s: %s" % (L, W, mb, label, " ".join("%6.2f" % x for x in row)), flush=True)
         d.free()

@@ -438,7 +438,7 @@ class Engine:
     def set_serial_table_bytes(self, table_bytes):
         _check(lib().rb_engine_set_serial_table_bytes(self.h, table_bytes), "rb_engine_set_serial_table_bytes")
 
-    def set_phased(self, min_table_bytes=6 << 20, max_table_bytes=128 << 20, base_ticks=0, ticks_per_mib=0, min_reads=2049):
+    def set_phased(self, min_table_bytes=5 << 18, max_table_bytes=128 << 20, base_ticks=0, ticks_per_mib=0, min_reads=2049):
         _check(lib().rb_engine_set_phased(self.h, min_table_bytes, max_table_bytes, base_ticks, ticks_per_mib, min_reads),
                "rb_engine_set_phased")
 

@@ -126,7 +126,7 @@ struct rb_engine {
     uint64_t nt_threshold_bytes = 512ull << 20;  // 2x the 256 MiB Infinity Cache: beyond it caching cannot help
     uint64_t serial_table_bytes = 128ull << 20;  // filters up to this size never run beside another filter (L2 share)
     // clock-phased gathers (rb_kernels.hip): tables between these sizes, batches of at least phase_min_reads reads
-    uint64_t phase_min_bytes = 6ull << 20, phase_max_bytes = 128ull << 20;
+    uint64_t phase_min_bytes = 5ull << 18, phase_max_bytes = 128ull << 20;
     // window length in 10 ns ticks.  phase_explicit: base + per MiB of table, as given to rb_engine_set_phased; otherwise the
     // built-in rule of phase_window_ticks() below (measured per kernel shape, profiles/r03/window_sweep.txt).
     uint32_t phase_base_ticks = 450, phase_ticks_per_mib = 0;
@@ -978,6 +978,11 @@ static double phase_fill(int shape, uint32_t kmers)
 static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32_t kmers)
 {
     const double mib = (double)table_bytes / 1048576.0;
+    // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
+    // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
+    // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
+    if ((shape == 1 || shape == 3) && mib < (lg == 0 ? 3.5 : 2.5)) return 19;
+    if ((shape == 1 || shape == 3) && mib < 7.0) return 20;
     const double two_mib_below = (lg == 0 ? 10.0 : (shape == 1 || shape == 3) ? 18.5 : 10.0) * phase_fill(shape, kmers);
     return mib < two_mib_below ? 21 : 22;
 }
@@ -989,6 +994,8 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
 static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
 {
     double base, cycle;
+    if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 130-250 (512 KiB slices) and 250-325 ticks (1 MiB)
+        return slice_log2 <= 19 ? (shape == 1 ? 200 : 250) : (shape == 1 ? 250 : 325);
     if (slice_log2 >= 22) {
         switch (shape) {
         case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 4000.0 : 3700.0; break;
@@ -1015,6 +1022,16 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 // optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
 // 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).  Scaled by phase_fill() like the cycle:
 // with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain).
+// ... and from which size on: the short-read shapes from 1.25 MiB (three slices of 512 KiB) when the reads fill the shape -- with
+// 150 bp reads in the four-tile shape a table of 3-7 MiB is served faster without phases (3 MiB: 4.6 against 3.9 ms), from 8 MiB
+// on with them (5.4 against 7.0) --, the general build from 6 MiB (500 bp reads: 2 MiB 11.6 -> 11.4 ms, 4 MiB no gain, 6 MiB
+// 17.7 -> 16.1)
+static uint64_t phase_shape_min_bytes(int shape, double fill)
+{
+    if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : (15ull << 19);
+    return 6ull << 20;
+}
+
 static uint64_t phase_shape_max_bytes(int shape, int lg)
 {
     if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
@@ -1073,12 +1090,12 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 1 on a wider
         // filter, e.g. 3072 bins over 24 ranks -- stride 48 -- and keeps the plain kernel)
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
+        const int shape = a.planes <= 10 ? a.short_only : 0;
+        const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, phase_fill(shape, kmers)) &&
+                                   (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * phase_fill(shape, kmers) &&
+                                   n_reads >= phase_min_reads_for(table_bytes);
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
-            n_reads >= e->phase_min_reads && stride_pow2 &&
-            (e->phase_explicit || ((double)table_bytes <= (double)phase_shape_max_bytes(a.planes <= 10 ? a.short_only : 0, a.lg) *
-                                                            phase_fill(a.planes <= 10 ? a.short_only : 0, kmers) &&
-                                   n_reads >= phase_min_reads_for(table_bytes)))) {
-            const int shape = a.planes <= 10 ? a.short_only : 0;
+            n_reads >= e->phase_min_reads && stride_pow2 && (e->phase_explicit || in_rule_range)) {
             const uint32_t slice_log2 = e->phase_slice_log2 ? e->phase_slice_log2 : phase_slice_log2(shape, a.lg, table_bytes, kmers);
             uint32_t sh = 0;
             while (slice_log2 >= 6 && (f->stride * 8) << (sh + 1) <= (1ull << slice_log2)) ++sh;  // (< 6: as small as max_slices allows)
