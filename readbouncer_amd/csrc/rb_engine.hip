@@ -1109,9 +1109,9 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
             a.phase.xcd_skew = e->phase_xcd_skew;
-        } else if (a.lg == 0 && e->short_read_kernel) {
-            // one-word blocks outside the phased range still take that kernel for its both-strands-in-one-tile path for
-            // reads of up to 256 k-mers: one "slice" that holds every offset, no clock, no waiting
+        } else if ((a.lg == 0 || (shape != 0 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2)) && e->short_read_kernel) {
+            // blocks outside the phased range still take that kernel for its both-strands-in-one-round path (one-word blocks
+            // always; two-word blocks for reads of up to 512 k-mers): one "slice" that holds every offset, no clock, no waiting
             a.phase.shift = 31;
             a.phase.n_slices = 1;
             a.phase.inv_ticks = 0;
