@@ -360,7 +360,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         decisions = t_dec.cpu().numpy()
 
         # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- and two-word blocks with a
-        # table of 1.25 (reads of up to 384 k-mers that fill their kernel shape) or 6 MiB up to 48-128 MiB by kernel shape (or one-word blocks of any size: the no-clock form of that kernel) take
+        # table of 1.25 (reads of up to 384 k-mers that fill their kernel shape) or 6 MiB up to 48-128 MiB by kernel shape (or one-word blocks of any size and two-word blocks with reads of up to 512 k-mers: the no-clock form of that kernel) take
         # the phased kernel, everything else the plain one; merged tables as the engine reports them
         kmers = max(0, read_len - int(filters[0].info["kmer_size"]) + 1)
         short = kmers <= 384
@@ -368,7 +368,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         def phased(f):
             W, tb = f.info["bin_width"], f.info["n_blocks"] * f.device_stride() * 8
             cap = ((128 if W == 1 else 96 if kmers <= 256 else 64) if short else (64 if W == 1 else 48)) << 20
-            return W <= 2 and f.info["n_hash"] == 3 and (((5 << 18) if short else (6 << 20)) <= tb <= cap or W == 1)
+            return W <= 2 and f.info["n_hash"] == 3 and (((5 << 18) if short else (6 << 20)) <= tb <= cap or W == 1 or kmers <= 512)
         n_merged = eng.merge_info()[1] if not bin_sharded else 0
         forms = set()
         if n_merged:
