@@ -395,14 +395,14 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
  * L2 costs a 128-byte request.  Two measures, both leave the results untouched:
  *  - filters of at most `table_bytes` (default 128 MiB) never run beside another filter of the same call, so each has the
  *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
- *  - for one- and two-word tables of [min_table_bytes, max_table_bytes] (default 1.25-128 MiB) and batches of at least min_reads
+ *  - for tables of one- to four-word blocks of [min_table_bytes, max_table_bytes] (default 1.25-128 MiB; three and four words: 4.5-48) and batches of at least min_reads
  *    (2049: everything above the latency kernel's micro-batches) the throughput kernel gathers in clock-phased slices: the
  *    table is cut into slices of 0.5 to 4 MiB (at most 32) and the 100 MHz wall clock tells every wave which slice to gather
  *    from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns -- both 0 = the built-in rule, a whole cycle
  *    over the table of 33-60 us by kernel shape -- so an XCD's L2 holds one slice at a time
  *    (rb_engine_set_phased; max_table_bytes = 0 switches it off; all five arguments 0 also takes one-word filters back to
- *    the plain kernel, whose 512-k-mer tiles are half empty on 250 bp reads).  Wider blocks gain nothing from phases and
- *    keep the plain kernel. */
+ *    the plain kernel, whose 512-k-mer tiles are half empty on 250 bp reads).  Blocks of five and more words gain nothing
+ *    from phases and keep the plain kernel. */
 RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
                                 uint32_t ticks_per_mib, uint32_t min_reads);

@@ -970,7 +970,7 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 // one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp; 32 MiB: 400 against 700).  Factor on the cycle, 0.5 ... 1.
 static double phase_fill(int shape, uint32_t kmers)
 {
-    const double fit = shape == 1 ? 238.0 : shape == 3 ? 348.0 : shape == 2 ? 488.0 : 0.0;
+    const double fit = (shape == 1 || shape == 5) ? 238.0 : shape == 3 ? 348.0 : shape == 2 ? 488.0 : 0.0;
     if (fit == 0.0) return 1.0;  // per-strand tiles of the general build: the work of a round does not depend on the read length
     return std::min(1.0, std::max(0.5, (double)kmers / fit));
 }
@@ -978,6 +978,8 @@ static double phase_fill(int shape, uint32_t kmers)
 static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32_t kmers)
 {
     const double mib = (double)table_bytes / 1048576.0;
+    if (shape == 5) return mib <= 12.0 ? 21 : 22;  // three- and four-word blocks (sessions 44-46, slice_size.txt)
+    if (shape == 4) return 22;
     // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
     // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
     // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
@@ -994,6 +996,10 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
 static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
 {
     double base, cycle;
+    // three- and four-word blocks: one optimum per slice size (<= 256 k-mers: 400 ticks with 2 MiB slices, 500 with 4 MiB; rounds
+    // of two tiles: 325, 200 from eight slices on)
+    if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
+    if (shape == 4) return n_slices <= 7 ? 325 : 200;
     if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 130-250 (512 KiB slices) and 250-325 ticks (1 MiB)
         return slice_log2 <= 19 ? (shape == 1 ? 200 : 250) : (shape == 1 ? 250 : 325);
     if (slice_log2 >= 22) {
@@ -1029,11 +1035,16 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 static uint64_t phase_shape_min_bytes(int shape, double fill)
 {
     if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : (15ull << 19);
+    // three- and four-word blocks: <= 256 k-mers from 4.5 MiB on (smaller tables take the same round without a clock); rounds of two
+    // tiles from 12 MiB on (below, the plain kernel is as fast or faster: 8 MiB 17.6 against 17.7 ms, 4 MiB 12.8 against 11.1)
+    if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
+    if (shape == 4) return 12ull << 20;
     return 6ull << 20;
 }
 
 static uint64_t phase_shape_max_bytes(int shape, int lg)
 {
+    if (shape == 4 || shape == 5) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 29.4 against 33.2 (360 bp); 64 MiB: even
     if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
     if (shape == 3) return (lg == 0 ? 128ull : 64ull) << 20;
     return (lg == 0 ? 64ull : 48ull) << 20;
@@ -1085,12 +1096,16 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     // less time than two rounds of four tiles on one-word 10 MB filters, 15 % on a one-word 20 MB table, 22 % on two-word blocks)
     if (a.short_only == 2 && kmers <= 384 && e->six_tile_kernel) a.short_only = 3;
     const uint64_t table_bytes = f->geo.n_blocks * f->stride * 8;
-    if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && a.lg <= 1 && a.n_slices == 1 && table_bytes < (1ull << 31)) {
+    // three- and four-word blocks: only the both-strands build of the phased kernel (reads of up to 512 k-mers, whole blocks)
+    const bool wide_short = a.lg == 2 && a.planes <= 10 && kmers <= 512 && a.col_begin == 0 && (a.col_end == 3 || a.col_end == 4) &&
+                            f->stride == 4 && W == a.col_end;
+    if (a.split_waves < 2 && f->geo.n_hash == 3 && a.wpl == 1 && (a.lg <= 1 || wide_short) && a.n_slices == 1 && table_bytes < (1ull << 31)) {
+        if (wide_short) a.short_only = (kmers <= 256 && e->six_tile_kernel != 2) ? 5 : 4;  // (RB_SIX_TILES=2: experiments without the four-tile build)
         // the phased kernels take a lookup's slice from its byte offset by a shift: block strides that are a power of two
         // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 1 on a wider
         // filter, e.g. 3072 bins over 24 ranks -- stride 48 -- and keeps the plain kernel)
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
-        const int shape = a.planes <= 10 ? a.short_only : 0;
+        const int shape = a.planes <= 10 ? a.short_only : 0;  // (4: three- and four-word blocks, rounds of two tiles per strand)
         const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, phase_fill(shape, kmers)) &&
                                    (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * phase_fill(shape, kmers) &&
                                    n_reads >= phase_min_reads_for(table_bytes);
@@ -1109,9 +1124,11 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
             a.phase.xcd_skew = e->phase_xcd_skew;
-        } else if ((a.lg == 0 || (shape != 0 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2)) && e->short_read_kernel) {
+        } else if ((a.lg == 0 || (shape != 0 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
+                    (shape == 5 && phase_fill(shape, kmers) >= 0.8 && table_bytes < (9ull << 19))) && e->short_read_kernel) {
             // blocks outside the phased range still take that kernel for its both-strands-in-one-round path (one-word blocks
-            // always; two-word blocks for reads of up to 512 k-mers): one "slice" that holds every offset, no clock, no waiting
+            // always; two-word blocks for reads of up to 512 k-mers; small three- and four-word tables for reads of up to 256:
+            // 2 MiB 7.2 -> 6.6 ms, 4 MiB 7.7 -> 6.9): one "slice" that holds every offset, no clock, no waiting
             a.phase.shift = 31;
             a.phase.n_slices = 1;
             a.phase.inv_ticks = 0;
@@ -1277,6 +1294,8 @@ static double est_filter_ms(const rb_engine *e, const rb_dibf *f)
     const double mib = (double)bytes / 1048576.0;
     const bool phased = f->geo.n_hash == 3 && f->geo.bin_width <= 2 && e->phase_max_bytes && bytes >= e->phase_min_bytes &&
                         bytes <= std::min<uint64_t>(e->phase_max_bytes, phase_shape_max_bytes(1, f->geo.bin_width == 1 ? 0 : 1));
+    // three- and four-word blocks (stride 4) in the both-strands build, 4.5-48 MiB: 8 MiB 9.4, 16 MiB 11.4, 24 MiB 12.7, 40 MiB 17.2
+    if (f->geo.n_hash == 3 && f->stride == 4 && e->phase_max_bytes && bytes >= (9ull << 19) && bytes <= (48ull << 20)) return 8.0 + 0.23 * mib;
     if (!phased) return est_plain_ms(mib);
     return f->geo.bin_width == 1 ? 6.6 + 0.125 * mib : 7.0 + 0.15 * mib;
 }

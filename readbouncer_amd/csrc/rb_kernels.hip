@@ -175,6 +175,8 @@ template <int T>
 __device__ __forceinline__ uint32_t wave_bin_counts(const uint64_t *x, int lane)
 {
     if constexpr (T == 6) return wave_bin_counts6(x[0], x[1], x[2], x[3], x[4], x[5], lane);
+    else if constexpr (T == 2)  // sums 0..2: two planes, two transposes
+        return (uint32_t)__popcll(wave_transpose64(x[0] ^ x[1], lane)) + 2u * (uint32_t)__popcll(wave_transpose64(x[0] & x[1], lane));
     else return wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
 }
 
@@ -429,6 +431,54 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
                     const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
                     x0[part * KB + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
                     x1[part * KB + uu] &= (((uint64_t)(ld[uu][h].w | out)) << 32) | (ld[uu][h].z | out);
+                }
+            }
+        }
+    }
+}
+
+// The same for three- and four-word blocks (stride 4 words) held by ONE lane: two 16-byte gathers per lookup.
+template <int N, int H, int KB>
+__device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x1)[N], uint64_t (&x2)[N], uint64_t (&x3)[N],
+                                                 const uint32_t (&bn)[N][H], const uint64_t *words, uint32_t slice_shift,
+                                                 const PhaseCfg ph)
+{
+    static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
+    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
+    uint32_t done = 0;
+#pragma unroll 1
+    while (done != all) {
+        const uint32_t cur = phase_next_slice(done, ph);
+        done |= 1u << cur;
+        const uint32_t start = cur << slice_shift;
+        const uint32_t span = 1u << slice_shift;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
+#pragma unroll
+        for (int part = 0; part < N / KB; ++part) {
+            rb_u32x4 lo[KB][H], hi[KB][H];
+#pragma unroll
+            for (int uu = 0; uu < KB; ++uu) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    uint32_t off = bn[part * KB + uu][h];
+                    asm volatile("" : "+v"(off));
+                    lo[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
+                    hi[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (off - start) | 16u, 0, 0);  // (blocks are 32-byte aligned and never straddle a slice; "no lookup" stays out of range)
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int uu = 0; uu < KB; ++uu) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    uint32_t off = bn[part * KB + uu][h];
+                    asm volatile("" : "+v"(off));
+                    const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
+                    x0[part * KB + uu] &= (((uint64_t)(lo[uu][h].y | out)) << 32) | (lo[uu][h].x | out);
+                    x1[part * KB + uu] &= (((uint64_t)(lo[uu][h].w | out)) << 32) | (lo[uu][h].z | out);
+                    x2[part * KB + uu] &= (((uint64_t)(hi[uu][h].y | out)) << 32) | (hi[uu][h].x | out);
+                    x3[part * KB + uu] &= (((uint64_t)(hi[uu][h].w | out)) << 32) | (hi[uu][h].z | out);
                 }
             }
         }
@@ -874,6 +924,73 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             cr += wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
             }
             uint32_t m = max(max(cf & 0xFFFFu, cf >> 16), max(cr & 0xFFFFu, cr >> 16));  // at most 512 each: no carry between halves
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const uint32_t o = shfl32(m, lane ^ sft);
+                m = o > m ? o : m;
+            }
+            if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)m;
+            return;
+        }
+    }
+    if constexpr (LG == 2 && (SHORT == 2 || SHORT == 1)) {
+        // Three- and four-word blocks (129-256 bins, stride 4 words), reads of up to 512 k-mers: ONE lane per block with two
+        // 16-byte gathers, both strands in rounds of two 64-k-mer tiles each (a lane's AND accumulators are 4 words x 4 k-mers =
+        // 32 registers; four tiles per strand would take 64 and leave three waves per SIMD)
+        // SHORT 1: one round of four tiles per strand (<= 256 k-mers; 116 registers, four waves per SIMD); otherwise rounds of two
+        // tiles (four tiles with the loop state take 163 registers, three waves: measured slower at 360 bp)
+        constexpr int T2 = SHORT == 1 ? 4 : 2;
+        if (n <= (SHORT == 1 ? 256u : 512u) && col_begin == 0 && (col_end == 3 || col_end == 4) && f.stride == 4) {
+            uint8_t *stage = s_stage[wave];
+            for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t k = f.k;
+            const uint32_t rem = f.n_bins & 63u;
+            const uint64_t last = rem ? ((1ULL << rem) - 1) : ~0ULL;
+            const uint64_t valid2 = col_end == 3 ? last : ~0ULL;  // word columns 0 and 1 are always whole
+            const uint64_t valid3 = col_end == 3 ? 0ULL : last;
+            const uint32_t slice_shift = min(31u, ph.shift + 5u);
+            uint32_t c01f = 0, c23f = 0, c01r = 0, c23r = 0;  // lane b: counts of bins b | 64 + b << 16, and 128 + b | 192 + b << 16
+#pragma unroll 1
+            for (uint32_t base = 0; base < (SHORT == 1 ? 1u : n); base += 64u * T2) {
+                uint32_t bn[2 * T2][3];
+                uint64_t x0[2 * T2], x1[2 * T2], x2[2 * T2], x3[2 * T2];
+#pragma unroll
+                for (int j = 0; j < 2 * T2; ++j) {
+                    const uint32_t p = base + (uint32_t)((j % T2) * 64 + lane);
+                    const bool ok = p < n;
+                    uint64_t v = 0;
+                    if (ok) {
+                        const uint8_t *b = stage + p;
+                        if (j < T2) {
+                            for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
+                        } else {
+                            for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
+                        bn[j][h] = ok ? blk * 32u : 0xFFFFFFFFu;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 2 * T2; ++j) {
+                    const bool ok = bn[j][0] != 0xFFFFFFFFu;
+                    x0[j] = ok ? ~0ULL : 0ULL;
+                    x1[j] = ok ? ~0ULL : 0ULL;
+                    x2[j] = ok ? valid2 : 0ULL;
+                    x3[j] = ok ? valid3 : 0ULL;
+                }
+                phased_gather_x4<2 * T2, 3, 1>(x0, x1, x2, x3, bn, f.words, slice_shift, ph);
+                c01f += wave_bin_counts<T2>(x0, lane) | (wave_bin_counts<T2>(x1, lane) << 16);
+                c23f += wave_bin_counts<T2>(x2, lane) | (wave_bin_counts<T2>(x3, lane) << 16);
+                c01r += wave_bin_counts<T2>(x0 + T2, lane) | (wave_bin_counts<T2>(x1 + T2, lane) << 16);
+                c23r += wave_bin_counts<T2>(x2 + T2, lane) | (wave_bin_counts<T2>(x3 + T2, lane) << 16);
+            }
+            uint32_t m = max(max(max(c01f & 0xFFFFu, c01f >> 16), max(c23f & 0xFFFFu, c23f >> 16)),
+                             max(max(c01r & 0xFFFFu, c01r >> 16), max(c23r & 0xFFFFu, c23r >> 16)));  // at most 512 each: no carry
 #pragma unroll
             for (int sft = 1; sft < 64; sft <<= 1) {
                 const uint32_t o = shfl32(m, lane ^ sft);
@@ -1549,7 +1666,23 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
 template <int NP>
 static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
 {
-    // blocks of one and two words only: wider blocks gain nothing from phases (rb_engine.hip, phase_slice_log2)
+    // blocks of one and two words; three- and four-word blocks (stride 4) only in the both-strands build for reads of up to
+    // 512 k-mers (short_only 4); wider blocks gain nothing from phases (rb_engine.hip, phase_slice_log2)
+    if (a.lg == 2) {
+        if constexpr (NP == 10) {
+            if ((a.short_only == 4 || a.short_only == 5) && a.col_begin == 0 && (a.col_end == 3 || a.col_end == 4) && a.f.stride == 4) {
+                dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+                if (a.short_only == 5)  // every read of the batch has at most 256 k-mers: one round of four tiles per strand
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                else
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                return hipGetLastError();
+            }
+        }
+        return hipErrorInvalidValue;
+    }
     return a.lg == 0 ? launch_phased<0, NP>(a, st) : launch_phased<1, NP>(a, st);
 }
 
@@ -1557,7 +1690,7 @@ hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st)
 {
     if (a.n_reads == 0) return hipSuccess;
     if (a.phase.n_slices && a.split_waves < 2) {  // planned by the engine for: 3 hash functions, one slice, lg <= 1, wpl 1, n_fused 0
-        if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 1 || a.n_slices != 1 || a.n_fused > 0 || a.phase.n_slices > 32) return hipErrorInvalidValue;
+        if (a.f.n_hash != 3 || a.wpl != 1 || a.lg > 2 || a.n_slices != 1 || a.n_fused > 0 || a.phase.n_slices > 32) return hipErrorInvalidValue;
         // slice of a lookup = byte offset >> (shift + 3 + log2 stride): more than one slice needs a power-of-two block stride
         if (a.phase.n_slices > 1 && (a.f.stride & (a.f.stride - 1)) != 0) return hipErrorInvalidValue;
         return a.planes <= 10 ? dispatch_phased<10>(a, st) : dispatch_phased<16>(a, st);
