@@ -368,7 +368,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         def phased(f):
             W, tb = f.info["bin_width"], f.info["n_blocks"] * f.device_stride() * 8
             if W in (3, 4) and f.info["n_hash"] == 3:  # both-strands build for stride-4 blocks
-                return (kmers <= 256 and tb <= (48 << 20)) or (kmers <= 512 and (12 << 20) <= tb <= (48 << 20))
+                return (kmers <= 256 and tb <= (48 << 20)) or (kmers <= 512 and (6 << 20) <= tb <= (48 << 20))
             cap = ((128 if W == 1 else 96 if kmers <= 256 else 64) if short else (64 if W == 1 else 48)) << 20
             return W <= 2 and f.info["n_hash"] == 3 and (((5 << 18) if short else (6 << 20)) <= tb <= cap or W == 1 or kmers <= 512)
         n_merged = eng.merge_info()[1] if not bin_sharded else 0

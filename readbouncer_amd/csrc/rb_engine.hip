@@ -970,7 +970,7 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 // one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp; 32 MiB: 400 against 700).  Factor on the cycle, 0.5 ... 1.
 static double phase_fill(int shape, uint32_t kmers)
 {
-    const double fit = (shape == 1 || shape == 5) ? 238.0 : shape == 3 ? 348.0 : shape == 2 ? 488.0 : 0.0;
+    const double fit = (shape == 1 || shape == 5) ? 238.0 : (shape == 3 || shape == 4) ? 348.0 : shape == 2 ? 488.0 : 0.0;
     if (fit == 0.0) return 1.0;  // per-strand tiles of the general build: the work of a round does not depend on the read length
     return std::min(1.0, std::max(0.5, (double)kmers / fit));
 }
@@ -979,7 +979,7 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
 {
     const double mib = (double)table_bytes / 1048576.0;
     if (shape == 5) return mib <= 12.0 ? 21 : 22;  // three- and four-word blocks (sessions 44-46, slice_size.txt)
-    if (shape == 4) return 22;
+    if (shape == 4) return mib <= 13.0 ? 21 : 22;
     // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
     // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
     // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
@@ -996,10 +996,10 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
 static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
 {
     double base, cycle;
-    // three- and four-word blocks: one optimum per slice size (<= 256 k-mers: 400 ticks with 2 MiB slices, 500 with 4 MiB; rounds
-    // of two tiles: 325, 200 from eight slices on)
+    // three- and four-word blocks: <= 256 k-mers: 400 ticks with 2 MiB slices, 500 with 4 MiB; rounds of three tiles: 325 with
+    // 2 MiB slices, 2400 / n but at least 325 with 4 MiB slices (16 MiB: 600, 24 MiB: 400, 40 MiB: 325)
     if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
-    if (shape == 4) return n_slices <= 7 ? 325 : 200;
+    if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(325, 2400 / std::max(n_slices, 1u));
     if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 130-250 (512 KiB slices) and 250-325 ticks (1 MiB)
         return slice_log2 <= 19 ? (shape == 1 ? 200 : 250) : (shape == 1 ? 250 : 325);
     if (slice_log2 >= 22) {
@@ -1035,16 +1035,16 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 static uint64_t phase_shape_min_bytes(int shape, double fill)
 {
     if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : (15ull << 19);
-    // three- and four-word blocks: <= 256 k-mers from 4.5 MiB on (smaller tables take the same round without a clock); rounds of two
-    // tiles from 12 MiB on (below, the plain kernel is as fast or faster: 8 MiB 17.6 against 17.7 ms, 4 MiB 12.8 against 11.1)
+    // three- and four-word blocks: <= 256 k-mers from 4.5 MiB on (smaller tables take the same round without a clock); rounds of
+    // three tiles from 6 MiB on (4 MiB: 10.8 against 11.1 ms at 360 bp, 16.5 against 14.6 at 500 bp)
     if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
-    if (shape == 4) return 12ull << 20;
+    if (shape == 4) return 6ull << 20;
     return 6ull << 20;
 }
 
 static uint64_t phase_shape_max_bytes(int shape, int lg)
 {
-    if (shape == 4 || shape == 5) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 29.4 against 33.2 (360 bp); 64 MiB: even
+    if (shape == 4 || shape == 5) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 25.4 against 33.6 (360 bp); 64 MiB: even
     if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
     if (shape == 3) return (lg == 0 ? 128ull : 64ull) << 20;
     return (lg == 0 ? 64ull : 48ull) << 20;

@@ -177,6 +177,11 @@ __device__ __forceinline__ uint32_t wave_bin_counts(const uint64_t *x, int lane)
     if constexpr (T == 6) return wave_bin_counts6(x[0], x[1], x[2], x[3], x[4], x[5], lane);
     else if constexpr (T == 2)  // sums 0..2: two planes, two transposes
         return (uint32_t)__popcll(wave_transpose64(x[0] ^ x[1], lane)) + 2u * (uint32_t)__popcll(wave_transpose64(x[0] & x[1], lane));
+    else if constexpr (T == 3) {  // sums 0..3: one carry-save step, two planes
+        uint64_t h, l;
+        RB_CSA(h, l, x[0], x[1], x[2]);
+        return (uint32_t)__popcll(wave_transpose64(l, lane)) + 2u * (uint32_t)__popcll(wave_transpose64(h, lane));
+    }
     else return wave_bin_counts4(x[0], x[1], x[2], x[3], lane);
 }
 
@@ -310,6 +315,9 @@ struct BaseSrc {
 #endif
 #ifndef RB_GATHER_KB3
 #define RB_GATHER_KB3 2
+#endif
+#ifndef RB_WIDE_TILES  // tiles per strand and round of the three- / four-word build for reads of 257-512 k-mers
+#define RB_WIDE_TILES 3
 #endif
 #ifndef RB_GATHER_BG  // per-strand tiles of the general build (reads of more than 512 k-mers, blocks of 3-8 words)
 #define RB_GATHER_BG 2
@@ -937,9 +945,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // Three- and four-word blocks (129-256 bins, stride 4 words), reads of up to 512 k-mers: ONE lane per block with two
         // 16-byte gathers, both strands in rounds of two 64-k-mer tiles each (a lane's AND accumulators are 4 words x 4 k-mers =
         // 32 registers; four tiles per strand would take 64 and leave three waves per SIMD)
-        // SHORT 1: one round of four tiles per strand (<= 256 k-mers; 116 registers, four waves per SIMD); otherwise rounds of two
-        // tiles (four tiles with the loop state take 163 registers, three waves: measured slower at 360 bp)
-        constexpr int T2 = SHORT == 1 ? 4 : 2;
+        // SHORT 1: one round of four tiles per strand (<= 256 k-mers; 116 registers, four waves per SIMD); otherwise rounds of three
+        // tiles (113 registers, four waves; 360 bp reads take two rounds, 91 % dense -- rounds of two tiles: three rounds, 11-17 %
+        // instead of 30-50 % over the plain kernel; four tiles with the loop state: 163 registers, three waves, slower still)
+        constexpr int T2 = SHORT == 1 ? 4 : RB_WIDE_TILES;
         if (n <= (SHORT == 1 ? 256u : 512u) && col_begin == 0 && (col_end == 3 || col_end == 4) && f.stride == 4) {
             uint8_t *stage = s_stage[wave];
             for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
