@@ -70,6 +70,17 @@ struct MergeMap {
     uint32_t out_offset[kMaxMerged];  // element offset of filter g's column in a row of the output
 };
 
+// Merged tables of at most four word columns (two to four narrow filters of one hash geometry, rb_engine.hip) are served by the
+// both-strands builds of the phased kernel, which hold a whole block in one lane: which member a column belongs to, how many
+// of its 64 bits are bins (0: the column does not exist), and where each member's maximum goes in a row of the output.  A filter
+// on its own is the case n = 1.
+struct NarrowMerge {
+    uint32_t n;              // members (1..4)
+    uint32_t col_member[4];  // word column -> member
+    uint32_t col_bits[4];    // word column -> bins in it (64: all; 0: no such column)
+    uint32_t out_offset[4];  // member -> element offset in a row of the output
+};
+
 struct CountLaunch {
     IbfDev f;
     ReadSrc src;
@@ -79,6 +90,7 @@ struct CountLaunch {
     int lg, wpl, planes;
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
     PhaseCfg phase;               // throughput form on narrow filters: clock-phased gathers (n_slices == 0: off)
+    NarrowMerge narrow;           // phased form on two- to four-word blocks: columns -> members (the engine fills it; n = 1: one filter)
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)

@@ -997,9 +997,10 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 {
     double base, cycle;
     // three- and four-word blocks: <= 256 k-mers: 400 ticks with 2 MiB slices, 500 with 4 MiB; rounds of three tiles: 325 with
-    // 2 MiB slices, 2400 / n but at least 325 with 4 MiB slices (16 MiB: 600, 24 MiB: 400, 40 MiB: 325)
+    // 2 MiB slices, 2400 / n but at least 400 with 4 MiB slices (16 MiB: 600, 24 MiB: 400; 28-32 MiB: 20.6 / 22.4 ms at 400 ticks between
+    // 27.5 / 29.7 at 325 and 23.4 / 25.5 at 500 -- session 50)
     if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
-    if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(325, 2400 / std::max(n_slices, 1u));
+    if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(400, 2400 / std::max(n_slices, 1u));
     if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 130-250 (512 KiB slices) and 250-325 ticks (1 MiB)
         return slice_log2 <= 19 ? (shape == 1 ? 200 : 250) : (shape == 1 ? 250 : 325);
     if (slice_log2 >= 22) {
@@ -1134,6 +1135,11 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.inv_ticks = 0;
         }
     }
+    // columns -> members for the one-lane-per-block builds of the phased kernel: a filter on its own is one member
+    a.narrow = NarrowMerge{};
+    a.narrow.n = 1;
+    for (uint32_t c = 0; c < 4; ++c)
+        a.narrow.col_bits[c] = c >= W ? 0u : (c + 1 == W && (f->geo.n_bins & 63)) ? (uint32_t)(f->geo.n_bins & 63) : 64u;
     a.split_parts = 1;
     a.split_sub = 1;
     if (a.split_waves >= 2)
@@ -1330,7 +1336,12 @@ static void plan_merged(rb_engine *e)
         if (members.size() < 2) continue;
         double apart = 0.0;
         for (uint32_t m : members) apart += est_filter_ms(e, e->filters[m]);
-        const double together = est_plain_ms((double)(gi.n_blocks * hbm_stride(width) * 8) / 1048576.0) + 0.3 * (double)members.size();
+        // (a merged table of two to four words is served by the phased kernel like a filter of that width)
+        const double merged_mib = (double)(gi.n_blocks * hbm_stride(width) * 8) / 1048576.0;
+        const bool narrow_phased = e->phase_max_bytes && ((width == 2 && merged_mib >= 1.25 && merged_mib <= 96.0) ||
+                                                          ((width == 3 || width == 4) && merged_mib <= 48.0));
+        const double together = (narrow_phased ? (width == 2 ? 7.0 + 0.15 * merged_mib : 8.0 + 0.23 * merged_mib) : est_plain_ms(merged_mib)) +
+                                0.3 * (double)members.size();
         if (e->merge_mode == 1 && apart <= 1.05 * together) continue;
         if ((gi.n_blocks * hbm_stride(width) + 8) * 8 > e->merge_max_bytes) continue;
         MergedGroup *g = new (std::nothrow) MergedGroup();
@@ -1462,6 +1473,45 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
             }
             if (rc != RB_OK) return rc;
             CountLaunch a{};
+            a.src.seqs = (const uint8_t *)d_seqs;
+            a.src.offsets = (const uint64_t *)d_offsets;
+            a.src.lens = (const uint32_t *)d_lens;
+            a.src.nmask = (const uint8_t *)desc->d_nmask;
+            a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
+            a.src.ids = (const uint32_t *)desc->d_read_ids;
+            a.src.base_off = desc->chunk_start;
+            a.n_reads = (uint32_t)n_reads;
+            if (g->width <= 4) {
+                // a merged block of two to four words is held by ONE lane of the both-strands builds of the phased kernel: the
+                // merged table is planned like a filter of that width (slices, windows), the kernel writes one maximum per member
+                rb_dibf as_filter;
+                as_filter.device = e->device;
+                as_filter.geo = e->filters[g->members[0]]->geo;
+                as_filter.geo.bin_width = g->width;
+                as_filter.geo.n_bins = g->width * 64;
+                as_filter.stride = g->stride;
+                CountLaunch p = a;
+                const bool planned = plan_geometry(e, &as_filter, n_reads, max_len, p);
+                const bool one_lane = (p.lg == 1 && p.short_only >= 1 && p.short_only <= 3) || (p.lg == 2 && (p.short_only == 4 || p.short_only == 5));
+                if (planned && p.phase.n_slices && p.split_waves < 2 && p.planes <= 10 && one_lane) {
+                    p.f = g->dev;
+                    p.f.comp_n = e->revcomp_of_n;
+                    p.narrow = NarrowMerge{};
+                    p.narrow.n = g->map.n;
+                    for (uint32_t c = 0; c < 4; ++c) {
+                        uint32_t m = 0;
+                        while (m < g->map.n && c >= g->map.col_end[m]) ++m;
+                        p.narrow.col_member[c] = m < g->map.n ? m : 0xFFFFFFFFu;
+                        p.narrow.col_bits[c] = m >= g->map.n ? 0u : (c + 1 == g->map.col_end[m] && g->map.rem[m]) ? g->map.rem[m] : 64u;
+                    }
+                    for (uint32_t m = 0; m < g->map.n; ++m) p.narrow.out_offset[m] = g->map.out_offset[m];
+                    p.out = maxcount;
+                    p.out_read_stride = (uint32_t)nf;
+                    p.out_slice_stride = 0;
+                    RB_HIP(launch_ibf_count_max(p, st));
+                    continue;
+                }
+            }
             a.f = g->dev;
             a.f.comp_n = e->revcomp_of_n;
             a.src.seqs = (const uint8_t *)d_seqs;

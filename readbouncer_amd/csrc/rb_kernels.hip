@@ -799,10 +799,31 @@ __global__ void merge_columns_kernel(const uint64_t *__restrict__ src, uint32_t 
 //            of windows; 6 tiles are 91 % dense and the per-bin sums of six words still fit three bit planes;
 //   SHORT 2  <= 512 k-mers: two rounds of 4 tiles (the general build, SHORT 0, takes this path too and falls back to
 //            the per-strand tiles of count_strand for longer reads).
+// bins of a word column as a mask (NarrowMerge::col_bits)
+__device__ __forceinline__ uint64_t col_bits_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : ((1ULL << bits) - 1); }
+
+// The end of the one-lane-per-block rounds: lane b holds, per word column c, the larger of the two strands' counts of bin 64 c + b;
+// every member of the (possibly merged) table gets the maximum over its columns and the wave.
+template <int NC>
+__device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC], const NarrowMerge &nm, int lane, uint16_t *out)
+{
+    for (uint32_t g = 0; g < nm.n; ++g) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) m = (nm.col_member[c] == g && colmax[c] > m) ? colmax[c] : m;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const uint32_t o = shfl32(m, lane ^ sft);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) out[nm.out_offset[g]] = (uint16_t)m;
+    }
+}
+
 template <int LG, int NP, int SHORT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
-    uint32_t out_read_stride)
+    uint32_t out_read_stride, NarrowMerge nm)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
     if (ph.xcd_skew) ph.skew = xcc_id();
@@ -888,8 +909,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
-            const uint32_t rem = f.n_bins & 63u;
-            const uint64_t valid1 = rem ? ((1ULL << rem) - 1) : ~0ULL;
+            const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
             const uint32_t slice_shift = min(31u, ph.shift + 4u);
             uint32_t cf = 0, cr = 0;  // lane b: counts of bins b (low half) and 64 + b (high half), forward / reverse complement
 #pragma unroll 1
@@ -922,7 +942,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int j = 0; j < 2 * T; ++j) {
                 const bool ok = bn[j][0] != 0xFFFFFFFFu;
-                x0[j] = ok ? ~0ULL : 0ULL;
+                x0[j] = ok ? valid0 : 0ULL;
                 x1[j] = ok ? valid1 : 0ULL;
             }
             // (the builds with loop state or six tiles send two k-mers' gathers at a time: with four the state does not fit
@@ -931,13 +951,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             cf += wave_bin_counts<T>(x0, lane) | (wave_bin_counts<T>(x1, lane) << 16);
             cr += wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
             }
-            uint32_t m = max(max(cf & 0xFFFFu, cf >> 16), max(cr & 0xFFFFu, cr >> 16));  // at most 512 each: no carry between halves
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) {
-                const uint32_t o = shfl32(m, lane ^ sft);
-                m = o > m ? o : m;
-            }
-            if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)m;
+            const uint32_t colmax[2] = {max(cf & 0xFFFFu, cr & 0xFFFFu), max(cf >> 16, cr >> 16)};  // at most 512 each: no carry between halves
+            write_member_maxima<2>(colmax, nm, lane, out + (size_t)read * out_read_stride);
             return;
         }
     }
@@ -955,10 +970,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
-            const uint32_t rem = f.n_bins & 63u;
-            const uint64_t last = rem ? ((1ULL << rem) - 1) : ~0ULL;
-            const uint64_t valid2 = col_end == 3 ? last : ~0ULL;  // word columns 0 and 1 are always whole
-            const uint64_t valid3 = col_end == 3 ? 0ULL : last;
+            const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
+            const uint64_t valid2 = col_bits_mask(nm.col_bits[2]), valid3 = col_bits_mask(nm.col_bits[3]);
             const uint32_t slice_shift = min(31u, ph.shift + 5u);
             uint32_t c01f = 0, c23f = 0, c01r = 0, c23r = 0;  // lane b: counts of bins b | 64 + b << 16, and 128 + b | 192 + b << 16
 #pragma unroll 1
@@ -987,8 +1000,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #pragma unroll
                 for (int j = 0; j < 2 * T2; ++j) {
                     const bool ok = bn[j][0] != 0xFFFFFFFFu;
-                    x0[j] = ok ? ~0ULL : 0ULL;
-                    x1[j] = ok ? ~0ULL : 0ULL;
+                    x0[j] = ok ? valid0 : 0ULL;
+                    x1[j] = ok ? valid1 : 0ULL;
                     x2[j] = ok ? valid2 : 0ULL;
                     x3[j] = ok ? valid3 : 0ULL;
                 }
@@ -998,14 +1011,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                 c01r += wave_bin_counts<T2>(x0 + T2, lane) | (wave_bin_counts<T2>(x1 + T2, lane) << 16);
                 c23r += wave_bin_counts<T2>(x2 + T2, lane) | (wave_bin_counts<T2>(x3 + T2, lane) << 16);
             }
-            uint32_t m = max(max(max(c01f & 0xFFFFu, c01f >> 16), max(c23f & 0xFFFFu, c23f >> 16)),
-                             max(max(c01r & 0xFFFFu, c01r >> 16), max(c23r & 0xFFFFu, c23r >> 16)));  // at most 512 each: no carry
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) {
-                const uint32_t o = shfl32(m, lane ^ sft);
-                m = o > m ? o : m;
-            }
-            if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)m;
+            const uint32_t colmax[4] = {max(c01f & 0xFFFFu, c01r & 0xFFFFu), max(c01f >> 16, c01r >> 16),
+                                        max(c23f & 0xFFFFu, c23r & 0xFFFFu), max(c23f >> 16, c23r >> 16)};  // at most 512 each: no carry
+            write_member_maxima<4>(colmax, nm, lane, out + (size_t)read * out_read_stride);
             return;
         }
     }
@@ -1021,7 +1029,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     }
     // SHORT: a read with more k-mers than promised (256 / 384 / 512) writes 0 here; the decision kernel turns a length above the
     // declared max_len into RB_ERR_INVALID_ARG, so the value is never used
-    if (lane == 0) out[(size_t)read * out_read_stride] = (uint16_t)best;
+    if (lane == 0) {
+        out[(size_t)read * out_read_stride + nm.out_offset[0]] = (uint16_t)best;
+        for (uint32_t g = 1; g < nm.n; ++g) out[(size_t)read * out_read_stride + nm.out_offset[g]] = 0;  // (merged tables: SHORT builds only)
+    }
 }
 
 // latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
@@ -1649,26 +1660,26 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
     if constexpr (LG <= 1 && NP == 10) {
         if (a.short_only == 1 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
             hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 1>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
             return hipGetLastError();
         }
     }
     if constexpr (LG <= 1 && NP == 10) {
         if (a.short_only == 2 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
             hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
             return hipGetLastError();
         }
     }
     if constexpr (LG <= 1 && NP == 10) {
         if (a.short_only == 3 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
             hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 3>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                               a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((ibf_count_max_phased_kernel<LG, NP, 0>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
     return hipGetLastError();
 }
 
@@ -1683,10 +1694,10 @@ static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
                 dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
                 if (a.short_only == 5)  // every read of the batch has at most 256 k-mers: one round of four tiles per strand
                     hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
                 else
                     hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
-                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride);
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
                 return hipGetLastError();
             }
         }

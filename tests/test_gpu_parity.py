@@ -1000,7 +1000,8 @@ def test_pool_runs_micro_batches_of_several_threads_concurrently():
     pool.destroy()
 
 
-@pytest.mark.parametrize("widths", [(122, 43, 29, 49), (64, 64, 64, 64, 10), (130, 200), (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64)])
+@pytest.mark.parametrize("widths", [(122, 43, 29, 49), (64, 64, 64, 64, 10), (130, 200), (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64),
+                                    (60, 50), (60, 50, 40), (100, 60, 30), (64, 64, 64, 64), (129, 3)])
 def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
     """Filters built with one fragment_size have the same noOfBlocks whatever their bin count (IBFBuild.cpp:404-413), so a k-mer
     hashes to the same block in all of them: the engine merges their blocks into one table and serves every member with ONE
@@ -1041,7 +1042,8 @@ def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
     # what merges: at most 16 words per merged block, so the twelve filters make a table of ten and a pair; tables as small as
     # these (L2-resident on their own and merged) always pay, so mode 1 merges what mode 2 does
     expect = {(122, 43, 29, 49): (1, 4), (64, 64, 64, 64, 10): (1, 5), (130, 200): (1, 2),
-              (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64): (2, 12)}[widths]
+              (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64): (2, 12),
+              (60, 50): (1, 2), (60, 50, 40): (1, 3), (100, 60, 30): (1, 3), (64, 64, 64, 64): (1, 4), (129, 3): (1, 2)}[widths]
     for mode in (0, 1, 2):
         eng.set_merge(mode)
         assert eng.merge_info()[:2] == ((0, 0) if mode == 0 else expect), (mode, eng.merge_info())
@@ -1051,6 +1053,24 @@ def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
         results[mode] = (mc, best, dec, st)
     assert np.array_equal(results[0][1], results[2][1])
     assert len(set(exp_dec.tolist())) >= 2 and exp_max.max() > 1023
+    # batches of short reads only: merged blocks of two to four words are then held by ONE lane of the both-strands builds of the
+    # phased kernel (<= 256 and <= 512 k-mers), with and without clock phases (the table cut into as many as 8 slices)
+    for hi in (250, 420):
+        sreads = make_reads(rng, ref, 2300, lo=5, hi=hi, err=0.1, n_frac=0.2) + ["", "ACGT", "N" * hi, ref[100:100 + hi]]
+        sbuf, soffs, slens = H.pack_reads(sreads)
+        sexp = np.stack([po.batch_raw_max(v, sbuf, soffs, slens, 8) for v in views], axis=1)
+        sdec, sst = po.batch_check_unblock(views[:nd], views[nd:], sbuf, soffs, slens, n_threads=8)
+        for mode, forced in ((2, False), (2, True), (0, True)):
+            eng.set_merge(mode)
+            if forced:
+                eng.set_phased(0, 1 << 40, 150, 0, 1)
+                eng.set_phase_slices(1, 8)
+            got = eng.classify(sbuf, soffs, slens)
+            eng.set_phased()
+            eng.set_phase_slices()
+            assert np.array_equal(got[0], sexp), (hi, mode, forced)
+            assert np.array_equal(got[2], sdec) and np.array_equal(got[3], sst), (hi, mode, forced)
+    eng.set_merge(2)
     # micro-batch of the same engine (latency kernels, no merged table) still agrees
     sub = eng.classify(buf, offs[:300], lens[:300])
     assert np.array_equal(sub[0], exp_max[:300])
@@ -1118,8 +1138,9 @@ def test_a_merged_copy_beyond_the_cap_is_not_made(monkeypatch):
 
 @pytest.mark.parametrize("shape,merged", [
     ([(122, 20.0), (43, 10.4), (29, 10.4), (49, 10.4)], True),   # the reference's README shape: 33.6 against 25.5 ms estimated
-    ([(40, 10.4), (50, 10.4), (60, 10.4)], False),              # three one-word filters of 10 MiB: the phased kernels are as fast
-    ([(64, 12.0), (64, 12.0)], False),                         # measured 0.88 x
+    ([(40, 10.4), (50, 10.4), (60, 10.4)], True),               # three one-word filters of 10 MiB: one three-word table, one lane per block (1.2 x)
+    ([(64, 12.0), (64, 12.0)], True),                          # one two-word table through the two-word phased kernel (1.4 x)
+    ([(128, 32.0), (128, 32.0)], False),                       # two two-word filters of 32 MiB: the merged table is beyond the one-lane builds (0.93 x)
     ([(64, 24.0), (64, 24.0), (64, 24.0)], True),               # measured 1.24 x
     ([(64, 160.0), (128, 320.0)], True),                        # beyond the phased range each sits at the request wall: 2 x
     ([(64, 1.0), (64, 1.0)], True),                             # the merged copy still fits an L2: 1.65 x
