@@ -358,9 +358,10 @@ RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
  * three hash functions a k-mer then hashes to the same block number in all of them.  For such filters (blocks of at most 8
  * words, at most 16 words together) the engine keeps a merged copy in which their blocks sit side by side, and one gather per
  * (k-mer, hash function) serves all of them -- the narrow filters are bound by requests, not bytes.  mode 1 (default): when it
- * pays -- the members one after the other are estimated to take longer than one pass over the merged table: the reference's README
+ * pays -- the members one after the other are estimated to take longer than one pass over the merged table (a merged table of
+ * two to four words is served by the clock-phased kernel like a filter of that width, wider ones by plain gathers): the reference's README
  * shape (a two-word deplete filter and three one-word targets), any two filters too large for the clock-phased kernels, small
- * ones whose merged copy still fits an L2; not two or three filters of 10-30 MiB, which the phased kernels serve as fast --;
+ * ones whose merged copy still fits an L2, two or three one-word filters of up to 30 MiB --;
  * 2: whenever two or more filters qualify; 0: never.  Large
  * batches only (micro-batches keep the latency kernels); the copy follows changes of its members (rb_dibf_insert ...).
  * Results are identical. */
