@@ -233,6 +233,14 @@ def workload_spec(ctx, name):
         return (["mock_deplete"], ["mock_t1", "mock_t2", "mock_t3"],
                 "README benchmark shape: 250bp prefixes vs 1 deplete (122 bins) + 3 target (43/29/49 bins) IBFs, k=13, F=100000, "
                 "check_unblock", 1_000_000, 250)
+    if name == "targets3":
+        # target-only adaptive sampling with three bacterial targets: three one-word filters of one hash geometry, which the engine
+        # serves from ONE three-word table through the one-lane-per-block build of the phased kernel
+        return ([], ["mock_t1", "mock_t2", "mock_t3"],
+                "three target IBFs (43/29/49 bins, 10.4 MB each), k=13, F=100000, 250bp prefixes, target-only check_unblock", 1_000_000, 250)
+    if name == "deplete_target":
+        return (["mock_t3"], ["mock_t1"], "one deplete (49 bins) + one target (43 bins) IBF, k=13, F=100000, 250bp prefixes, check_unblock",
+                1_000_000, 250)
     w = synth.WORKLOADS[name]
     return [name], [], w["name"], w["reads"], w["read_len"]
 
@@ -374,7 +382,9 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         n_merged = eng.merge_info()[1] if not bin_sharded else 0
         forms = set()
         if n_merged:
-            forms.add("ibf_count_max_merged_kernel")
+            # a merged table of two to four words is held by one lane of the both-strands builds of the phased kernel
+            narrow = n_merged == len(filters) and sum(f.info["bin_width"] for f in filters) <= 4 and kmers <= 512
+            forms.add("ibf_count_max_phased_kernel" if narrow else "ibf_count_max_merged_kernel")
         if n_merged < len(filters):  # (which filters a partial merge leaves out is the engine's business: name both forms then)
             forms |= {"ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel" for f in filters}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -16,6 +16,9 @@ run c1 60 --workload c1
 run c1_250 40 --workload c1 --read-len 250
 run w1_64mib_250 40 --workload w1_64mib
 run w1_64mib_360 40 --workload w1_64mib --read-len 360
+run targets3_250 40 --workload targets3
+run targets3_360 40 --workload targets3 --read-len 360
+run deplete_target_250 40 --workload deplete_target
 run c2 60 --workload c2
 run c4 90 --workload c4
 run c3 90 --workload c3 --reads 2000000
