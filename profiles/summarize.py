@@ -20,13 +20,18 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 if os.path.exists(os.path.join(src, "hbm_peak.txt")):
     shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
-for w in ("c2", "c3", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain"):
+for w in ("c2", "c3", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
     hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
 
 
-def counter_means(path):
+# workloads whose step launches ONE kernel name several times and no other count kernel (the step count cannot be read off the
+# dispatch counts then): dispatches per step
+SAME_KERNEL_PER_STEP = {"targets3_apart": 3, "deplete_target_apart": 2}
+
+
+def counter_means(path, per_step=1):
     """{counter: (dispatches, value per step, kernel ms per step)} of the count kernels (every form of K1).  A step launches
     one count kernel per filter -- different template instantiations, or the same one several times (the three one-word
     targets of the README shape): the per-step figure is the sum over all dispatches divided by the number of steps, and
@@ -44,7 +49,7 @@ def counter_means(path):
             per_kernel[k] = per_kernel.get(k, 0) + 1
     out = {}
     for name, (n, v, ms) in tot.items():
-        steps = min(c for (cn, _k), c in per_kernel.items() if cn == name)
+        steps = min(c for (cn, _k), c in per_kernel.items() if cn == name) // per_step
         out[name] = (n, v / steps, ms / steps)
     return out
 
@@ -55,11 +60,14 @@ rows, traffic = [], {}
 MOCK = ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]
 FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
            "readme": MOCK, "c1_r01": ["c1"], "readme_r01": MOCK, "readme_skew": MOCK, "readme360": MOCK, "readme360_six0": MOCK,
-           "readme_phased": MOCK, "readme360_phased": MOCK, "w1_64mib": ["w1_64mib"], "w1_64mib_plain": ["w1_64mib"]}
-READ_LEN = {"readme": 250, "readme_r01": 250, "readme_skew": 250, "readme_phased": 250, "w1_64mib": 250, "w1_64mib_plain": 250}
+           "readme_phased": MOCK, "readme360_phased": MOCK, "w1_64mib": ["w1_64mib"], "w1_64mib_plain": ["w1_64mib"],
+           "targets3": ["mock_t1", "mock_t2", "mock_t3"], "targets3_apart": ["mock_t1", "mock_t2", "mock_t3"],
+           "deplete_target": ["mock_t3", "mock_t1"], "deplete_target_apart": ["mock_t3", "mock_t1"]}
+READ_LEN = {"readme": 250, "readme_r01": 250, "readme_skew": 250, "readme_phased": 250, "w1_64mib": 250, "w1_64mib_plain": 250,
+            "targets3": 250, "targets3_apart": 250, "deplete_target": 250, "deplete_target_apart": 250}
 when = os.environ.get("RB_EVIDENCE_DATE", "")
 for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0", "readme_phased", "readme360_phased",
-          "w1_64mib", "w1_64mib_plain"):
+          "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):
         continue
@@ -68,7 +76,7 @@ for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r0
         hits = glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)
         if not hits:
             continue
-        for name, (n, v, ms) in counter_means(hits[0]).items():
+        for name, (n, v, ms) in counter_means(hits[0], SAME_KERNEL_PER_STEP.get(w, 1)).items():
             rows.append((w, p, name, n, v, ms))
             m[name] = v
     if "FETCH_SIZE" not in m:
