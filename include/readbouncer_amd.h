@@ -359,12 +359,11 @@ RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
  * words, at most 16 words together) the engine keeps a merged copy in which their blocks sit side by side, and one gather per
  * (k-mer, hash function) serves all of them -- the narrow filters are bound by requests, not bytes.  mode 1 (default): when it
  * pays -- the members one after the other are estimated to take longer than one pass over the merged table (a merged table of
- * two to four words is served by the clock-phased kernel like a filter of that width, wider ones by plain gathers): the reference's README
- * shape (a two-word deplete filter and three one-word targets), any two filters too large for the clock-phased kernels, small
- * ones whose merged copy still fits an L2, two or three one-word filters of up to 30 MiB --;
- * 2: whenever two or more filters qualify; 0: never.  Large
- * batches only (micro-batches keep the latency kernels); the copy follows changes of its members (rb_dibf_insert ...).
- * Results are identical. */
+ * two to four words is served by the clock-phased kernel like a filter of that width, wider ones by plain gathers): the
+ * reference's README shape (a two-word deplete filter and three one-word targets), any two filters too large for the
+ * clock-phased kernels, small ones whose merged copy still fits an L2, two or three one-word filters of up to 30 MiB --;
+ * 2: whenever two or more filters qualify; 0: never.  Large batches only (micro-batches keep the latency kernels); the copy
+ * follows changes of its members (rb_dibf_insert ...).  Results are identical. */
 RB_API int rb_engine_set_merge(rb_engine *e, int mode);
 /* What the engine has merged (or will, at its next large batch): the number of merged tables, the filters they serve and the HBM
  * bytes of the copies, which the engine owns beside the members.  A copy larger than 16 GiB (RB_MERGE_MAX_BYTES) is not made,
@@ -396,8 +395,9 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
  * L2 costs a 128-byte request.  Two measures, both leave the results untouched:
  *  - filters of at most `table_bytes` (default 128 MiB) never run beside another filter of the same call, so each has the
  *    L2 to itself (rb_engine_set_serial_table_bytes; 0 = overlap everything as rb_engine_set_overlap says);
- *  - for tables of one- to four-word blocks of [min_table_bytes, max_table_bytes] (default 1.25-128 MiB; three and four words: 4.5-48) and batches of at least min_reads
- *    (2049: everything above the latency kernel's micro-batches) the throughput kernel gathers in clock-phased slices: the
+ *  - for tables of one- to four-word blocks of [min_table_bytes, max_table_bytes] (default 1.25-128 MiB; three and four words:
+ *    4.5-48 MiB) and batches of at least min_reads (2049: everything above the latency kernel's micro-batches; more for tables
+ *    beyond 32 MiB) the throughput kernel gathers in clock-phased slices: the
  *    table is cut into slices of 0.5 to 4 MiB (at most 32) and the 100 MHz wall clock tells every wave which slice to gather
  *    from, in windows of base_ticks + ticks_per_mib * table MiB ticks of 10 ns -- both 0 = the built-in rule, a whole cycle
  *    over the table of 33-60 us by kernel shape -- so an XCD's L2 holds one slice at a time
@@ -407,7 +407,7 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
                                 uint32_t ticks_per_mib, uint32_t min_reads);
-/* How the phased form cuts a table, for tests and experiments: slices of 2^slice_log2 bytes (0 = the built-in rule, 2 or 4 MiB
+/* How the phased form cuts a table, for tests and experiments: slices of 2^slice_log2 bytes (0 = the built-in rule, 0.5 to 4 MiB
  * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and
  * never more than max_slices (1-32, default 32; a table that would need more gets larger slices).  Results are identical. */
 RB_API int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_slices);
