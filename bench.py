@@ -8,8 +8,9 @@ Headline workload (N = 1 and N > 1 alike) = BASELINE.json configs[2], the config
 on: 10 M reads x 360 bp against the GRCh38-scale depletion IBF (8192 bins, 8 GiB) -- ONE launch of 10 M reads per step and
 GPU.  The same line carries `other_configs`: configs[1] (c2, whose 0.41 GB table is partly Infinity-Cache resident),
 configs[3] (c4: deplete + target, full check_unblock; full steps, CPU baseline, parity), configs[4] (c5: the 48-flowcell
-replay with its latency percentiles, plus a leg through the live step with concatenated undecided chunks) and the shape of
-the reference's README benchmark -- run in this process (and, for N > 1, by all ranks), after the headline measurement.
+replay with its latency percentiles, plus a leg through the live step with concatenated undecided chunks), the shape of
+the reference's README benchmark (at 250 and at 360 bp) and two narrower shapes of the same filters (three targets alone; one
+deplete + one target) -- run in this process (and, for N > 1, by all ranks), after the headline measurement.
 
 With N > 1 every rank (one process per GPU) holds a replica of the IBF and its own shard of reads (weak scaling, no
 data-path collective); time = max over ranks, value = all reads / that time.  `python bench.py --gpus N` starts the N ranks
@@ -755,7 +756,7 @@ def null_engine_run(args, torch, dist, world, rank, backend):
     head = leg(args.workload or "c3", args.steps, args.bin_sharded)
     others = {}
     if not args.workload and not args.bin_sharded and not args.no_extras:
-        for name in ("c2", "c4", "c5", "readme"):
+        for name in ("c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"):
             others[name] = leg(name, 1, False)
     infos = [{"rank": rank, "device": None}]
     if dist is not None:
@@ -839,7 +840,10 @@ def main():
                 ("c2", lambda: run_throughput(ctx, "c2", cpu_seconds=5.0)),
                 ("readme", lambda: run_throughput(ctx, "readme", cpu_seconds=5.0)),
                 # the README filters at the north star's read length
-                ("readme_360bp", lambda: run_throughput(ctx, "readme", read_len=360, steps=min(args.steps, 5), warmup=1, cpu_seconds=0))]
+                ("readme_360bp", lambda: run_throughput(ctx, "readme", read_len=360, steps=min(args.steps, 5), warmup=1, cpu_seconds=0)),
+                # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
+                ("targets3", lambda: run_throughput(ctx, "targets3", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0)),
+                ("deplete_target", lambda: run_throughput(ctx, "deplete_target", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0))]
         for lname, fn in legs:
             try:
                 r = fn()

@@ -54,7 +54,7 @@ def test_gpus2_default_line_structure_cpu():
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
                 "roofline", "cpu_baseline", "parity", "ranks", "other_configs"):
         assert key in d, key
-    assert set(d["other_configs"]) == {"c2", "c4", "c5", "readme"}
+    assert set(d["other_configs"]) == {"c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"}
     for sub in d["other_configs"].values():
         assert sub["n_gpus"] == 2 and sub["value"] > 0
     r = d["ranks"]
@@ -149,7 +149,8 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
     assert d1["cpu_baseline"]["value"] > 0 and d2["cpu_baseline"] is None  # timed at N = 1 only
     for d in (d1, d2):
         assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
-        assert set(d["other_configs"]) >= {"c2", "c4", "c5", "readme"}
+        assert set(d["other_configs"]) >= {"c2", "c4", "c5", "readme", "targets3", "deplete_target"}
+        assert d["other_configs"]["targets3"]["parity"]["decision_mismatches"] == 0
         assert d["other_configs"]["c4"]["parity"]["decision_mismatches"] == 0
         assert d["other_configs"]["c5"]["latency"]["slo_met"] is True
         assert d["other_configs"]["c5"]["parity"]["replayed_decisions_equal_one_batch"] is True
