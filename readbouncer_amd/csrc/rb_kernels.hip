@@ -316,6 +316,10 @@ struct BaseSrc {
 #ifndef RB_GATHER_KB3
 #define RB_GATHER_KB3 2
 #endif
+#ifndef RB_WIDE_WAVES  // waves per SIMD the four-tile build for THREE-word blocks is compiled for (94 registers, no scratch; the
+                       // four-word build would spill 104 bytes at five waves and stays at four: 116 registers)
+#define RB_WIDE_WAVES 5
+#endif
 #ifndef RB_WIDE_TILES  // tiles per strand and round of the three- / four-word build for reads of 257-512 k-mers
 #define RB_WIDE_TILES 3
 #endif
@@ -446,7 +450,7 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
 }
 
 // The same for three- and four-word blocks (stride 4 words) held by ONE lane: two 16-byte gathers per lookup.
-template <int N, int H, int KB>
+template <int N, int H, int KB, int NW = 4>
 __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x1)[N], uint64_t (&x2)[N], uint64_t (&x3)[N],
                                                  const uint32_t (&bn)[N][H], const uint64_t *words, uint32_t slice_shift,
                                                  const PhaseCfg ph)
@@ -465,6 +469,7 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
 #pragma unroll
         for (int part = 0; part < N / KB; ++part) {
             rb_u32x4 lo[KB][H], hi[KB][H];
+            rb_u32x2 hi2[KB][H];  // NW == 3: the third word alone (8 bytes)
 #pragma unroll
             for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
@@ -472,7 +477,9 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
                     uint32_t off = bn[part * KB + uu][h];
                     asm volatile("" : "+v"(off));
                     lo[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
-                    hi[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (off - start) | 16u, 0, 0);  // (blocks are 32-byte aligned and never straddle a slice; "no lookup" stays out of range)
+                    // (blocks are 32-byte aligned and never straddle a slice; "no lookup" stays out of range)
+                    if constexpr (NW == 3) hi2[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, (off - start) | 16u, 0, 0);
+                    else hi[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (off - start) | 16u, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -485,8 +492,12 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
                     const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
                     x0[part * KB + uu] &= (((uint64_t)(lo[uu][h].y | out)) << 32) | (lo[uu][h].x | out);
                     x1[part * KB + uu] &= (((uint64_t)(lo[uu][h].w | out)) << 32) | (lo[uu][h].z | out);
-                    x2[part * KB + uu] &= (((uint64_t)(hi[uu][h].y | out)) << 32) | (hi[uu][h].x | out);
-                    x3[part * KB + uu] &= (((uint64_t)(hi[uu][h].w | out)) << 32) | (hi[uu][h].z | out);
+                    if constexpr (NW == 3) {
+                        x2[part * KB + uu] &= (((uint64_t)(hi2[uu][h].y | out)) << 32) | (hi2[uu][h].x | out);
+                    } else {
+                        x2[part * KB + uu] &= (((uint64_t)(hi[uu][h].y | out)) << 32) | (hi[uu][h].x | out);
+                        x3[part * KB + uu] &= (((uint64_t)(hi[uu][h].w | out)) << 32) | (hi[uu][h].z | out);
+                    }
                 }
             }
         }
@@ -820,8 +831,8 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
     }
 }
 
-template <int LG, int NP, int SHORT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : 3, SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
+template <int LG, int NP, int SHORT, int NW = 4>  // NW: words per block the one-lane build for stride-4 blocks holds (3: no fourth column)
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : (LG == 2 && SHORT == 1) ? (NW == 3 ? RB_WIDE_WAVES : 4) : 3, SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride, NarrowMerge nm)
 {
@@ -964,7 +975,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         // tiles (113 registers, four waves; 360 bp reads take two rounds, 91 % dense -- rounds of two tiles: three rounds, 11-17 %
         // instead of 30-50 % over the plain kernel; four tiles with the loop state: 163 registers, three waves, slower still)
         constexpr int T2 = SHORT == 1 ? 4 : RB_WIDE_TILES;
-        if (n <= (SHORT == 1 ? 256u : 512u) && col_begin == 0 && (col_end == 3 || col_end == 4) && f.stride == 4) {
+        if (n <= (SHORT == 1 ? 256u : 512u) && col_begin == 0 && (col_end == (uint32_t)NW || (NW == 4 && col_end == 3)) && f.stride == 4) {
             uint8_t *stage = s_stage[wave];
             for (uint32_t i = lane; i < len; i += 64) stage[i] = (uint8_t)seq.ord(i);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1003,13 +1014,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     x0[j] = ok ? valid0 : 0ULL;
                     x1[j] = ok ? valid1 : 0ULL;
                     x2[j] = ok ? valid2 : 0ULL;
-                    x3[j] = ok ? valid3 : 0ULL;
+                    x3[j] = (ok && NW == 4) ? valid3 : 0ULL;
                 }
-                phased_gather_x4<2 * T2, 3, 1>(x0, x1, x2, x3, bn, f.words, slice_shift, ph);
+                phased_gather_x4<2 * T2, 3, 1, NW>(x0, x1, x2, x3, bn, f.words, slice_shift, ph);
                 c01f += wave_bin_counts<T2>(x0, lane) | (wave_bin_counts<T2>(x1, lane) << 16);
-                c23f += wave_bin_counts<T2>(x2, lane) | (wave_bin_counts<T2>(x3, lane) << 16);
                 c01r += wave_bin_counts<T2>(x0 + T2, lane) | (wave_bin_counts<T2>(x1 + T2, lane) << 16);
-                c23r += wave_bin_counts<T2>(x2 + T2, lane) | (wave_bin_counts<T2>(x3 + T2, lane) << 16);
+                if constexpr (NW == 4) {
+                    c23f += wave_bin_counts<T2>(x2, lane) | (wave_bin_counts<T2>(x3, lane) << 16);
+                    c23r += wave_bin_counts<T2>(x2 + T2, lane) | (wave_bin_counts<T2>(x3 + T2, lane) << 16);
+                } else {
+                    c23f += wave_bin_counts<T2>(x2, lane);
+                    c23r += wave_bin_counts<T2>(x2 + T2, lane);
+                }
             }
             const uint32_t colmax[4] = {max(c01f & 0xFFFFu, c01r & 0xFFFFu), max(c01f >> 16, c01r >> 16),
                                         max(c23f & 0xFFFFu, c23r & 0xFFFFu), max(c23f >> 16, c23r >> 16)};  // at most 512 each: no carry
@@ -1692,11 +1708,16 @@ static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
         if constexpr (NP == 10) {
             if ((a.short_only == 4 || a.short_only == 5) && a.col_begin == 0 && (a.col_end == 3 || a.col_end == 4) && a.f.stride == 4) {
                 dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
-                if (a.short_only == 5)  // every read of the batch has at most 256 k-mers: one round of four tiles per strand
-                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                // short_only 5: every read of the batch has at most 256 k-mers: one round of four tiles per strand; three-word blocks
+                // have a build without the fourth column (one 8-byte gather instead of the second 16-byte one, 16 registers less)
+                if (a.short_only == 5 && a.col_end == 4)
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1, 4>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                        a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
-                else
-                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                else if (a.short_only == 5)
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1, 3>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
+                else  // (rounds of three tiles: one build; a three-word build measured 7 % slower there, 116 registers either way)
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2, 4>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                        a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
                 return hipGetLastError();
             }
