@@ -984,9 +984,17 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
     // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
     // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
     // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
-    if ((shape == 1 || shape == 3) && mib < (lg == 0 ? 3.5 : 2.5)) return 19;
-    if ((shape == 1 || shape == 3) && mib < 7.0) return 20;
-    const double two_mib_below = (lg == 0 ? 10.0 : (shape == 1 || shape == 3) ? 18.5 : 10.0) * phase_fill(shape, kmers);
+    if ((shape == 1 || shape == 3) && phase_fill(shape, kmers) >= 0.9) {
+        if (mib < (lg == 0 ? 3.5 : 2.5)) return 19;
+        if (mib < 7.0) return 20;
+    } else if ((shape == 1 || shape == 3) && mib < 7.5) {
+        // reads that leave the shape partly empty (session 57): larger pieces -- 1 MiB slices below 3.5 MiB for one-word blocks, 2 MiB
+        // slices otherwise (150 bp: 4 MiB one-word 3.79 -> 3.35 ms, 7 MiB 6.06 -> 4.88; 300 bp: 7 MiB 12.6 -> 8.6)
+        return (lg == 0 && mib < 3.5) ? 20 : 21;
+    }
+    // (session 55, the builds with more waves per SIMD: one-word 360 bp and two-word 250 bp keep 2 MiB slices longer)
+    const double switch_mib = lg == 0 ? (shape == 3 ? 17.0 : 10.0) : shape == 1 ? 26.0 : shape == 3 ? 18.5 : 10.0;
+    const double two_mib_below = switch_mib * phase_fill(shape, kmers);
     return mib < two_mib_below ? 21 : 22;
 }
 
@@ -1003,22 +1011,34 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
     if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
     if (shape == 6) return slice_log2 <= 21 ? 500 : n_slices <= 4 ? 850 : n_slices <= 8 ? 600 : 500;  // (five waves per SIMD: longer windows)
     if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(400, 2400 / std::max(n_slices, 1u));
-    if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 130-250 (512 KiB slices) and 250-325 ticks (1 MiB)
-        return slice_log2 <= 19 ? (shape == 1 ? 200 : 250) : (shape == 1 ? 250 : 325);
+    if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 200-400 (512 KiB slices) and 325-400 ticks (1 MiB)
+        return lg == 1 ? 400 : slice_log2 <= 19 ? 250 : (shape == 1 ? 325 : 400);
+    if (slice_log2 == 21 && n_slices <= 4 && (shape == 1 || shape == 3) && phase_fill(shape, kmers) < 0.9)
+        return shape == 1 ? 450 : 600;  // small tables, reads that leave the shape partly empty: 2 MiB slices, 400-500 / 500-700 ticks
+    // Session 55: the one-word builds and the two-word 250 bp build are compiled for 8 / 6 / 7 waves per SIMD since then (rb_kernels.hip,
+    // phased_min_waves); more reads per cycle, longer cycles: one-word 250 bp 150 + 5500 / n (was 150 + 4000 / n), 360 bp 150 + 6800 / n
+    // (100 + 5200 / n), two-word 250 bp 100 + 5000 / n (100 + 3700 / n); with 2 MiB slices one-word 250 bp 4600 / n, one-word
+    // 360 bp and two-word 250 bp 500 ticks up to 7 / 9 slices and 400 beyond.
+    if (slice_log2 == 21 && ((shape == 3 && lg == 0) || (shape == 1 && lg == 1)))
+        return n_slices <= (lg == 0 ? 7u : 9u) ? 500 : 400;
     if (slice_log2 >= 22) {
         switch (shape) {
-        case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 4000.0 : 3700.0; break;
-        case 3: base = lg == 0 ? 100.0 : 150.0; cycle = lg == 0 ? 5200.0 : 4400.0; break;
+        case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 5500.0 : 5000.0; break;
+        case 3: base = 150.0; cycle = lg == 0 ? 6800.0 : 4400.0; break;
         case 2: base = 200.0; cycle = 2500.0; break;
         default: base = lg == 0 ? 200.0 : 100.0; cycle = lg == 0 ? 2500.0 : 2000.0; break;
         }
     } else {
         switch (shape) {
-        case 1: base = lg == 0 ? 0.0 : 325.0; cycle = lg == 0 ? 3600.0 : 0.0; break;
+        case 1: base = lg == 0 ? 0.0 : 325.0; cycle = lg == 0 ? 4600.0 : 0.0; break;
         case 3: base = lg == 0 ? 0.0 : 400.0; cycle = lg == 0 ? 4400.0 : 0.0; break;
         default: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 2400.0 : 0.0; break;
         }
     }
+    // two-word 250 bp, 4 MiB slices (session 55): below the optimum the times jump (48 MiB: 12.6 ms at 600 ticks, 17.8 at 500; 64 MiB:
+    // 13.8 at 500, 19.2 at 400): never below 600 ticks up to 12 slices, 500 beyond
+    if (shape == 1 && lg == 1 && slice_log2 >= 22 && phase_fill(shape, kmers) >= 0.9)
+        return (uint64_t)std::max(base + cycle / std::max(n_slices, 1u), n_slices <= 12 ? 600.0 : 500.0);
     const double t = (base + cycle / std::max(n_slices, 1u)) * phase_fill(shape, kmers);
     // two-word blocks: below 325 / 400 ticks the times get erratic (64 MiB, 300 bp: 26.0 ms at 352 ticks, 21.5 at 400)
     const double lo = lg == 0 ? 0.0 : shape == 1 ? 325.0 : shape == 3 ? 400.0 : 0.0;
@@ -1031,13 +1051,14 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 // optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
 // 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).  Scaled by phase_fill() like the cycle:
 // with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain).
-// ... and from which size on: the short-read shapes from 1.25 MiB (three slices of 512 KiB) when the reads fill the shape -- with
-// 150 bp reads in the four-tile shape a table of 3-7 MiB is served faster without phases (3 MiB: 4.6 against 3.9 ms), from 8 MiB
-// on with them (5.4 against 7.0) --, the general build from 6 MiB (500 bp reads: 2 MiB 11.6 -> 11.4 ms, 4 MiB no gain, 6 MiB
+// ... and from which size on: the short-read shapes from 1.25 MiB (three slices of 512 KiB) when the reads fill the shape, the
+// general build from 6 MiB (500 bp reads: 2 MiB 11.6 -> 11.4 ms, 4 MiB no gain, 6 MiB
 // 17.7 -> 16.1)
-static uint64_t phase_shape_min_bytes(int shape, double fill)
+static uint64_t phase_shape_min_bytes(int shape, int lg, double fill)
 {
-    if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : (15ull << 19);
+    // (session 57, the builds with more waves per SIMD: reads that leave the shape partly empty gain from 2 MiB on with one-word
+    // blocks, from 3 MiB on with two-word blocks -- 4.5 MiB for reads as short as 150 bp, where a 4 MiB table loses: 3.83 against 3.60)
+    if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : lg == 0 ? (2ull << 20) : fill >= 0.75 ? (3ull << 20) : (9ull << 19);
     // three- and four-word blocks: <= 256 k-mers from 4.5 MiB on (smaller tables take the same round without a clock); rounds of
     // three tiles from 6 MiB on (4 MiB: 10.8 against 11.1 ms at 360 bp, 16.5 against 14.6 at 500 bp)
     if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
@@ -1111,7 +1132,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
         // (4 / 5: three- and four-word blocks, rounds of three tiles / one round of four; 6: the three-word build of 5, five waves per SIMD)
         const int shape = a.planes > 10 ? 0 : (a.short_only == 5 && a.col_end == 3) ? 6 : a.short_only;
-        const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, phase_fill(shape, kmers)) &&
+        const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, a.lg, phase_fill(shape, kmers)) &&
                                    (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * phase_fill(shape, kmers) &&
                                    n_reads >= phase_min_reads_for(table_bytes);
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
@@ -1308,7 +1329,7 @@ static double est_filter_ms(const rb_engine *e, const rb_dibf *f)
     // three- and four-word blocks (stride 4) in the both-strands build, 4.5-48 MiB: 8 MiB 9.4, 16 MiB 11.4, 24 MiB 12.7, 40 MiB 17.2
     if (f->geo.n_hash == 3 && f->stride == 4 && e->phase_max_bytes && bytes >= (9ull << 19) && bytes <= (48ull << 20)) return 8.0 + 0.23 * mib;
     if (!phased) return est_plain_ms(mib);
-    return f->geo.bin_width == 1 ? 6.6 + 0.125 * mib : 7.0 + 0.15 * mib;
+    return f->geo.bin_width == 1 ? 6.3 + 0.115 * mib : 6.3 + 0.125 * mib;  // (session 55: 8 MiB 7.0 / 6.7, 32 MiB 9.5 / 10.5, 64 MiB 14.1 / 13.8)
 }
 
 // Which filters share a merged table.  Candidates: three hash functions, blocks of at most 8 words, equal noOfBlocks and k; at
@@ -1345,7 +1366,7 @@ static void plan_merged(rb_engine *e)
         const double merged_mib = (double)(gi.n_blocks * hbm_stride(width) * 8) / 1048576.0;
         const bool narrow_phased = e->phase_max_bytes && ((width == 2 && merged_mib >= 1.25 && merged_mib <= 96.0) ||
                                                           ((width == 3 || width == 4) && merged_mib <= 48.0));
-        const double together = (narrow_phased ? (width == 2 ? 7.0 + 0.15 * merged_mib : 8.0 + 0.23 * merged_mib) : est_plain_ms(merged_mib)) +
+        const double together = (narrow_phased ? (width == 2 ? 6.3 + 0.125 * merged_mib : 8.0 + 0.23 * merged_mib) : est_plain_ms(merged_mib)) +
                                 0.3 * (double)members.size();
         if (e->merge_mode == 1 && apart <= 1.05 * together) continue;
         if ((gi.n_blocks * hbm_stride(width) + 8) * 8 > e->merge_max_bytes) continue;

@@ -831,8 +831,34 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
     }
 }
 
+// Waves per SIMD each build of the phased kernel is compiled for (amdgpu_waves_per_eu minimum = the register budget the compiler
+// works against).  Left to itself it stops at the first allocation that fits its default target; told to aim higher it finds
+// 56 instead of 73 registers for the one-word 250 bp build (8 waves), 76 instead of 93 for the one-word 360 bp build (6 waves), 72
+// instead of 86 for the two-word 250 bp build (7 waves) -- all without scratch (the two-word 360 bp build spills 96 bytes at five
+// waves and stays at four).  More reads per cycle: 5-15 % less time per read at the (longer) windows that go with it
+// (profiles/r03/slice_size.txt, session 54).
+#ifndef RB_WAVES_0_1
+#define RB_WAVES_0_1 7
+#endif
+#ifndef RB_WAVES_0_3
+#define RB_WAVES_0_3 6
+#endif
+#ifndef RB_WAVES_1_1
+#define RB_WAVES_1_1 6
+#endif
+#ifndef RB_WAVES_1_3
+#define RB_WAVES_1_3 3
+#endif
+constexpr int phased_min_waves(int lg, int shrt, int nw)
+{
+    if (lg == 0) return shrt == 1 ? RB_WAVES_0_1 : shrt == 3 ? RB_WAVES_0_3 : shrt ? 4 : 3;
+    if (lg == 1) return shrt == 1 ? RB_WAVES_1_1 : shrt == 3 ? RB_WAVES_1_3 : 3;
+    if (lg == 2 && shrt == 1) return nw == 3 ? RB_WIDE_WAVES : 4;
+    return 3;
+}
+
 template <int LG, int NP, int SHORT, int NW = 4>  // NW: words per block the one-lane build for stride-4 blocks holds (3: no fourth column)
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((SHORT && LG == 0) ? 4 : (LG == 2 && SHORT == 1) ? (NW == 3 ? RB_WIDE_WAVES : 4) : 3, SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(phased_min_waves(LG, SHORT, NW), SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride, NarrowMerge nm)
 {
