@@ -849,16 +849,29 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
 #ifndef RB_WAVES_1_3
 #define RB_WAVES_1_3 3
 #endif
+#ifndef RB_WAVES_0_2
+#define RB_WAVES_0_2 4
+#endif
+#ifndef RB_WAVES_1_2
+#define RB_WAVES_1_2 3
+#endif
+#ifndef RB_WAVES_2_2
+#define RB_WAVES_2_2 3
+#endif
+#ifndef RB_WAVES_GEN
+#define RB_WAVES_GEN 3
+#endif
 constexpr int phased_min_waves(int lg, int shrt, int nw)
 {
-    if (lg == 0) return shrt == 1 ? RB_WAVES_0_1 : shrt == 3 ? RB_WAVES_0_3 : shrt ? 4 : 3;
-    if (lg == 1) return shrt == 1 ? RB_WAVES_1_1 : shrt == 3 ? RB_WAVES_1_3 : 3;
+    if (lg == 0) return shrt == 1 ? RB_WAVES_0_1 : shrt == 3 ? RB_WAVES_0_3 : shrt ? RB_WAVES_0_2 : RB_WAVES_GEN;
+    if (lg == 1) return shrt == 1 ? RB_WAVES_1_1 : shrt == 3 ? RB_WAVES_1_3 : shrt ? RB_WAVES_1_2 : RB_WAVES_GEN;
     if (lg == 2 && shrt == 1) return nw == 3 ? RB_WIDE_WAVES : 4;
+    if (lg == 2) return RB_WAVES_2_2;
     return 3;
 }
 
 template <int LG, int NP, int SHORT, int NW = 4>  // NW: words per block the one-lane build for stride-4 blocks holds (3: no fourth column)
-__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(phased_min_waves(LG, SHORT, NW), SHORT ? 8 : 4))) void ibf_count_max_phased_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(phased_min_waves(LG, SHORT, NW), 8))) void ibf_count_max_phased_kernel(
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride, NarrowMerge nm)
 {
