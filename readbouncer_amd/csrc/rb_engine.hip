@@ -970,7 +970,7 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
 // one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp; 32 MiB: 400 against 700).  Factor on the cycle, 0.5 ... 1.
 static double phase_fill(int shape, uint32_t kmers)
 {
-    const double fit = (shape == 1 || shape == 5 || shape == 6) ? 238.0 : (shape == 3 || shape == 4) ? 348.0 : shape == 2 ? 488.0 : 0.0;
+    const double fit = (shape == 1 || shape == 5 || shape == 6) ? 238.0 : (shape == 3 || shape == 4 || shape == 7) ? 348.0 : shape == 2 ? 488.0 : 0.0;
     if (fit == 0.0) return 1.0;  // per-strand tiles of the general build: the work of a round does not depend on the read length
     return std::min(1.0, std::max(0.5, (double)kmers / fit));
 }
@@ -980,7 +980,7 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
     const double mib = (double)table_bytes / 1048576.0;
     if (shape == 5) return mib <= 12.0 ? 21 : 22;  // three- and four-word blocks (sessions 44-46, slice_size.txt)
     if (shape == 6) return mib <= 14.0 ? 21 : 22;  // three-word blocks, <= 256 k-mers: the build with five waves per SIMD (session 53)
-    if (shape == 4) return mib <= 13.0 ? 21 : 22;
+    if (shape == 4 || shape == 7) return mib <= 13.0 ? 21 : 22;
     // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
     // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
     // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
@@ -1011,6 +1011,7 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
     if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
     if (shape == 6) return slice_log2 <= 21 ? 500 : n_slices <= 4 ? 850 : n_slices <= 8 ? 600 : 500;  // (five waves per SIMD: longer windows)
     if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(400, 2400 / std::max(n_slices, 1u));
+    if (shape == 7) return slice_log2 <= 21 ? 400 : std::max<uint64_t>(400, 3400 / std::max(n_slices, 1u));  // (three-word build, five waves: session 59)
     if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 200-400 (512 KiB slices) and 325-400 ticks (1 MiB)
         return lg == 1 ? 400 : slice_log2 <= 19 ? 250 : (shape == 1 ? 325 : 400);
     if (slice_log2 == 21 && n_slices <= 4 && (shape == 1 || shape == 3) && phase_fill(shape, kmers) < 0.9)
@@ -1063,13 +1064,13 @@ static uint64_t phase_shape_min_bytes(int shape, int lg, double fill)
     // three tiles from 6 MiB on (4 MiB: 10.8 against 11.1 ms at 360 bp, 16.5 against 14.6 at 500 bp)
     if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
     if (shape == 6) return fill >= 0.8 ? (3ull << 20) : ~0ull;  // (4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB)
-    if (shape == 4) return 6ull << 20;
+    if (shape == 4 || shape == 7) return 6ull << 20;
     return 6ull << 20;
 }
 
 static uint64_t phase_shape_max_bytes(int shape, int lg)
 {
-    if (shape == 4 || shape == 5 || shape == 6) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 25.4 against 33.6 (360 bp); 64 MiB: even
+    if (shape == 4 || shape == 5 || shape == 6 || shape == 7) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 25.4 against 33.6 (360 bp); 64 MiB: even
     if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
     if (shape == 3) return (lg == 0 ? 128ull : 64ull) << 20;
     return (lg == 0 ? 64ull : 48ull) << 20;
@@ -1130,8 +1131,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 1 on a wider
         // filter, e.g. 3072 bins over 24 ranks -- stride 48 -- and keeps the plain kernel)
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
-        // (4 / 5: three- and four-word blocks, rounds of three tiles / one round of four; 6: the three-word build of 5, five waves per SIMD)
-        const int shape = a.planes > 10 ? 0 : (a.short_only == 5 && a.col_end == 3) ? 6 : a.short_only;
+        // (4 / 5: three- and four-word blocks, rounds of three tiles / one round of four; 7 / 6: their three-word builds, five waves per SIMD)
+        const int shape = a.planes > 10 ? 0 : (a.short_only == 5 && a.col_end == 3) ? 6 : (a.short_only == 4 && a.col_end == 3) ? 7 : a.short_only;
         const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, a.lg, phase_fill(shape, kmers)) &&
                                    (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * phase_fill(shape, kmers) &&
                                    n_reads >= phase_min_reads_for(table_bytes);

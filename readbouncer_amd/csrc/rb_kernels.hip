@@ -849,6 +849,9 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
 #ifndef RB_WAVES_1_3
 #define RB_WAVES_1_3 3
 #endif
+#ifndef RB_WIDE3_ROUNDS  // a three-word build for the rounds of three tiles as well (94 registers at five waves per SIMD; session 59: 3-10 % faster)
+#define RB_WIDE3_ROUNDS 1
+#endif
 #ifndef RB_WAVES_0_2
 #define RB_WAVES_0_2 4
 #endif
@@ -858,6 +861,9 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
 #ifndef RB_WAVES_2_2
 #define RB_WAVES_2_2 3
 #endif
+#ifndef RB_WAVES_2_2_NW3
+#define RB_WAVES_2_2_NW3 5
+#endif
 #ifndef RB_WAVES_GEN
 #define RB_WAVES_GEN 3
 #endif
@@ -866,7 +872,7 @@ constexpr int phased_min_waves(int lg, int shrt, int nw)
     if (lg == 0) return shrt == 1 ? RB_WAVES_0_1 : shrt == 3 ? RB_WAVES_0_3 : shrt ? RB_WAVES_0_2 : RB_WAVES_GEN;
     if (lg == 1) return shrt == 1 ? RB_WAVES_1_1 : shrt == 3 ? RB_WAVES_1_3 : shrt ? RB_WAVES_1_2 : RB_WAVES_GEN;
     if (lg == 2 && shrt == 1) return nw == 3 ? RB_WIDE_WAVES : 4;
-    if (lg == 2) return RB_WAVES_2_2;
+    if (lg == 2) return nw == 3 ? RB_WAVES_2_2_NW3 : RB_WAVES_2_2;
     return 3;
 }
 
@@ -1755,7 +1761,12 @@ static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
                 else if (a.short_only == 5)
                     hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 1, 3>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                        a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
-                else  // (rounds of three tiles: one build; a three-word build measured 7 % slower there, 116 registers either way)
+#if RB_WIDE3_ROUNDS
+                else if (a.col_end == 3)
+                    hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2, 3>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
+                                       a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
+#endif
+                else  // (four-word blocks; at four waves per SIMD a three-word build had measured 7 % slower, at five it wins)
                     hipLaunchKernelGGL((ibf_count_max_phased_kernel<2, 10, 2, 4>), grid, dim3(64 * kWavesPerBlock), 0, st, a.f, a.col_begin,
                                        a.col_end, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
                 return hipGetLastError();
