@@ -700,8 +700,11 @@ __device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item
 }
 
 // throughput form: one wave per (read, column slice), both strands in sequence
+#ifndef RB_WAVES_PLAIN  // waves per SIMD the plain throughput kernel is compiled for (one word per lane, ten planes)
+#define RB_WAVES_PLAIN 3
+#endif
 template <int LG, int WPL, int NP, int H, bool NT>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_kernel(
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((WPL == 1 && NP == 10 && H == 3) ? RB_WAVES_PLAIN : 3, 8))) void ibf_count_max_kernel(
     FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
     uint32_t out_read_stride, uint32_t out_slice_stride)
 {
