@@ -1026,7 +1026,7 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
         switch (shape) {
         case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 5500.0 : 5000.0; break;
         case 3: base = 150.0; cycle = lg == 0 ? 6800.0 : 4400.0; break;
-        case 2: base = 200.0; cycle = 2500.0; break;
+        case 2: base = lg == 0 ? 300.0 : 200.0; cycle = lg == 0 ? 2400.0 : 2500.0; break;  // (one-word: rounds of three tiles at eight waves, session 61)
         default: base = lg == 0 ? 200.0 : 100.0; cycle = lg == 0 ? 2500.0 : 2000.0; break;
         }
     } else {
@@ -1051,7 +1051,8 @@ static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint3
 // 360 bp); two-word blocks 96 MiB at 250 bp (20.2 / 24.8; even at 127 MiB), 64 MiB at 360 bp (22.2 / 35.1; at 96 MiB the
 // optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
 // 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).  Scaled by phase_fill() like the cycle:
-// with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain).
+// with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain); shapes that are
+// at least 80 % full keep the whole range (430 bp, one-word 64 MiB: 30.7 ms phased against 42.6 plain).
 // ... and from which size on: the short-read shapes from 1.25 MiB (three slices of 512 KiB) when the reads fill the shape, the
 // general build from 6 MiB (500 bp reads: 2 MiB 11.6 -> 11.4 ms, 4 MiB no gain, 6 MiB
 // 17.7 -> 16.1)
@@ -1065,7 +1066,7 @@ static uint64_t phase_shape_min_bytes(int shape, int lg, double fill)
     if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
     if (shape == 6) return fill >= 0.8 ? (3ull << 20) : ~0ull;  // (4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB)
     if (shape == 4 || shape == 7) return 6ull << 20;
-    return 6ull << 20;
+    return (shape == 2 && lg == 0) ? (5ull << 20) : (6ull << 20);
 }
 
 static uint64_t phase_shape_max_bytes(int shape, int lg)
@@ -1134,7 +1135,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         // (4 / 5: three- and four-word blocks, rounds of three tiles / one round of four; 7 / 6: their three-word builds, five waves per SIMD)
         const int shape = a.planes > 10 ? 0 : (a.short_only == 5 && a.col_end == 3) ? 6 : (a.short_only == 4 && a.col_end == 3) ? 7 : a.short_only;
         const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, a.lg, phase_fill(shape, kmers)) &&
-                                   (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * phase_fill(shape, kmers) &&
+                                   (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * (phase_fill(shape, kmers) >= 0.8 ? 1.0 : phase_fill(shape, kmers)) &&
                                    n_reads >= phase_min_reads_for(table_bytes);
         if (e->phase_max_bytes && table_bytes >= e->phase_min_bytes && table_bytes <= e->phase_max_bytes &&
             n_reads >= e->phase_min_reads && stride_pow2 && (e->phase_explicit || in_rule_range)) {

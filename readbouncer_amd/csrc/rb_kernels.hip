@@ -852,11 +852,15 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
 #ifndef RB_WAVES_1_3
 #define RB_WAVES_1_3 3
 #endif
+#ifndef RB_TILES_ROUNDS  // tiles per strand and round of the one-word build for reads of 385-512 k-mers: three (63 registers, eight waves per
+                        // SIMD; two rounds of four tiles took 111 registers, four waves: session 61, 7-13 % slower); two-word blocks keep four
+#define RB_TILES_ROUNDS 3
+#endif
 #ifndef RB_WIDE3_ROUNDS  // a three-word build for the rounds of three tiles as well (94 registers at five waves per SIMD; session 59: 3-10 % faster)
 #define RB_WIDE3_ROUNDS 1
 #endif
 #ifndef RB_WAVES_0_2
-#define RB_WAVES_0_2 4
+#define RB_WAVES_0_2 7
 #endif
 #ifndef RB_WAVES_1_2
 #define RB_WAVES_1_2 3
@@ -895,7 +899,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
     uint32_t best = 0;
-    constexpr int T = SHORT == 3 ? 6 : 4;                      // 64-k-mer tiles per strand and round
+    constexpr int T = SHORT == 3 ? 6 : (SHORT == 2 && LG == 0) ? RB_TILES_ROUNDS : 4;  // 64-k-mer tiles per strand and round
     constexpr uint32_t kRound = 64u * T;                       // k-mers per strand and round
     constexpr bool kOneRound = SHORT == 1 || SHORT == 3;       // no loop state (registers)
     if constexpr (LG == 0) {
@@ -942,7 +946,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int j = 0; j < 2 * T; ++j) x[j] = bn[j][0] != 0xFFFFFFFFu ? lc.valid[0] : 0ULL;  // after the hashing: 16 registers less there
             // (six tiles per strand: the 36 gathers of a window go out in two batches of 18)
-            phased_gather<2 * T, 3, false, T == 6 ? RB_GATHER_B3 : (SHORT == 1 ? RB_GATHER_B1 : 8)>(x, bn, f.words, slice_shift, ph);
+            phased_gather<2 * T, 3, false, T == 6 ? RB_GATHER_B3 : (SHORT == 1 ? RB_GATHER_B1 : (T == 4 ? 8 : 2))>(x, bn, f.words, slice_shift, ph);
             cf += wave_bin_counts<T>(x, lane);
             cr += wave_bin_counts<T>(x + T, lane);
             }
