@@ -295,7 +295,7 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
 @pytest.mark.parametrize("bins,mib", [(64, 8.0), (64, 100.0), (128, 60.0), (100, 30.0), (64, 2.0), (128, 5.0), (90, 1.0), (256, 24.0), (150, 40.0), (200, 3.0)])
 def test_phased_form_over_its_whole_range_agrees_with_the_plain_kernel(bins, mib):
     """The phased form serves one- and two-word tables of 1.25-128 MiB in slices of 0.5-4 MiB, up to 32 of them (rb_engine.hip,
-    phase_slice_log2 / phase_window_ticks): same maxima as the plain kernel on 10^5 reads of 250, 360 and 600 bp across that
+    phase_slice_log2 / phase_window_ticks): same maxima as the plain kernel on 10^5 reads of 250, 360, 450 and 600 bp across that
     range (2 MiB: four slices of 512 KiB; 5 MiB two-word: 1 MiB slices; 8 MiB: four slices of 2 MiB; 100 MiB: 25 slices of
     4 MiB; two-word 60 and 30 MiB; 1 MiB two-word: the both-strands round without a clock; four-word 24 MiB, three-word 40 MiB and
     four-word 3 MiB: one lane per block with two 16-byte gathers), and a sample against the oracle."""
@@ -308,7 +308,7 @@ def test_phased_form_over_its_whole_range_agrees_with_the_plain_kernel(bins, mib
     eng = capi.Engine(0, [d], [])
     h = d.download()
     view = po.OracleIBF.wrap(bins, 3, 13, h.info["n_bits"], h.words())
-    for read_len in (250, 360, 600):
+    for read_len in (250, 360, 450, 600):
         buf, offs, lens = synth.make_reads(read_len + bins, 100_000, read_len, ref)
         eng.set_phased(0, 0, 0, 0, 0)
         plain = eng.classify(buf, offs, lens)
