@@ -993,7 +993,9 @@ static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32
         return (lg == 0 && mib < 3.5) ? 20 : 21;
     }
     // (session 55, the builds with more waves per SIMD: one-word 360 bp and two-word 250 bp keep 2 MiB slices longer)
-    const double switch_mib = lg == 0 ? (shape == 3 ? 17.0 : 10.0) : shape == 1 ? 26.0 : shape == 3 ? 18.5 : 10.0;
+    // (two-word 250 bp: with 2 MiB slices the optimum of 18-24 MiB tables is a narrow dip -- 24 MiB: 9.7 ms at 400 ticks between 12.5 at 325
+    // and 10.9 at 500 --, with 4 MiB slices a flat 9.6-10.1 over 850-1200 ticks: 4 MiB from 17 MiB on)
+    const double switch_mib = lg == 0 ? (shape == 3 ? 17.0 : 10.0) : shape == 1 ? 17.0 : shape == 3 ? 18.5 : 10.0;
     const double two_mib_below = switch_mib * phase_fill(shape, kmers);
     return mib < two_mib_below ? 21 : 22;
 }
