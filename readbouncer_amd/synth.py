@@ -71,8 +71,18 @@ def build_device_filter(device, w, fill_seed, plant_seed, n_segments=2048, seg_l
     return d, ref
 
 
-def make_reads(seed, n_reads, read_len, ref, positive_fraction=0.5, error_rate=0.10, seg_len=2000):
-    """fixed-length reads: positives sampled inside planted segments with substitutions, negatives uniform.
+# Threshold-adjacent stratum: every tenth positive read gets NEAR_ERROR instead of `error_rate`.  A substitution draws from ACGT
+# (a quarter of them restore the base), so the effective rate is 0.75 x nominal: 0.19-0.23 nominal = 14-17 % effective, where a
+# 360 bp read keeps 348 x (1 - e)^13 = 30-48 of its 13-mers -- around the threshold of 38 (r = 0.1) and down to that of the
+# r - 0.02 re-test's neighbourhood.  Without it nearly every read of a batch sits far from its threshold (positives ~125 shared
+# k-mers, negatives ~10) and a count that is off by a few could not flip a decision.
+NEAR_FRACTION = 0.1
+NEAR_ERROR = (0.19, 0.23)
+
+
+def make_reads(seed, n_reads, read_len, ref, positive_fraction=0.5, error_rate=0.10, seg_len=2000, near_fraction=NEAR_FRACTION):
+    """fixed-length reads: positives sampled inside planted segments with substitutions (a `near_fraction` of them at the
+    threshold-adjacent error rates NEAR_ERROR), negatives uniform.
     returns (uint8 [n_reads*read_len], uint64 offsets, uint32 lens)"""
     rng = np.random.default_rng(seed)
     n_pos = int(n_reads * positive_fraction)
@@ -84,7 +94,11 @@ def make_reads(seed, n_reads, read_len, ref, positive_fraction=0.5, error_rate=0
         start = seg * seg_len + off
         idx = start[:, None] + np.arange(read_len)[None, :]
         pos = ref[idx]
-        err = rng.random((n_pos, read_len)) < error_rate
+        rate = np.full(n_pos, error_rate)
+        if near_fraction > 0:
+            near = rng.random(n_pos) < near_fraction
+            rate[near] = rng.uniform(NEAR_ERROR[0], NEAR_ERROR[1], size=int(near.sum()))
+        err = rng.random((n_pos, read_len)) < rate[:, None]
         pos[err] = _ACGT[rng.integers(0, 4, size=int(err.sum()), dtype=np.uint8)]
         # every second positive is given as its reverse complement
         comp = np.zeros(256, dtype=np.uint8)
@@ -98,8 +112,10 @@ def make_reads(seed, n_reads, read_len, ref, positive_fraction=0.5, error_rate=0
     return np.ascontiguousarray(out.reshape(-1)), offs, lens
 
 
-def make_reads_device(seed, n_reads, read_len, ref, device, positive_fraction=0.5, error_rate=0.10, seg_len=2000):
-    """same construction as make_reads, generated with torch on `device` (plumbing: 10M reads are 3.6 GB);
+def make_reads_device(seed, n_reads, read_len, ref, device, positive_fraction=0.5, error_rate=0.10, seg_len=2000,
+                      near_fraction=NEAR_FRACTION):
+    """same construction as make_reads (threshold-adjacent stratum included), generated with torch on `device` (plumbing: 10M
+    reads are 3.6 GB);
     returns torch tensors (uint8 [n_reads*read_len], int64 offsets, int32 lens) resident on the device"""
     import torch
     g = torch.Generator(device=device)
@@ -124,7 +140,12 @@ def make_reads_device(seed, n_reads, read_len, ref, device, positive_fraction=0.
             off = torch.randint(0, seg_len - read_len + 1, (m,), generator=g, device=device)
             idx = (seg * seg_len + off)[:, None] + ar[None, :]
             pos = t_ref[idx]
-            err = torch.rand((m, read_len), generator=g, device=device) < error_rate
+            rate = torch.full((m,), float(error_rate), device=device)
+            if near_fraction > 0:
+                near = torch.rand((m,), generator=g, device=device) < near_fraction
+                span = torch.rand((m,), generator=g, device=device) * (NEAR_ERROR[1] - NEAR_ERROR[0]) + NEAR_ERROR[0]
+                rate = torch.where(near, span, rate)
+            err = torch.rand((m, read_len), generator=g, device=device) < rate[:, None]
             sub = acgt[torch.randint(0, 4, (m, read_len), generator=g, device=device)]
             pos = torch.where(err, sub, pos)
             rc = comp[pos.flip(1).long()]

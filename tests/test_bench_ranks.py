@@ -54,7 +54,7 @@ def test_gpus2_default_line_structure_cpu():
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
                 "roofline", "cpu_baseline", "parity", "ranks", "other_configs"):
         assert key in d, key
-    assert set(d["other_configs"]) == {"c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"}
+    assert set(d["other_configs"]) == {"c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"}
     for sub in d["other_configs"].values():
         assert sub["n_gpus"] == 2 and sub["value"] > 0
     r = d["ranks"]
@@ -148,14 +148,27 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
     assert d1["test_reads_divisor"] == 50 and d2["n_gpus"] == 2 and "config3" in d2["config"]["workload"]
     assert d1["cpu_baseline"]["value"] > 0 and d2["cpu_baseline"] is None  # timed at N = 1 only
     for d in (d1, d2):
-        assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
-        assert set(d["other_configs"]) >= {"c2", "c4", "c5", "readme", "targets3", "deplete_target"}
-        assert d["other_configs"]["targets3"]["parity"]["decision_mismatches"] == 0
-        assert d["other_configs"]["c4"]["parity"]["decision_mismatches"] == 0
-        assert d["other_configs"]["c5"]["latency"]["slo_met"] is True
+        assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["raw_max_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
+        assert d["parity"]["near_threshold_reads"] > 0  # the sample holds reads on which a count off by a few would flip the decision
+        assert set(d["other_configs"]) >= {"c3np2", "c2", "c4", "c5", "readme", "targets3", "deplete_target"}
+        for leg in ("c3np2", "c2", "c4", "readme", "targets3", "deplete_target"):
+            par = d["other_configs"][leg]["parity"]
+            assert par["decision_mismatches"] == 0 and par["raw_max_mismatches"] == 0 and par["checked_reads"] > 0, leg
+        assert "generic modulus" in d["other_configs"]["c3np2"]["config"]["workload"]
+        assert d["other_configs"]["c3np2"]["config"]["filters"][0]["bytes"] % (1 << 20) != 0  # BinSizeBits x 8256: not a power of two
+        # (latency SLO and keep-up of the c5 leg: wall-clock figures, asserted by test_c5_leg_meets_its_slo under -m gpuperf)
         assert d["other_configs"]["c5"]["parity"]["replayed_decisions_equal_one_batch"] is True
-        assert d["other_configs"]["c5"]["live_step"]["concatenated_share"] > 0.3 and d["other_configs"]["c5"]["live_step"]["kept_up"] is True
+        assert d["other_configs"]["c5"]["live_step"]["concatenated_share"] > 0.3
     assert d2["config"]["decisions_sha1"] == d1["config"]["decisions_sha1"]
     assert d2["other_configs"]["c4"]["config"]["decisions_sha1"] == d1["other_configs"]["c4"]["config"]["decisions_sha1"]
     assert min(d1["other_configs"]["c4"]["config"]["decisions"]) > 0
     assert len(d2["ranks"]["devices"]) == 2 and d2["ranks"]["devices"][0]["device"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.gpuperf
+def test_c5_leg_meets_its_slo():
+    """wall-clock half of the default line's c5 leg (only under -m gpuperf): p99 below 1 ms, the live step keeps up"""
+    p, d = _run(["--gpus", "1", "--workload", "c5"], {}, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["latency"]["slo_met"] is True and d["live_step"]["kept_up"] is True and d["live_step"]["slo_met"] is True

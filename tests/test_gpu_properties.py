@@ -5,7 +5,7 @@ compared with the oracle."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.gpu  # (tests that assert elapsed time carry `gpuperf` as well: conftest.py keeps them out of -m gpu)
 
 from oracle import pyoracle as po
 from readbouncer_amd import capi, synth
@@ -132,17 +132,16 @@ def test_c4_sample_against_oracle(c4):
         assert np.array_equal(base[0][idx, f], po.batch_raw_max(o, buf, offs[idx], lens[idx], 8))
 
 
-def test_c3_ten_million_reads_in_one_call(c4):
-    """BASELINE configs[2] as stated: ONE call over 10 M device-resident 360 bp reads (3.6 GB of read bytes, 2.5 M
-    workgroups) against the 8 GiB filter.  Checked through what the size allows: strand symmetry of the whole batch (a
-    second 10 M-read call on the reverse complements), batch-partition invariance against separate calls on slices of it,
-    the status/decision bookkeeping, and 2 000 sampled reads against the oracle."""
+def _ten_million_reads_in_one_call(dep, read_seed):
+    """ONE call over 10 M device-resident 360 bp reads (3.6 GB of read bytes, 2.5 M workgroups) against `dep` (planted with
+    the segments of seed 40).  Checked through what the size allows: strand symmetry of the whole batch (a second 10 M-read
+    call on the reverse complements), batch-partition invariance against separate calls on slices of it, the
+    status/decision bookkeeping, and 2 000 sampled reads against the oracle -- raw maxima and decisions."""
     torch = pytest.importorskip("torch")
-    dep = c4[0]
     dev = torch.device("cuda:0")
     n, L = 10_000_000, 360
-    ref = synth.planted_reference(40)[0]  # the segments the c4 fixture planted into this filter
-    t_seq, t_off, t_len = synth.make_reads_device(1234, n, L, ref, dev)
+    ref = synth.planted_reference(40)[0]  # the segments planted into this filter
+    t_seq, t_off, t_len = synth.make_reads_device(read_seed, n, L, ref, dev)
     t_max = torch.zeros((n, 1), dtype=torch.int16, device=dev)
     t_dec = torch.zeros(n, dtype=torch.uint8, device=dev)
     t_st = torch.full((n,), 255, dtype=torch.uint8, device=dev)
@@ -191,12 +190,32 @@ def test_c3_ten_million_reads_in_one_call(c4):
     exp_dec, _ = po.batch_check_unblock([o], [], sample, so, sl, n_threads=8)
     assert np.array_equal(t_max[t_idx, 0].cpu().numpy().view(np.uint16), exp_max)
     assert np.array_equal(t_dec[t_idx].cpu().numpy(), exp_dec)
+    # the sample reaches the threshold's neighbourhood (synth's threshold-adjacent stratum): reads on which a count that is
+    # off by a few would flip the decision
+    assert int((np.abs(exp_max.astype(np.int64) - 38) <= 5).sum()) >= 5
+    eng.destroy()
+    del t_seq, t_max, t_dec, t_st
+    torch.cuda.empty_cache()
 
 
-def test_c5_replay_as_stated(c4):
-    """BASELINE configs[4] on one GPU: >= 150 k chunks/s for >= 1 s through rb_replay_arrivals against the 8 GiB deplete +
-    600-bin target filters; every decision equals what one big rb_classify_batch gives; p99 (arrival -> decision on the
-    host) below the 1 ms SLO."""
+def test_c3_ten_million_reads_in_one_call(c4):
+    """BASELINE configs[2] as stated, against the 8 GiB filter (2^23 blocks: block_index takes the mask shortcut)"""
+    _ten_million_reads_in_one_call(c4[0], 1234)
+
+
+def test_c3np2_ten_million_reads_in_one_call():
+    """the same at the reference's own sizing of an 8192-bin filter: noOfBits = BinSizeBits x 8256
+    (src/IBF/IBFBuild.cpp:404-413) -- a block count that is not a power of two, so every lookup takes the generic
+    (Barrett) modulus of ibf_spec.h, the path every filter built by ReadBouncer itself takes"""
+    w = synth.WORKLOADS["c3np2"]
+    dep, _ = synth.build_device_filter(0, w, fill_seed=4, plant_seed=40)
+    nb = dep.info["n_blocks"]
+    assert nb & (nb - 1) and dep.info["n_bits"] == capi.calculate_filter_size_bits(w["fragment"], 13, 3, 0.01, 8192)
+    _ten_million_reads_in_one_call(dep, 4321)
+    dep.free()
+
+
+def _c5_arrivals(c4):
     dep, tgt, eng, buf, offs, lens, base = c4
     rate, seconds, L = 150_000.0, 1.2, 360
     n = int(rate * seconds)
@@ -205,19 +224,19 @@ def test_c5_replay_as_stated(c4):
     for _ in range(10):  # code objects, staging buffers, threshold table
         eng.classify(buf[: 64 * L], offs[:64], lens[:64])
         eng.classify(buf[: 4096 * L], offs[:4096], lens[:4096])
-    for attempt in range(3):  # the latency figures are a capability of the path: one stall of the box (>= 12 ms of the 1.2 s
-        # hold 1 % of the chunks) is retried, the decisions must be right every time
-        dec, lat, call_reads, call_service, elapsed = eng.replay_arrivals(buf[: n * L], L, arrival, max_batch=16384)
-        assert np.array_equal(dec, base[2][:n])  # the fixture's one-batch decisions of the same reads
-        assert len(set(dec.tolist())) == 3
-        assert elapsed >= 1.0 and n / elapsed >= 0.98 * rate  # kept up with the arrivals
-        p50, p99 = np.percentile(lat, 50), np.percentile(lat, 99)
-        print("c5 replay attempt %d: p50 %.3f ms, p99 %.3f ms, %d calls" % (attempt, p50 * 1e3, p99 * 1e3, len(call_reads)))
-        if p99 < 1e-3:
-            break
-    assert p99 < 1e-3, "p99 %.3f ms" % (p99 * 1e3)
-    assert p50 < 0.3e-3
-    assert int(call_reads.sum()) == n
+    return rate, n, L, arrival
+
+
+def test_c5_replay_as_stated(c4):
+    """BASELINE configs[4] on one GPU: 150 k chunks/s for 1.2 s through rb_replay_arrivals against the 8 GiB deplete +
+    600-bin target filters; every decision equals what one big rb_classify_batch gives, whatever micro-batches the arrival
+    process cut.  (The stopwatch side -- keep-up, p99 below the 1 ms SLO -- is test_c5_replay_latency_slo, marker gpuperf.)"""
+    dep, tgt, eng, buf, offs, lens, base = c4
+    rate, n, L, arrival = _c5_arrivals(c4)
+    dec, lat, call_reads, call_service, elapsed = eng.replay_arrivals(buf[: n * L], L, arrival, max_batch=16384)
+    assert np.array_equal(dec, base[2][:n])  # the fixture's one-batch decisions of the same reads
+    assert len(set(dec.tolist())) == 3
+    assert int(call_reads.sum()) == n and len(lat) == n
     # unsorted arrivals are refused, an oversized max_batch is clamped
     bad = arrival.copy()
     bad[10] = bad[9] - 1e-3
@@ -225,6 +244,24 @@ def test_c5_replay_as_stated(c4):
         eng.replay_arrivals(buf[: n * L], L, bad)
     d2 = eng.replay_arrivals(buf[: 2000 * L], L, arrival[:2000], max_batch=1 << 40)[0]
     assert np.array_equal(d2, base[2][:2000])
+
+
+@pytest.mark.gpuperf
+def test_c5_replay_latency_slo(c4):
+    """The wall-clock half of config 5 (never part of -m gpu): the replay keeps up with 150 k chunks/s and p99 (arrival ->
+    decision on the host) stays below the 1 ms SLO, p50 below 0.3 ms.  A capability of the path: one stall of the box
+    (>= 12 ms of the 1.2 s hold 1 % of the chunks) is retried."""
+    dep, tgt, eng, buf, offs, lens, base = c4
+    rate, n, L, arrival = _c5_arrivals(c4)
+    for attempt in range(3):
+        dec, lat, call_reads, call_service, elapsed = eng.replay_arrivals(buf[: n * L], L, arrival, max_batch=16384)
+        assert elapsed >= 1.0 and n / elapsed >= 0.98 * rate  # kept up with the arrivals
+        p50, p99 = np.percentile(lat, 50), np.percentile(lat, 99)
+        print("c5 replay attempt %d: p50 %.3f ms, p99 %.3f ms, %d calls" % (attempt, p50 * 1e3, p99 * 1e3, len(call_reads)))
+        if p99 < 1e-3:
+            break
+    assert p99 < 1e-3, "p99 %.3f ms" % (p99 * 1e3)
+    assert p50 < 0.3e-3
 
 
 @pytest.fixture(scope="module")
