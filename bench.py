@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured: 6.5 TB/s streaming, 6.8-6.9 TB/s random rows (profiles/hbm_peak.hip)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); what the box of the run delivers on random whole-block gathers is measured live (roofline.read_peak_probe)
 METRIC = "reads/sec (360bp prefixes classified vs IBF, unblock/keep decisions)"
 # test hook (tests/test_bench_ranks.py only; the line then carries "test_reads_divisor"): every leg's default batch divided by
 # this, so that the full default run -- headline + other_configs -- fits a unit test
@@ -365,8 +365,24 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         if tj.get("hbm_bytes_per_read") and not bin_sharded and read_len == default_len:
             traffic = tj["hbm_bytes_per_read"] * n_reads
             traffic_source = "replayed: profiles/traffic.json (%s), per read x reads per launch" % tj.get("source", "rocprofv3 --pmc, separate passes")
-        probe = load_json("ceilings.json").get(name, {})
         decisions = t_dec.cpu().numpy()
+        # read peak of THIS device for the dominant filter's access pattern, measured now: random whole-block gathers from the
+        # same table with no compute attached (rb_dibf_probe_read_peak, rb_probe.hip), 12 and 24 loads in flight per wave
+        probe = None
+        if not bin_sharded and not os.environ.get("RB_BENCH_NO_PROBE"):
+            dom = max(filters, key=lambda f: f.info["bin_width"])
+            bb = dom.device_stride() * 8
+            row = 4096 if bb >= 3072 else 1024 if bb >= 1024 else 128 if bb >= 128 else 0
+            if row:
+                try:
+                    ntl = dom.info["n_blocks"] * bb > (512 << 20)  # the engine's own rule (rb_engine_set_nt_threshold)
+                    runs = [(dom.probe_read_peak(row, ntl, lif, target_ms=150.0), lif) for lif in (12, 24)]
+                    (gb, pms), lif = max(runs)
+                    probe = {"GBps": gb, "row_bytes": row, "block_bytes": bb, "nontemporal": bool(ntl), "loads_in_flight_per_wave": lif,
+                             "run_ms": pms, "table_bytes": dom.info["n_blocks"] * bb,
+                             "source": "rb_dibf_probe_read_peak: this run, this device, this filter's table; no compute attached"}
+                except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
+                    probe = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
 
         # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- and two-word blocks with a
         # table of 1.25 (reads of up to 384 k-mers that fill their kernel shape) or 6 MiB up to 48-128 MiB by kernel shape (or one-word blocks of any size and two-word blocks with reads of up to 512 k-mers: the no-clock form of that kernel) take
@@ -393,12 +409,10 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 "kernel": " + ".join(sorted(forms)), "avg_kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_read": bytes_per_read,
                 "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
-        if probe.get("GBps"):
-            # the same access pattern with no compute attached (profiles/hbm_peak.hip / gather_probe.hip): a reference
-            # point for what this chip delivers on the pattern, NOT an upper bound (K1 keeps more gathers in flight)
-            roof["no_compute_probe_GBps"] = probe["GBps"]
-            roof["vs_no_compute_probe"] = achieved / probe["GBps"]
-            roof["no_compute_probe_source"] = probe.get("source")
+        if probe:
+            roof["read_peak_probe"] = probe
+            if probe.get("GBps"):
+                roof["frac_of_measured_read_peak"] = achieved / probe["GBps"]
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
         if table_bytes < (256 << 20) * 4:
             roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "

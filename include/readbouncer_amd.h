@@ -423,6 +423,15 @@ RB_API int rb_engine_set_host_slice_bytes(rb_engine *e, uint64_t slice_bytes);
 RB_API int rb_engine_set_timing(rb_engine *e, int enabled);
 RB_API int rb_engine_kernel_time(rb_engine *e, double *total_ms, uint64_t *n_calls);
 
+/* Measurement aid, NOT part of the classify path (no reference counterpart): what this device delivers for the access pattern
+ * of the wide count kernels -- random gathers of whole rows of row_bytes (128, 1024 or 4096) from the first table_bytes (0 = all)
+ * of the filter's own table in HBM, 16 bytes per lane, loads_in_flight (12 or 24) wave instructions issued back to back,
+ * nontemporal as rb_engine_set_nt_threshold would choose, no compute attached; runs of about target_ms (0 = 200), best of three.
+ * bench.py calls it on the filter it has just timed so that `roofline` carries a same-box, same-run reference point
+ * (`read_peak_probe`) beside the 8 TB/s spec figure. */
+RB_API int rb_dibf_probe_read_peak(rb_dibf *f, uint64_t table_bytes, uint32_t row_bytes, int nontemporal, uint32_t loads_in_flight,
+                                   double target_ms, double *gbps_out, double *ms_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -119,6 +119,7 @@ SIGNATURES = {
     "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "rb_dibf_probe_read_peak": (_int, [_vp, _u64, _u32, _int, _u32, _dbl, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }
 
 _lib = None
@@ -271,6 +272,13 @@ class DeviceIBF:
 
     def device_stride(self):
         return lib().rb_dibf_device_stride(self.h)
+
+    def probe_read_peak(self, row_bytes, nontemporal, loads_in_flight=12, table_bytes=0, target_ms=200.0):
+        """measurement aid: GB/s of random whole-row gathers from this filter's table with no compute attached -> (GB/s, ms)"""
+        g, ms = _dbl(0.0), _dbl(0.0)
+        _check(lib().rb_dibf_probe_read_peak(self.h, table_bytes, row_bytes, int(bool(nontemporal)), loads_in_flight, target_ms,
+                                             C.byref(g), C.byref(ms)), "rb_dibf_probe_read_peak")
+        return g.value, ms.value
 
     def resize_bins(self, new_bins):
         h = C.c_void_p()
