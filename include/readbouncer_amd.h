@@ -121,7 +121,11 @@ RB_API int rb_dibf_clone_to(const rb_dibf *src, int device, rb_dibf **out);
  * between two GPUs of a node), 0 for the runtime's staged path or a same-device copy; *seconds = wall time of the copy */
 RB_API int rb_dibf_clone_to_ex(const rb_dibf *src, int device, rb_dibf **out, int *used_peer, double *seconds);
 RB_API int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info);
+/* The device image itself.  Engines that keep a merged copy of several filters (rb_engine_set_merge) notice changes made through
+ * rb_dibf_insert / rb_dibf_add_sequence / rb_dibf_fill_synth by themselves; a caller that WRITES through this pointer calls
+ * rb_dibf_touch afterwards (with its writes complete), or merged copies keep serving the old bits. */
 RB_API void *rb_dibf_device_words(rb_dibf *f);
+RB_API int rb_dibf_touch(rb_dibf *f);
 /* words between consecutive blocks of the device image (see above) */
 RB_API uint64_t rb_dibf_device_stride(const rb_dibf *f);
 RB_API int rb_dibf_device(const rb_dibf *f);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "rb_dibf_download": (_int, [_vp, _pp]),
     "rb_dibf_get_info": (_int, [_vp, C.POINTER(IbfInfo)]),
     "rb_dibf_device_words": (_vp, [_vp]),
+    "rb_dibf_touch": (_int, [_vp]),
     "rb_dibf_device_stride": (_u64, [_vp]),
     "rb_dibf_device": (_int, [_vp]),
     "rb_dibf_free": (None, [_vp]),
@@ -147,11 +148,14 @@ def _preload_hip_runtime():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        # RB_AMD_LIBRARY: another build of the SAME library (tests load the -DRB_TESTING build in a child process); never a
+        # different implementation -- the symbol table below is checked either way
+        path = os.environ.get("RB_AMD_LIBRARY") or LIB_PATH
+        if not os.path.exists(path):
             raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                              "(hipcc --offload-arch=gfx950); there is no fallback implementation" % LIB_PATH)
+                              "(hipcc --offload-arch=gfx950); there is no fallback implementation" % path)
         _preload_hip_runtime()
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res

@@ -477,6 +477,12 @@ int rb_dibf_get_info(const rb_dibf *f, rb_ibf_info *info)
 }
 
 void *rb_dibf_device_words(rb_dibf *f) { return f ? f->d_words : nullptr; }
+int rb_dibf_touch(rb_dibf *f)
+{
+    if (!f) return rb::fail(RB_ERR_INVALID_ARG, "null filter");
+    f->version.fetch_add(1);
+    return RB_OK;
+}
 uint64_t rb_dibf_device_stride(const rb_dibf *f) { return f ? f->stride : 0; }
 int rb_dibf_device(const rb_dibf *f) { return f ? f->device : -1; }
 
@@ -517,10 +523,13 @@ int rb_dibf_fill_synth(rb_dibf *f, uint64_t seed)
     const uint64_t used = f->geo.n_blocks * f->geo.bin_width;
     const uint64_t rem = f->geo.n_bins & 63;
     const uint64_t last_mask = rem ? ((1ULL << rem) - 1) : ~0ULL;
+    // the version moves before the first write AND after the last one has landed: an engine that copies the table into a merged
+    // group in between records the intermediate number and finds its copy stale at its next call
     f->version.fetch_add(1);
     RB_HIP(hipMemset(f->d_words, 0, dibf_device_words(f) * 8));
     RB_HIP(launch_fill_synth(f->d_words, used, (uint32_t)f->geo.bin_width, (uint32_t)f->stride, last_mask, seed, nullptr));
     RB_HIP(hipDeviceSynchronize());
+    f->version.fetch_add(1);
     return RB_OK;
 }
 
@@ -588,6 +597,7 @@ int rb_dibf_insert(rb_dibf *f, const char *seq, size_t len, const uint64_t *star
     if (e == hipSuccess) e = hipDeviceSynchronize();
     d_seq.release();
     d_tab.release();
+    f->version.fetch_add(1);  // (before and after the writes, see rb_dibf_fill_synth)
     if (e != hipSuccess) return rb::fail(RB_ERR_HIP, std::string("insert: ") + hipGetErrorString(e));
     return RB_OK;
 }
@@ -628,23 +638,28 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) e->wall_clock_khz = (uint32_t)khz;
         else (void)hipGetLastError();
     }
-    // RB_REVCOMP_OF_N=4: the other candidate of the recalled reverse-complement-of-N rule (ibf_spec.h) for a whole process --
-    // the CLI and the C++ mirror create their engines themselves -- without a rebuild; rb_engine_set_revcomp_of_n is the API
+    // Process-wide switches read from the environment -- for the CLI and the C++ mirror, which create their engines themselves
+    // (RB_REVCOMP_OF_N=4: the other candidate of the recalled reverse-complement-of-N rule, ibf_spec.h; the others pick kernel forms
+    // for A/B measurements and never change a result).  Each has a setter in the API.  Every override that was ACCEPTED is named in
+    // rb_last_warning() of the creating thread, so that a stray variable cannot change behaviour without a trace.
+    std::string accepted;
+    auto note = [&](const char *name, const char *v) { accepted += std::string(accepted.empty() ? "" : ", ") + name + "=" + v; };
     if (const char *v = std::getenv("RB_REVCOMP_OF_N")) {
-        if (std::atoi(v) == 3 || std::atoi(v) == 4) e->revcomp_of_n = (uint32_t)std::atoi(v);
+        if (std::atoi(v) == 3 || std::atoi(v) == 4) { e->revcomp_of_n = (uint32_t)std::atoi(v); note("RB_REVCOMP_OF_N", v); }
     }
     if (const char *v = std::getenv("RB_MERGE")) {  // A/B switch for measurements; rb_engine_set_merge is the API
-        if (std::atoi(v) >= 0 && std::atoi(v) <= 2) e->merge_mode = std::atoi(v);
+        if (std::atoi(v) >= 0 && std::atoi(v) <= 2) { e->merge_mode = std::atoi(v); note("RB_MERGE", v); }
     }
-    if (const char *v = std::getenv("RB_MERGE_MAX_BYTES")) e->merge_max_bytes = std::strtoull(v, nullptr, 10);
+    if (const char *v = std::getenv("RB_MERGE_MAX_BYTES")) { e->merge_max_bytes = std::strtoull(v, nullptr, 10); note("RB_MERGE_MAX_BYTES", v); }
     if (const char *v = std::getenv("RB_PHASE_MAX_SLICES")) {
-        if (std::atoi(v) >= 1 && std::atoi(v) <= 32) e->phase_max_slices = (uint32_t)std::atoi(v);
+        if (std::atoi(v) >= 1 && std::atoi(v) <= 32) { e->phase_max_slices = (uint32_t)std::atoi(v); note("RB_PHASE_MAX_SLICES", v); }
     }
     if (const char *v = std::getenv("RB_PHASE_SLICE_LOG2")) {
-        if (std::atoi(v) >= 1 && std::atoi(v) <= 26) e->phase_slice_log2 = (uint32_t)std::atoi(v);
+        if (std::atoi(v) >= 1 && std::atoi(v) <= 26) { e->phase_slice_log2 = (uint32_t)std::atoi(v); note("RB_PHASE_SLICE_LOG2", v); }
     }
-    if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) e->phase_xcd_skew = std::atoi(v) != 0;
-    if (const char *v = std::getenv("RB_SIX_TILES")) e->six_tile_kernel = std::atoi(v);
+    if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
+    if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
+    rb::set_warning(accepted.empty() ? std::string() : "rb_engine_create: environment overrides in effect: " + accepted);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->d_parts.resize(e->filters.size());
     const size_t n_aux = std::min<size_t>(3, e->filters.size() - 1);

@@ -122,12 +122,17 @@ int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *
         std::vector<void *> streams(n_devices, nullptr);
         std::vector<bool> need_file(n_devices, false);
         const auto t0 = std::chrono::steady_clock::now();
-        // test hook (tests/test_gpu_parity.py): RB_POOL_TEST_FAIL_CLONE=start|finish makes every device-to-device copy
-        // "fail" at that step, so that the ladder below -- peer copy, staged copy, own file stream -- is walked on a box
-        // where the copies themselves cannot fail
+        // Fault injection, compiled into the TESTING build of the library only (make testing: libreadbouncer_amd_testing.so,
+        // -DRB_TESTING): RB_POOL_TEST_FAIL_CLONE=start|finish makes every device-to-device copy "fail" at that step, so that the
+        // ladder below -- peer copy, staged copy, own file stream -- is walked on a box where the copies themselves cannot fail
+        // (tests/test_gpu_parity.py runs that build in a child process).  The product library has no such switch.
+#ifdef RB_TESTING
         const char *inject = std::getenv("RB_POOL_TEST_FAIL_CLONE");
         const bool fail_start = inject && std::strcmp(inject, "start") == 0;
         const bool fail_finish = inject && std::strcmp(inject, "finish") == 0;
+#else
+        const bool fail_start = false, fail_finish = false;
+#endif
         for (size_t d = 1; d < n_devices; ++d) {
             rb_dibf *f = nullptr;
             int peer = 0;

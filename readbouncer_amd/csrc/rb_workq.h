@@ -3,6 +3,7 @@
 // on, and the pick of the least loaded worker.  The reference's counterpart is N classification threads popping one
 // SafeQueue (src/main/adaptive_sampling.hpp:745-751, src/util/SafeQueue.hpp:14).
 #pragma once
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -108,8 +109,10 @@ private:
 };
 
 // Picks workers for the parts of a call and queues them.  Callers on different host threads only meet inside dispatch():
-// an unsplit call goes to the least loaded worker (ties: round-robin from a cursor), a call of several parts to consecutive
-// workers from the cursor on, each part behind whatever that worker still has queued (FIFO per worker).
+// the `parts` parts of a call go to the `parts` least loaded workers (ties: round-robin from a cursor that moves on past the
+// last worker chosen), each part behind whatever that worker still has queued (FIFO per worker).  An unsplit call is the
+// case parts == 1; a call of as many parts as there are workers takes them all.  (Until round 3 a multi-part call always
+// started at the cursor without moving it: concurrent 2-part calls on 8 workers all queued on the same two.)
 class Dispatcher {
 public:
     explicit Dispatcher(std::vector<Worker *> workers) : workers_(std::move(workers)) {}
@@ -119,20 +122,32 @@ public:
     {
         std::lock_guard<std::mutex> lock(mu_);
         const size_t nw = workers_.size();
-        size_t first = next_ % nw;
-        if (parts == 1) {
-            size_t best = ~(size_t)0;
-            for (size_t k = 0; k < nw; ++k) {
-                const size_t i = (next_ + k) % nw;
-                const size_t l = workers_[i]->load();
-                if (l < best) { best = l; first = i; }
-            }
-            next_ = (first + 1) % nw;
+        if (parts > nw) parts = nw;
+        // workers in cursor order with their loads; a stable selection of the `parts` smallest keeps the round-robin among ties
+        std::vector<size_t> order(nw), load(nw);
+        for (size_t k = 0; k < nw; ++k) {
+            order[k] = (next_ + k) % nw;
+            load[k] = workers_[order[k]]->load();
         }
+        std::vector<size_t> pick;  // positions in `order`
+        std::vector<bool> taken(nw, false);
+        for (size_t p = 0; p < parts; ++p) {
+            size_t best = nw;
+            for (size_t k = 0; k < nw; ++k)
+                if (!taken[k] && (best == nw || load[k] < load[best])) best = k;
+            taken[best] = true;
+            pick.push_back(best);
+        }
+        size_t last = 0;
+        for (size_t k : pick) last = std::max(last, k);
+        next_ = (order[last] + 1) % nw;
         job.pending = parts;  // no worker sees `job` before the first submit
-        for (size_t k = 0; k < parts; ++k) {
-            const size_t w = (first + k) % nw;
-            workers_[w]->submit(Task{make_task(k, w), &job});
+        size_t part = 0;
+        for (size_t k = 0; k < nw; ++k) {  // parts in cursor order: part 0 on the first chosen worker after the cursor
+            if (!taken[k]) continue;
+            const size_t w = order[k];
+            workers_[w]->submit(Task{make_task(part, w), &job});
+            ++part;
         }
     }
 

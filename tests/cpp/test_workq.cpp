@@ -102,6 +102,30 @@ int main()
         release = true;
         blocker.wait();
     }
+    // concurrent calls of FEWER parts than there are workers are spread over all of them (until round 3 every multi-part call
+    // started at the same cursor position: four 2-part calls on this pool queued on workers 0 and 1 while 2 and 3 sat idle)
+    {
+        std::atomic<bool> release{false};
+        std::vector<std::unique_ptr<rbq::Job>> jobs;
+        std::vector<std::atomic<int>> hits(W);
+        for (auto &x : hits) x = 0;
+        for (size_t j = 0; j < W / 2; ++j) {
+            jobs.emplace_back(new rbq::Job());
+            disp.dispatch(2, *jobs.back(), [&](size_t, size_t w) -> std::function<int()> {
+                ++hits[w];  // counted at dispatch: which worker each part was queued on
+                return [&] { while (!release) std::this_thread::sleep_for(std::chrono::microseconds(50)); return 0; };
+            });
+        }
+        for (size_t w = 0; w < W; ++w) CHECK(hits[w] == 1);  // W/2 calls x 2 parts: one part per worker
+        // one more 2-part call while every worker holds one blocked part: it still takes two DIFFERENT workers
+        rbq::Job extra;
+        std::vector<int> where;
+        disp.dispatch(2, extra, [&](size_t, size_t w) -> std::function<int()> { where.push_back((int)w); return [] { return 0; }; });
+        CHECK(where.size() == 2 && where[0] != where[1]);
+        release = true;
+        for (auto &j : jobs) j->wait();
+        extra.wait();
+    }
     // shutdown runs what is queued
     {
         std::atomic<int> done{0};

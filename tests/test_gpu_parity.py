@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Bit-exact (integer/bit work).  Run on the MI355X box with `-m gpu`."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -10,6 +11,8 @@ pytestmark = pytest.mark.gpu
 from oracle import pyoracle as po
 from readbouncer_amd import capi
 from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 READ_354 = "AAAAAAAACCCCCCCCCGAGAGAGGAGAGAGGAGAGAGAGAGCCCCAAAAGAGAGGAGA" * 6
 
@@ -504,18 +507,37 @@ def test_pool_shards_reads_across_engines():
             pool.destroy()
         # the fall-back ladder of rb_pool_create_from_files, walked by an injected failure (the copies themselves cannot
         # fail on this box): a clone refused at its start, or lost at its end, makes that device stream the file itself --
-        # the pool comes up the same and classifies the same (code that never ran before an 8-GPU node)
+        # the pool comes up the same and classifies the same (code that never ran before an 8-GPU node).
+        # The injection exists in the TESTING build of the library only (-DRB_TESTING, libreadbouncer_amd_testing.so): a child
+        # process loads that build; the product library ignores the variable (checked last).
+        import subprocess
+        np.save(os.path.join(tmp, "buf.npy"), buf), np.save(os.path.join(tmp, "offs.npy"), offs), np.save(os.path.join(tmp, "lens.npy"), lens)
+        np.save(os.path.join(tmp, "mc.npy"), exp_max), np.save(os.path.join(tmp, "dec.npy"), exp_dec)
+        child = ("import os, sys, numpy as np\n"
+                 "sys.path.insert(0, %r)\n"
+                 "from readbouncer_amd import capi\n"
+                 "t = %r\n"
+                 "L = lambda n: np.load(os.path.join(t, n + '.npy'))\n"
+                 "pool = capi.Pool.from_files([0, 0, 0], [os.path.join(t, 'f0.ibf')], [os.path.join(t, 'f1.ibf')])\n"
+                 "assert pool.size() == 3\n"
+                 "pool.set_min_split(500)\n"
+                 "mc, best, dec, st = pool.classify(L('buf'), L('offs'), L('lens'))\n"
+                 "assert np.array_equal(mc, L('mc')) and np.array_equal(dec, L('dec'))\n"
+                 "pool.destroy()\n"
+                 "print('ladder ok', os.environ.get('RB_POOL_TEST_FAIL_CLONE'))\n") % (ROOT, tmp)
+        testing_lib = os.path.join(ROOT, "readbouncer_amd", "libreadbouncer_amd_testing.so")
+        assert os.path.exists(testing_lib), "build() makes the testing build next to the product library"
         for where in ("start", "finish"):
-            os.environ["RB_POOL_TEST_FAIL_CLONE"] = where
-            try:
-                pool = capi.Pool.from_files([0, 0, 0], paths[:1], paths[1:])
-            finally:
-                del os.environ["RB_POOL_TEST_FAIL_CLONE"]
-            assert pool.size() == 3
-            pool.set_min_split(500)
-            mc, best, dec, st = pool.classify(buf, offs, lens)
-            assert np.array_equal(mc, exp_max) and np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), where
-            pool.destroy()
+            env = dict(os.environ, RB_POOL_TEST_FAIL_CLONE=where, RB_AMD_LIBRARY=testing_lib)
+            r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0 and "ladder ok " + where in r.stdout, (where, r.stdout[-500:], r.stderr[-1500:])
+        os.environ["RB_POOL_TEST_FAIL_CLONE"] = "start"  # the product library has no such switch: nothing changes
+        try:
+            pool = capi.Pool.from_files([0, 0, 0], paths[:1], paths[1:])
+        finally:
+            del os.environ["RB_POOL_TEST_FAIL_CLONE"]
+        assert pool.size() == 3
+        pool.destroy()
         with pytest.raises(capi.RBError):
             capi.Pool.from_files([0, 0], [os.path.join(tmp, "missing.ibf")], [])
     # a clone is a bit-identical replica
