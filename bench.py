@@ -384,29 +384,21 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
                     probe = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
 
-        # which form of K1 the engine plans for these filters (rb_engine.hip, plan_geometry): one- and two-word blocks with a
-        # table of 1.25 (reads of up to 384 k-mers that fill their kernel shape) or 6 MiB up to 48-128 MiB by kernel shape (or one-word blocks of any size and two-word blocks with reads of up to 512 k-mers: the no-clock form of that kernel) take
-        # the phased kernel, everything else the plain one; merged tables as the engine reports them
-        kmers = max(0, read_len - int(filters[0].info["kmer_size"]) + 1)
-        short = kmers <= 384
-
-        def phased(f):
-            W, tb = f.info["bin_width"], f.info["n_blocks"] * f.device_stride() * 8
-            if W in (3, 4) and f.info["n_hash"] == 3:  # both-strands build for stride-4 blocks
-                return (kmers <= 256 and tb <= (48 << 20)) or (kmers <= 512 and (6 << 20) <= tb <= (48 << 20))
-            cap = ((128 if W == 1 else 96 if kmers <= 256 else 64) if short else (64 if W == 1 else 48)) << 20
-            return W <= 2 and f.info["n_hash"] == 3 and (((5 << 18) if short else (6 << 20)) <= tb <= cap or W == 1 or kmers <= 512)
-        n_merged = eng.merge_info()[1] if not bin_sharded else 0
-        forms = set()
-        if n_merged:
-            # a merged table of two to four words is held by one lane of the both-strands builds of the phased kernel
-            narrow = n_merged == len(filters) and sum(f.info["bin_width"] for f in filters) <= 4 and kmers <= 512
-            forms.add("ibf_count_max_phased_kernel" if narrow else "ibf_count_max_merged_kernel")
-        if n_merged < len(filters):  # (which filters a partial merge leaves out is the engine's business: name both forms then)
-            forms |= {"ibf_count_max_phased_kernel" if phased(f) else "ibf_count_max_kernel" for f in filters}
+        # which form of K1 the engine launched for these filters on this batch, as the engine itself reports it (rb_engine_plan):
+        # kernel, and for the clock-phased form the row of the planner's table with its slice size and window length
+        plans = []
+        if not bin_sharded:
+            for fi in range(len(filters)):
+                try:
+                    pl = eng.plan(fi, n_reads, read_len)
+                    plans.append({k: pl[k] for k in ("kernel", "table_bytes", "merged_members", "phased", "phase_shape_name", "phase_slice_log2",
+                                                     "phase_slices", "phase_window_ticks", "column_slices", "nontemporal") if pl[k] not in (0, "")})
+                except Exception as ex:  # noqa: BLE001
+                    plans.append({"error": str(ex)[:120]})
+        forms = {pl.get("kernel", "?") for pl in plans} or {"ibf_count_max_kernel"}
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": " + ".join(sorted(forms)), "avg_kernel_ms": avg_kernel_s * 1e3,
+                "kernel": " + ".join(sorted(forms)), "plan": plans, "avg_kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_read": bytes_per_read,
                 "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
         if probe:

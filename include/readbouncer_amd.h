@@ -411,6 +411,24 @@ RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_serial_table_bytes(rb_engine *e, uint64_t table_bytes);
 RB_API int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_table_bytes, uint32_t base_ticks,
                                 uint32_t ticks_per_mib, uint32_t min_reads);
+/* What the engine would launch for filter `filter_index` (deplete filters first) on a batch of n_reads reads of at most max_len
+ * bases, with its current settings: kernel form, geometry, and -- for the phased form -- the row of the planner's table
+ * (readbouncer_amd/csrc/rb_phase_plan.h) with the slice size and window length it gives.  For bench.py's roofline line (which
+ * kernel was timed), profiles/phase_rule_check.py (rule against measured best) and the tests; no reference counterpart. */
+typedef struct rb_plan_info {
+    char kernel[48];             /* ibf_count_max_kernel | _phased_kernel | _merged_kernel | _split_kernel */
+    uint64_t table_bytes;        /* of the table the lookups go to (the merged copy when merged_members > 0) */
+    uint32_t block_words, stride_words;
+    uint32_t merged_members;     /* > 0: the filter is served from a merged table of that many filters */
+    uint32_t lanes_per_block_log2, words_per_lane, column_slices, counter_planes, nontemporal;
+    uint32_t split_waves;        /* latency form: waves per workgroup (0: throughput form) */
+    uint32_t phased;             /* 1: clock-phased gathers */
+    uint32_t phase_shape;        /* rbplan::PhaseShape */
+    char phase_shape_name[64];
+    uint32_t phase_slice_log2, phase_slices, phase_window_ticks;  /* window length in 10 ns ticks */
+} rb_plan_info;
+RB_API int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads, uint32_t max_len, rb_plan_info *out);
+
 /* How the phased form cuts a table, for tests and experiments: slices of 2^slice_log2 bytes (0 = the built-in rule, 0.5 to 4 MiB
  * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and
  * never more than max_slices (1-32, default 32; a table that would need more gets larger slices).  Results are identical. */

@@ -24,6 +24,14 @@ class BatchDesc(C.Structure):
                 ("chunk_start", C.c_uint32), ("chunk_length", C.c_uint32), ("d_read_ids", C.c_void_p)]
 
 
+class PlanInfo(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("table_bytes", C.c_uint64), ("block_words", C.c_uint32), ("stride_words", C.c_uint32),
+                ("merged_members", C.c_uint32), ("lanes_per_block_log2", C.c_uint32), ("words_per_lane", C.c_uint32),
+                ("column_slices", C.c_uint32), ("counter_planes", C.c_uint32), ("nontemporal", C.c_uint32), ("split_waves", C.c_uint32),
+                ("phased", C.c_uint32), ("phase_shape", C.c_uint32), ("phase_shape_name", C.c_char * 64),
+                ("phase_slice_log2", C.c_uint32), ("phase_slices", C.c_uint32), ("phase_window_ticks", C.c_uint32)]
+
+
 class IbfCompare(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("file_bits", "rebuilt_bits", "new_bits", "payload_bits")]
 
@@ -120,6 +128,7 @@ SIGNATURES = {
     "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
+    "rb_engine_plan": (_int, [_vp, _sz, _sz, _u32, C.POINTER(PlanInfo)]),
     "rb_dibf_probe_read_peak": (_int, [_vp, _u64, _u32, _int, _u32, _dbl, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }
 
@@ -434,6 +443,14 @@ class Engine:
         t, f, b = C.c_uint32(), C.c_uint32(), C.c_uint64()
         _check(lib().rb_engine_merge_info(self.h, C.byref(t), C.byref(f), C.byref(b)), "rb_engine_merge_info")
         return t.value, f.value, b.value
+
+    def plan(self, filter_index, n_reads, max_len):
+        """what the engine would launch for that filter on such a batch -> dict (rb_plan_info)"""
+        p = PlanInfo()
+        _check(lib().rb_engine_plan(self.h, filter_index, n_reads, max_len, C.byref(p)), "rb_engine_plan")
+        d = {k: getattr(p, k) for k, _ in PlanInfo._fields_}
+        d["kernel"], d["phase_shape_name"] = p.kernel.decode(), p.phase_shape_name.decode()
+        return d
 
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")

@@ -91,6 +91,8 @@ struct CountLaunch {
     int nt;                       // non-temporal table gathers (tables beyond the Infinity Cache)
     PhaseCfg phase;               // throughput form on narrow filters: clock-phased gathers (n_slices == 0: off)
     NarrowMerge narrow;           // phased form on two- to four-word blocks: columns -> members (the engine fills it; n = 1: one filter)
+    int phase_shape;              // engine bookkeeping (rbplan::PhaseShape of the planner's row for this launch; the kernels do not read it)
+    uint32_t phase_slice_log2, phase_ticks;  // ... the slice size and window length the planner chose (10 ns ticks), for rb_engine_plan
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)

@@ -9,14 +9,17 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 
 #include "rb_device.h"
+#include "rb_phase_plan.h"
 
 using namespace rb;
+using namespace rbplan;
 
 #define RB_HIP(call)                                                                              \
     do {                                                                                          \
@@ -961,150 +964,6 @@ static int ensure_thresholds(rb_engine *e, uint32_t max_len, double r, double co
     return RB_OK;
 }
 
-// Slice size and window length of the clock-phased gathers, by kernel shape, block width and table size.  Measured on
-// single filters of 7-96 MiB (profiles/r03/slice_size.txt, sessions 25-26; K1 ms per 1 M reads) after the waves had learnt to
-// serve the slices in the order of the clock (phase_next_slice), which made the optima flat (+-100 ticks cost 1-3 %):
-//  - the best window length falls with the number of slices n as CYCLE / n: what is constant is the length of a whole cycle
-//    over the table, 33-60 us -- the time the resident waves need for one round of their lookups -- so a lookup of any slice
-//    waits at most one cycle whatever n is (best windows, one-word blocks, 250 bp, 4 MiB slices: n = 3: 1500 ticks, 4: 1000-1200,
-//    5: 850-1000, 6: 850, 8: 700, 10-12: 500, 16: 400, 24: 250);
-//  - a slice of 4 MiB (one XCD's whole L2) is the better cut from 10 MiB on for one-word blocks, from 18.5 MiB on for two-word
-//    blocks (with 2 MiB slices their optimum is a narrow dip that moves with the table, with 4 MiB slices a flat region: the
-//    README deplete filter, 122 bins = 18.9 MiB, 360 bp: 15.1-15.5 ms at 800-1000 ticks against 14.6 / 15.2 / 16.1 at 350 / 400 / 450);
-//    smaller tables do better with 2 MiB slices.  1 MiB slices always lose
-//    (more passes over a read's lookups, nothing gained in the L2);
-//  - with that the phased form wins over the plain kernel up to 64-128 MiB (32 slices are the kernels' limit): one-word blocks at
-//    250 bp 7.3-7.8 ms up to 10 MiB, 9.4 at 20, 10.9 at 32, 14.8 at 64, 18.3 at 96 MiB, where the plain kernel takes 10.4-24.8.
-//    Rounds 1-2 and the first half of round 3 cut every table into at most 8 slices by a shift alone (1 MiB slices at 8 MiB,
-//    2 MiB at 16 MiB) with a window length fitted at 10 and 20 MB only: 10.5 / 11.1 / 14.1 ms at 8 / 16 / 32 MiB.
-//  - blocks of four and eight words gain nothing from phases at any size (every pass over the slices issues four / eight
-//    times the load instructions per lookup of the one-word kernel: 8 MiB table 12.4 against 12.1 ms plain, 32 MiB 26.7 against
-//    21.6) and keep the plain kernel.
-// The rules below were fitted with reads that fill their kernel shape (238 k-mers in four tiles, 348 in six, 488 in two rounds of
-// four); a wave with fewer k-mers is through its round sooner, and the best cycle shrinks with it (session 38: 150 bp reads,
-// one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp; 32 MiB: 400 against 700).  Factor on the cycle, 0.5 ... 1.
-static double phase_fill(int shape, uint32_t kmers)
-{
-    const double fit = (shape == 1 || shape == 5 || shape == 6) ? 238.0 : (shape == 3 || shape == 4 || shape == 7) ? 348.0 : shape == 2 ? 488.0 : 0.0;
-    if (fit == 0.0) return 1.0;  // per-strand tiles of the general build: the work of a round does not depend on the read length
-    return std::min(1.0, std::max(0.5, (double)kmers / fit));
-}
-
-static uint32_t phase_slice_log2(int shape, int lg, uint64_t table_bytes, uint32_t kmers)
-{
-    const double mib = (double)table_bytes / 1048576.0;
-    if (shape == 5) return mib <= 12.0 ? 21 : 22;  // three- and four-word blocks (sessions 44-46, slice_size.txt)
-    if (shape == 6) return mib <= 14.0 ? 21 : 22;  // three-word blocks, <= 256 k-mers: the build with five waves per SIMD (session 53)
-    if (shape == 4 || shape == 7) return mib <= 13.0 ? 21 : 22;
-    // small tables (session 41): even a table that fits an L2 gains from being walked in pieces -- 2 MiB one-word 5.95 -> 5.30 ms
-    // per 1 M reads of 250 bp with 512 KiB slices, two-word 7.0 -> 5.45 (there the both-strands round counts too); 4-6 MiB
-    // tables do best with 1 MiB slices (6 MiB: 8.7 -> 6.95 one-word, 9.6 -> 7.0 two-word).  Short-read shapes only.
-    if ((shape == 1 || shape == 3) && phase_fill(shape, kmers) >= 0.9) {
-        if (mib < (lg == 0 ? 3.5 : 2.5)) return 19;
-        if (mib < 7.0) return 20;
-    } else if ((shape == 1 || shape == 3) && mib < 7.5) {
-        // reads that leave the shape partly empty (session 57): larger pieces -- 1 MiB slices below 3.5 MiB for one-word blocks, 2 MiB
-        // slices otherwise (150 bp: 4 MiB one-word 3.79 -> 3.35 ms, 7 MiB 6.06 -> 4.88; 300 bp: 7 MiB 12.6 -> 8.6)
-        return (lg == 0 && mib < 3.5) ? 20 : 21;
-    }
-    // (session 55, the builds with more waves per SIMD: one-word 360 bp and two-word 250 bp keep 2 MiB slices longer)
-    // (two-word 250 bp: with 2 MiB slices the optimum of 18-24 MiB tables is a narrow dip -- 24 MiB: 9.7 ms at 400 ticks between 12.5 at 325
-    // and 10.9 at 500 --, with 4 MiB slices a flat 9.6-10.1 over 850-1200 ticks: 4 MiB from 17 MiB on)
-    const double switch_mib = lg == 0 ? (shape == 3 ? 17.0 : 10.0) : shape == 1 ? 17.0 : shape == 3 ? 18.5 : 10.0;
-    const double two_mib_below = switch_mib * phase_fill(shape, kmers);
-    return mib < two_mib_below ? 21 : 22;
-}
-
-// shape: 1 = both strands in one round of four tiles (<= 256 k-mers), 3 = one round of six tiles (<= 384), 2 = two rounds of
-// four tiles (<= 512), 0 = the general build.  base + cycle / n, fitted to the best windows of the sweep (for n = 3 ... 24:
-// one-word 250 bp 1500 ... 250-325, 360 bp 1800-2000 ... 250-325; two-word 250 bp 1500 ... 250-325, 360 bp 1800 ... 400;
-// 500 / 1000 bp 1000 ... 450; two-word blocks with 2 MiB slices have one optimum, 325 / 400, for every n).
-static uint64_t phase_window_ticks(int shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
-{
-    double base, cycle;
-    // three- and four-word blocks: <= 256 k-mers: 400 ticks with 2 MiB slices, 500 with 4 MiB; rounds of three tiles: 325 with
-    // 2 MiB slices, 2400 / n but at least 400 with 4 MiB slices (16 MiB: 600, 24 MiB: 400; 28-32 MiB: 20.6 / 22.4 ms at 400 ticks between
-    // 27.5 / 29.7 at 325 and 23.4 / 25.5 at 500 -- session 50)
-    if (shape == 5) return slice_log2 <= 21 ? 400 : 500;
-    if (shape == 6) return slice_log2 <= 21 ? 500 : n_slices <= 4 ? 850 : n_slices <= 8 ? 600 : 500;  // (five waves per SIMD: longer windows)
-    if (shape == 4) return slice_log2 <= 21 ? 325 : std::max<uint64_t>(400, 2400 / std::max(n_slices, 1u));
-    if (shape == 7) return slice_log2 <= 21 ? 400 : std::max<uint64_t>(400, 3400 / std::max(n_slices, 1u));  // (three-word build, five waves: session 59)
-    if (slice_log2 <= 20 && (shape == 1 || shape == 3))  // small tables: flat optima at 200-400 (512 KiB slices) and 325-400 ticks (1 MiB)
-        return lg == 1 ? 400 : slice_log2 <= 19 ? 250 : (shape == 1 ? 325 : 400);
-    if (slice_log2 == 21 && n_slices <= 4 && (shape == 1 || shape == 3) && phase_fill(shape, kmers) < 0.9)
-        return shape == 1 ? 450 : 600;  // small tables, reads that leave the shape partly empty: 2 MiB slices, 400-500 / 500-700 ticks
-    // Session 55: the one-word builds and the two-word 250 bp build are compiled for 8 / 6 / 7 waves per SIMD since then (rb_kernels.hip,
-    // phased_min_waves); more reads per cycle, longer cycles: one-word 250 bp 150 + 5500 / n (was 150 + 4000 / n), 360 bp 150 + 6800 / n
-    // (100 + 5200 / n), two-word 250 bp 100 + 5000 / n (100 + 3700 / n); with 2 MiB slices one-word 250 bp 4600 / n, one-word
-    // 360 bp and two-word 250 bp 500 ticks up to 7 / 9 slices and 400 beyond.
-    if (slice_log2 == 21 && ((shape == 3 && lg == 0) || (shape == 1 && lg == 1)))
-        return n_slices <= (lg == 0 ? 7u : 9u) ? 500 : 400;
-    if (slice_log2 >= 22) {
-        switch (shape) {
-        case 1: base = lg == 0 ? 150.0 : 100.0; cycle = lg == 0 ? 5500.0 : 5000.0; break;
-        case 3: base = 150.0; cycle = lg == 0 ? 6800.0 : 4400.0; break;
-        case 2: base = lg == 0 ? 300.0 : 200.0; cycle = lg == 0 ? 2400.0 : 2500.0; break;  // (one-word: rounds of three tiles at eight waves, session 61)
-        default: base = lg == 0 ? 200.0 : 100.0; cycle = lg == 0 ? 2500.0 : 2000.0; break;
-        }
-    } else {
-        switch (shape) {
-        case 1: base = lg == 0 ? 0.0 : 325.0; cycle = lg == 0 ? 4600.0 : 0.0; break;
-        case 3: base = lg == 0 ? 0.0 : 400.0; cycle = lg == 0 ? 4400.0 : 0.0; break;
-        default: base = lg == 0 ? 0.0 : 450.0; cycle = lg == 0 ? 2400.0 : 0.0; break;
-        }
-    }
-    // two-word 250 bp, 4 MiB slices (session 55): below the optimum the times jump (48 MiB: 12.6 ms at 600 ticks, 17.8 at 500; 64 MiB:
-    // 13.8 at 500, 19.2 at 400): never below 600 ticks up to 12 slices, 500 beyond
-    if (shape == 1 && lg == 1 && slice_log2 >= 22 && phase_fill(shape, kmers) >= 0.9)
-        return (uint64_t)std::max(base + cycle / std::max(n_slices, 1u), n_slices <= 12 ? 600.0 : 500.0);
-    const double t = (base + cycle / std::max(n_slices, 1u)) * phase_fill(shape, kmers);
-    // two-word blocks: below 325 / 400 ticks the times get erratic (64 MiB, 300 bp: 26.0 ms at 352 ticks, 21.5 at 400)
-    const double lo = lg == 0 ? 0.0 : shape == 1 ? 325.0 : shape == 3 ? 400.0 : 0.0;
-    return (uint64_t)std::max(t, lo);
-}
-
-// Up to which table size the phased form beats the plain kernel (which sits at the fabric-request wall from about 64 MiB on),
-// profiles/r03/slice_size.txt: one-word blocks and short reads 127 MiB (22.1 against 25.2 ms at 250 bp, 32.5 against 36.7 at
-// 360 bp); two-word blocks 96 MiB at 250 bp (20.2 / 24.8; even at 127 MiB), 64 MiB at 360 bp (22.2 / 35.1; at 96 MiB the
-// optimum is narrow and the rule misses it); the general build 64 MiB for one-word blocks (500 bp 34.4 / 49.3, 1000 bp
-// 74.6 / 100.3), 48 MiB for two-word blocks (1000 bp 85.9 / 97.4; even at 64 MiB).  Scaled by phase_fill() like the cycle:
-// with half-empty tiles the plain kernel catches up sooner (150 bp, two-word 64 MiB: 14.7 ms phased against 13.8 plain); shapes that are
-// at least 80 % full keep the whole range (430 bp, one-word 64 MiB: 30.7 ms phased against 42.6 plain).
-// ... and from which size on: the short-read shapes from 1.25 MiB (three slices of 512 KiB) when the reads fill the shape, the
-// general build from 6 MiB (500 bp reads: 2 MiB 11.6 -> 11.4 ms, 4 MiB no gain, 6 MiB
-// 17.7 -> 16.1)
-static uint64_t phase_shape_min_bytes(int shape, int lg, double fill)
-{
-    // (session 57, the builds with more waves per SIMD: reads that leave the shape partly empty gain from 2 MiB on with one-word
-    // blocks, from 3 MiB on with two-word blocks -- 4.5 MiB for reads as short as 150 bp, where a 4 MiB table loses: 3.83 against 3.60)
-    if (shape == 1 || shape == 3) return fill >= 0.9 ? (5ull << 18) : lg == 0 ? (2ull << 20) : fill >= 0.75 ? (3ull << 20) : (9ull << 19);
-    // three- and four-word blocks: <= 256 k-mers from 4.5 MiB on (smaller tables take the same round without a clock); rounds of
-    // three tiles from 6 MiB on (4 MiB: 10.8 against 11.1 ms at 360 bp, 16.5 against 14.6 at 500 bp)
-    if (shape == 5) return fill >= 0.8 ? (9ull << 19) : ~0ull;
-    if (shape == 6) return fill >= 0.8 ? (3ull << 20) : ~0ull;  // (4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB)
-    if (shape == 4 || shape == 7) return 6ull << 20;
-    return (shape == 2 && lg == 0) ? (5ull << 20) : (6ull << 20);
-}
-
-static uint64_t phase_shape_max_bytes(int shape, int lg)
-{
-    if (shape == 4 || shape == 5 || shape == 6 || shape == 7) return 48ull << 20;  // 40 MiB: 17.2 against 22.8 ms (250 bp), 25.4 against 33.6 (360 bp); 64 MiB: even
-    if (shape == 1) return (lg == 0 ? 128ull : 96ull) << 20;
-    if (shape == 3) return (lg == 0 ? 128ull : 64ull) << 20;
-    return (lg == 0 ? 64ull : 48ull) << 20;
-}
-
-// A read needs at least one whole cycle over its table's slices, and a cycle is not shorter than the refill of the table: small
-// batches of a large table are served faster by the plain kernel (profiles/r03/phased_batch_size.txt, second part: 64 MiB
-// one-word, 250 bp, 2 049 reads per call 78 us phased against 65 plain, 4 096: 105 / 116; 120 MiB: even at 16 384 reads, 1.11-1.17 x
-// at 65 536).  Tables of up to 32 MiB pay from the first batch above the latency kernel's (rb_engine::phase_min_reads).
-static size_t phase_min_reads_for(uint64_t table_bytes)
-{
-    if (table_bytes > (64ull << 20)) return 32768;
-    if (table_bytes > (32ull << 20)) return 4096;
-    return 0;
-}
-
 // Kernel geometry of one filter for a batch: the rank's word columns (bin-sharded operation), lanes per block, words
 // per lane, counter planes, column slices, and the form of K1 (throughput, or latency with its waves / workgroups per
 // read).  false = this rank owns no column of the filter.
@@ -1149,8 +1008,20 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
         // only (hbm_stride gives one to every filter narrower than 16 words; a bin-sharded rank can reach lg <= 1 on a wider
         // filter, e.g. 3072 bins over 24 ranks -- stride 48 -- and keeps the plain kernel)
         const bool stride_pow2 = (f->stride & (f->stride - 1)) == 0;
-        // (4 / 5: three- and four-word blocks, rounds of three tiles / one round of four; 7 / 6: their three-word builds, five waves per SIMD)
-        const int shape = a.planes > 10 ? 0 : (a.short_only == 5 && a.col_end == 3) ? 6 : (a.short_only == 4 && a.col_end == 3) ? 7 : a.short_only;
+        // the kernel shape this batch takes (CountLaunch::short_only is the kernels' own code for it: 1 / 3 / 2 = at most 256 / 384 /
+        // 512 k-mers per read, 5 / 4 = the same for stride-4 blocks held by one lane; three-word blocks have builds of their own)
+        PhaseShape shape = PhaseShape::General;
+        if (a.planes <= 10) {
+            switch (a.short_only) {
+            case 1: shape = PhaseShape::FourTiles; break;
+            case 2: shape = PhaseShape::Rounds; break;
+            case 3: shape = PhaseShape::SixTiles; break;
+            case 4: shape = a.col_end == 3 ? PhaseShape::Wide3Rounds : PhaseShape::WideRounds; break;
+            case 5: shape = a.col_end == 3 ? PhaseShape::Wide3FourTiles : PhaseShape::WideFourTiles; break;
+            default: break;
+            }
+        }
+        a.phase_shape = (int)shape;
         const bool in_rule_range = table_bytes >= phase_shape_min_bytes(shape, a.lg, phase_fill(shape, kmers)) &&
                                    (double)table_bytes <= (double)phase_shape_max_bytes(shape, a.lg) * (phase_fill(shape, kmers) >= 0.8 ? 1.0 : phase_fill(shape, kmers)) &&
                                    n_reads >= phase_min_reads_for(table_bytes);
@@ -1164,14 +1035,16 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
                                                : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
+            a.phase_slice_log2 = slice_log2;
+            a.phase_ticks = (uint32_t)ticks;
             ticks = std::max<uint64_t>(2, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock (>= 2: 2^32 / ticks must fit 32 bits)
             a.phase.shift = sh;
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
             a.phase.xcd_skew = e->phase_xcd_skew;
-        } else if ((a.lg == 0 || (shape != 0 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
-                    (shape == 5 && phase_fill(shape, kmers) >= 0.8 && table_bytes < (9ull << 19)) ||
-                    (shape == 6 && phase_fill(shape, kmers) >= 0.8 && table_bytes < (3ull << 20))) && e->short_read_kernel) {
+        } else if ((a.lg == 0 || (shape != PhaseShape::General && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
+                    ((shape == PhaseShape::WideFourTiles || shape == PhaseShape::Wide3FourTiles) && phase_fill(shape, kmers) >= 0.8 &&
+                     table_bytes < phase_shape_min_bytes(shape, a.lg, 1.0))) && e->short_read_kernel) {
             // blocks outside the phased range still take that kernel for its both-strands-in-one-round path (one-word blocks
             // always; two-word blocks for reads of up to 512 k-mers; small three- and four-word tables for reads of up to 256:
             // 2 MiB 7.2 -> 6.6 ms, 4 MiB 7.7 -> 6.9): one "slice" that holds every offset, no clock, no waiting
@@ -1344,7 +1217,7 @@ static double est_filter_ms(const rb_engine *e, const rb_dibf *f)
     const uint64_t bytes = f->geo.n_blocks * f->stride * 8;
     const double mib = (double)bytes / 1048576.0;
     const bool phased = f->geo.n_hash == 3 && f->geo.bin_width <= 2 && e->phase_max_bytes && bytes >= e->phase_min_bytes &&
-                        bytes <= std::min<uint64_t>(e->phase_max_bytes, phase_shape_max_bytes(1, f->geo.bin_width == 1 ? 0 : 1));
+                        bytes <= std::min<uint64_t>(e->phase_max_bytes, phase_shape_max_bytes(PhaseShape::FourTiles, f->geo.bin_width == 1 ? 0 : 1));
     // three- and four-word blocks (stride 4) in the both-strands build, 4.5-48 MiB: 8 MiB 9.4, 16 MiB 11.4, 24 MiB 12.7, 40 MiB 17.2
     if (f->geo.n_hash == 3 && f->stride == 4 && e->phase_max_bytes && bytes >= (9ull << 19) && bytes <= (48ull << 20)) return 8.0 + 0.23 * mib;
     if (!phased) return est_plain_ms(mib);
@@ -1650,6 +1523,63 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     e->tickets_dirty = false;  // every launch of this call was accepted (and, on the engine's own stream, has finished)
+    return RB_OK;
+}
+
+// what the engine would launch for filter `filter_index` on a batch of n_reads reads of at most max_len bases
+extern "C" int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads, uint32_t max_len, rb_plan_info *out)
+{
+    if (!e || !out || filter_index >= e->filters.size()) return rb::fail(RB_ERR_INVALID_ARG, "rb_engine_plan: bad argument");
+    std::lock_guard<std::mutex> lock(e->mu);
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    std::memset(out, 0, sizeof *out);
+    if (!e->merged_planned) plan_merged(e);
+    const rb_dibf *f = e->filters[filter_index];
+    rb_dibf as_filter;
+    const MergedGroup *g = nullptr;
+    if (!e->merged.empty() && n_reads > e->split_threshold && e->shard_world == 1 && e->merged_of[filter_index] >= 0 &&
+        !e->merged[e->merged_of[filter_index]]->members.empty())
+        g = e->merged[e->merged_of[filter_index]];
+    if (g) {  // the table the lookups really go to: the group's merged copy, planned like a filter of its width
+        out->merged_members = (uint32_t)g->members.size();
+        as_filter.device = e->device;
+        as_filter.geo = f->geo;
+        as_filter.geo.bin_width = g->width;
+        as_filter.geo.n_bins = g->width * 64;
+        as_filter.stride = hbm_stride(g->width);
+        f = &as_filter;
+    }
+    CountLaunch a{};
+    a.n_reads = (uint32_t)std::min<size_t>(n_reads, 0x7FFFFFFFu);
+    const bool planned = plan_geometry(e, f, n_reads, max_len, a);
+    out->table_bytes = f->geo.n_blocks * f->stride * 8;
+    out->block_words = (uint32_t)f->geo.bin_width;
+    out->stride_words = (uint32_t)f->stride;
+    if (!planned) return RB_OK;  // this rank owns no column of the filter
+    const bool one_lane = (a.lg == 1 && a.short_only >= 1 && a.short_only <= 3) || (a.lg == 2 && (a.short_only == 4 || a.short_only == 5));
+    const bool merged_plain = g && !(g->width <= 4 && a.phase.n_slices && a.split_waves < 2 && a.planes <= 10 && one_lane);
+    out->lanes_per_block_log2 = (uint32_t)a.lg;
+    out->words_per_lane = (uint32_t)a.wpl;
+    out->column_slices = a.n_slices;
+    out->counter_planes = (uint32_t)a.planes;
+    out->nontemporal = (uint32_t)a.nt;
+    out->split_waves = (uint32_t)(a.split_waves >= 2 ? a.split_waves : 0);
+    const char *form = "ibf_count_max_kernel";
+    if (a.split_waves >= 2) form = "ibf_count_max_split_kernel";
+    else if (merged_plain) form = "ibf_count_max_merged_kernel";
+    else if (a.phase.n_slices) form = "ibf_count_max_phased_kernel";
+    std::snprintf(out->kernel, sizeof out->kernel, "%s", form);
+    if (!merged_plain && a.split_waves < 2 && a.phase.n_slices) {
+        out->phase_shape = (uint32_t)a.phase_shape;
+        std::snprintf(out->phase_shape_name, sizeof out->phase_shape_name, "%s", phase_rule((PhaseShape)a.phase_shape, a.lg).name);
+        out->phase_slices = a.phase.n_slices;
+        if (a.phase.inv_ticks) {  // clock-phased (one slice and no clock: the both-strands round of that kernel without waiting)
+            out->phased = 1;
+            out->phase_slice_log2 = a.phase_slice_log2;
+            out->phase_window_ticks = a.phase_ticks;
+        }
+    }
     return RB_OK;
 }
 

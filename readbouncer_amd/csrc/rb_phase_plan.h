@@ -1,0 +1,229 @@
+// rb_phase_plan.h -- the planner of the clock-phased gathers (rb_kernels.hip, "phased form"): for a kernel shape, a block width
+// and a table size, whether the phased form is used at all, how the table is cut into slices and how long a window lasts.
+// Plain C++ (no HIP): rb_engine.hip plans with it, tests/cpp/dump_phase_plan.cpp pins it on a CPU (tests/golden/phase_plan.txt),
+// profiles/phase_rule_check.py holds it against measurements at points BETWEEN the fitted ones and fails when it is off.
+//
+// Everything the planner knows is the ONE table kPhaseRules below: a row per (kernel shape, block width) with named fields.  The
+// functions under it only read that table.  Where the numbers come from (K1 ms per 1 M reads on one MI355X,
+// profiles/r03/slice_size.txt and window_sweep.txt, sessions 25-61):
+//  - the best window length falls with the number of slices n as CYCLE / n: what is constant is the length of a whole cycle
+//    over the table, 33-60 us -- the time the resident waves need for one round of their lookups -- so a lookup of any slice
+//    waits at most one cycle whatever n is (one-word blocks, 250 bp, 4 MiB slices: n = 3: 1500 ticks, 4: 1000-1200, 6: 850,
+//    8: 700, 10-12: 500, 16: 400, 24: 250); after the waves had learnt to serve the slices in the order of the clock
+//    (phase_next_slice) the optima are flat: +-100 ticks cost 1-3 %;
+//  - a slice of 4 MiB (one XCD's whole L2) is the better cut for larger tables, 2 MiB for smaller ones (`four_mib_from_mib`), and
+//    the short-read shapes walk even tables that fit an L2 in pieces of 512 KiB / 1 MiB (`small_full`, session 41: 2 MiB one-word
+//    5.95 -> 5.30 ms); 1 MiB slices lose on everything larger;
+//  - the windows were fitted with reads that FILL their kernel shape (`fit_kmers`: 238 k-mers in four tiles, 348 in six, 488 in
+//    two rounds of four); a wave with fewer k-mers is through its round sooner and the best cycle shrinks with it (session 38:
+//    150 bp reads, one-word 20 MiB: best window 700 ticks against 850-1000 at 250 bp) -- phase_fill(), 0.5 ... 1, scales the
+//    curves, moves the 2 / 4 MiB switch and narrows the range of table sizes;
+//  - beyond `max_bytes` the plain kernel (at the fabric-request wall from about 64 MiB on) is as fast or faster, below
+//    `min_bytes` the phased form has nothing to win; blocks of five and more words gain nothing from phases at any size.
+#pragma once
+#include <algorithm>
+#include <cstddef>
+#include <cstdint>
+
+namespace rbplan {
+
+// Kernel shapes of ibf_count_max_phased_kernel (rb_kernels.hip): how many 64-k-mer tiles per strand a wave holds per round of windows
+enum class PhaseShape : int {
+    General = 0,         // per-strand tiles of the general build (reads of more than 512 k-mers; 16 planes)
+    FourTiles = 1,       // both strands in ONE round of four tiles: reads of up to 256 k-mers (the reference's default 250 bp chunk)
+    Rounds = 2,          // rounds of three (one-word) or four (two-word) tiles: up to 512 k-mers
+    SixTiles = 3,        // ONE round of six tiles: 257-384 k-mers (360 bp reads)
+    WideRounds = 4,      // three- and four-word blocks held by one lane, rounds of three tiles (up to 512 k-mers), four-word build
+    WideFourTiles = 5,   // ... one round of four tiles (up to 256 k-mers), four-word build
+    Wide3FourTiles = 6,  // ... the three-word build of that (five waves per SIMD)
+    Wide3Rounds = 7,     // ... the three-word build of the rounds of three tiles
+};
+constexpr int kPhaseShapes = 8;
+
+constexpr uint64_t operator""_KiB(unsigned long long v) { return v << 10; }
+constexpr uint64_t operator""_MiB(unsigned long long v) { return v << 20; }
+constexpr uint64_t kNever = ~0ull;
+
+// "below this table size (MiB): slices of 2^slice_log2 bytes"; bound 0 ends a list
+struct SliceStep {
+    double below_mib;
+    uint32_t slice_log2;
+};
+// "reads that fill the shape at least this much: phased from this table size on"; evaluated in order, the last row has fill 0
+struct MinStep {
+    double fill_at_least;
+    uint64_t bytes;
+};
+// Window length in 10 ns ticks for one slice size.  Either up to three constants by the number of slices (n <= n0: t0,
+// n <= n1: t1, else t2; kind Steps) or base + cycle / n (kind Curve: scaled by phase_fill; kind IntCurve: integer division, not
+// scaled -- the wide rounds were fitted that way), never below `floor`.
+struct Window {
+    enum Kind { Steps, Curve, IntCurve } kind;
+    uint32_t n0, n1;
+    double t0, t1, t2;
+    double base, cycle, floor;
+    // Curve only, reads that fill the shape (fill >= 0.9): unscaled, and never below full_floor_small up to full_floor_n slices,
+    // full_floor_large beyond (two-word 250 bp: below its optimum the times jump -- 48 MiB: 12.6 ms at 600 ticks, 17.8 at 500)
+    uint32_t full_floor_n;
+    double full_floor_small, full_floor_large;
+};
+constexpr Window constant(double t) { return Window{Window::Steps, ~0u, ~0u, t, t, t, 0, 0, 0, 0, 0, 0}; }
+constexpr Window steps(uint32_t n0, double t0, uint32_t n1, double t1, double t2) { return Window{Window::Steps, n0, n1, t0, t1, t2, 0, 0, 0, 0, 0, 0}; }
+constexpr Window curve(double base, double cycle, double floor = 0.0) { return Window{Window::Curve, 0, 0, 0, 0, 0, base, cycle, floor, 0, 0, 0}; }
+constexpr Window curve_full_floor(double base, double cycle, double floor, uint32_t n, double small, double large)
+{
+    return Window{Window::Curve, 0, 0, 0, 0, 0, base, cycle, floor, n, small, large};
+}
+constexpr Window int_curve(double cycle, double floor) { return Window{Window::IntCurve, 0, 0, 0, 0, 0, 0, cycle, floor, 0, 0, 0}; }
+
+struct PhaseRule {
+    const char *name;
+    PhaseShape shape;
+    int lg;               // log2 lanes per block: 0 = one-word blocks, 1 = two-word blocks, 2 = stride-4 blocks (three / four words) in one lane
+    double fit_kmers;     // k-mers per read the windows were fitted with; 0: the work of a round does not depend on the read length
+    // ---- which tables
+    MinStep min_bytes[3];
+    uint64_t max_bytes;   // (x fill when the reads fill less than 80 % of the shape: the plain kernel catches up sooner)
+    // ---- slice size
+    SliceStep small_full[2];     // reads that fill the shape (>= 0.9): tables below these sizes get 512 KiB / 1 MiB slices
+    SliceStep small_partial[2];  // reads that leave it partly empty: larger pieces (session 57)
+    double four_mib_from_mib;    // 2 MiB slices below this table size, 4 MiB from it on
+    bool four_mib_scaled;        // ... x fill, and "below" is strict; false: the bound itself still takes 2 MiB slices (wide shapes)
+    // ---- window length by slice size: 512 KiB, 1 MiB, 2 MiB, 4 MiB and more
+    Window window[4];
+    double partial_2mib_ticks;   // 2 MiB slices, at most four of them, reads that leave the shape partly empty (0: no such rule)
+};
+
+// clang-format off
+constexpr PhaseRule kPhaseRules[] = {
+    // ------------------------------------------------------------------------------------------------ one-word blocks (<= 64 bins)
+    {"general, one-word", PhaseShape::General, 0, 0.0,
+     {{0.0, 6_MiB}}, 64_MiB,                       // 500 bp reads: 6 MiB 17.7 -> 16.1 ms; 64 MiB 34.4 against 49.3 plain
+     {}, {}, 10.0, true,
+     {curve(0, 2400), curve(0, 2400), curve(0, 2400), curve(200, 2500)}, 0},
+    {"four tiles, one-word", PhaseShape::FourTiles, 0, 238.0,
+     {{0.9, 1280_KiB}, {0.0, 2_MiB}}, 128_MiB,     // 127 MiB: 22.1 against 25.2 ms plain
+     {{3.5, 19}, {7.0, 20}}, {{3.5, 20}, {7.5, 21}}, 10.0, true,
+     {constant(250), constant(325), curve(0, 4600), curve(150, 5500)}, 450},   // (eight waves per SIMD since session 55: 150 + 5500 / n)
+    {"rounds of three tiles, one-word", PhaseShape::Rounds, 0, 488.0,
+     {{0.0, 5_MiB}}, 64_MiB,
+     {}, {}, 10.0, true,
+     {curve(0, 2400), curve(0, 2400), curve(0, 2400), curve(300, 2400)}, 0},   // (session 61)
+    {"six tiles, one-word", PhaseShape::SixTiles, 0, 348.0,
+     {{0.9, 1280_KiB}, {0.0, 2_MiB}}, 128_MiB,     // 127 MiB: 32.5 against 36.7 ms plain
+     {{3.5, 19}, {7.0, 20}}, {{3.5, 20}, {7.5, 21}}, 17.0, true,
+     {constant(250), constant(400), steps(7, 500, ~0u, 400, 400), curve(150, 6800)}, 600},
+    // ------------------------------------------------------------------------------------------------ two-word blocks (65-128 bins)
+    {"general, two-word", PhaseShape::General, 1, 0.0,
+     {{0.0, 6_MiB}}, 48_MiB,                       // 1000 bp: 48 MiB 85.9 against 97.4 plain
+     {}, {}, 10.0, true,
+     {curve(450, 0), curve(450, 0), curve(450, 0), curve(100, 2000)}, 0},
+    {"four tiles, two-word", PhaseShape::FourTiles, 1, 238.0,
+     {{0.9, 1280_KiB}, {0.75, 3_MiB}, {0.0, 4608_KiB}}, 96_MiB,   // 96 MiB: 20.2 against 24.8 ms plain
+     {{2.5, 19}, {7.0, 20}}, {{7.5, 21}}, 17.0, true,           // (with 2 MiB slices the optimum of 18-24 MiB tables is a narrow dip, with 4 MiB a flat region)
+     {constant(400), constant(400), steps(9, 500, ~0u, 400, 400), curve_full_floor(100, 5000, 325, 12, 600, 500)}, 450},
+    {"rounds of four tiles, two-word", PhaseShape::Rounds, 1, 488.0,
+     {{0.0, 6_MiB}}, 48_MiB,
+     {}, {}, 10.0, true,
+     {curve(450, 0), curve(450, 0), curve(450, 0), curve(200, 2500)}, 0},
+    {"six tiles, two-word", PhaseShape::SixTiles, 1, 348.0,
+     {{0.9, 1280_KiB}, {0.75, 3_MiB}, {0.0, 4608_KiB}}, 64_MiB,   // 64 MiB: 22.2 against 35.1 ms plain; at 96 MiB the optimum is narrow
+     {{2.5, 19}, {7.0, 20}}, {{7.5, 21}}, 18.5, true,
+     {constant(400), constant(400), curve(400, 0, 400), curve(150, 4400, 400)}, 600},   // (below 400 ticks the times get erratic)
+    // ------------------------------------------------------------------------------- three- and four-word blocks (129-256 bins), one lane per block
+    {"wide, rounds of three tiles (four-word build)", PhaseShape::WideRounds, 2, 348.0,
+     {{0.0, 6_MiB}}, 48_MiB,                       // 40 MiB: 25.4 against 33.6 ms plain (360 bp); 64 MiB: even
+     {}, {}, 13.0, false,
+     {constant(325), constant(325), constant(325), int_curve(2400, 400)}, 0},   // (16 MiB: 600, 24 MiB: 400 -- session 50)
+    {"wide, four tiles (four-word build)", PhaseShape::WideFourTiles, 2, 238.0,
+     {{0.8, 4608_KiB}, {0.0, kNever}}, 48_MiB,     // 40 MiB: 17.2 against 22.8 ms plain (250 bp)
+     {}, {}, 12.0, false,
+     {constant(400), constant(400), constant(400), constant(500)}, 0},
+    {"wide, four tiles (three-word build)", PhaseShape::Wide3FourTiles, 2, 238.0,
+     {{0.8, 3_MiB}, {0.0, kNever}}, 48_MiB,        // 4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB
+     {}, {}, 14.0, false,
+     {constant(500), constant(500), constant(500), steps(4, 850, 8, 600, 500)}, 0},   // (five waves per SIMD: longer windows, session 53)
+    {"wide, rounds of three tiles (three-word build)", PhaseShape::Wide3Rounds, 2, 348.0,
+     {{0.0, 6_MiB}}, 48_MiB,
+     {}, {}, 13.0, false,
+     {constant(400), constant(400), constant(400), int_curve(3400, 400)}, 0},   // (session 59)
+};
+// clang-format on
+
+// the row of a shape and block width (shapes 0-3 exist for one- and two-word blocks, the wide shapes for stride-4 blocks)
+constexpr bool phase_shape_is_wide(PhaseShape shape) { return (int)shape >= (int)PhaseShape::WideRounds; }
+constexpr const PhaseRule &phase_rule(PhaseShape shape, int lg)
+{
+    for (const PhaseRule &r : kPhaseRules)
+        if (r.shape == shape && (r.lg == lg || phase_shape_is_wide(shape))) return r;
+    for (const PhaseRule &r : kPhaseRules)
+        if (r.shape == shape) return r;  // (a block width the shape has no row for: its first row)
+    return kPhaseRules[0];
+}
+
+// how full the kernel shape is with reads of `kmers` k-mers: factor on the cycle, 0.5 ... 1
+inline double phase_fill(PhaseShape shape, uint32_t kmers)
+{
+    const double fit = phase_rule(shape, phase_shape_is_wide(shape) ? 2 : 0).fit_kmers;
+    if (fit == 0.0) return 1.0;
+    return std::min(1.0, std::max(0.5, (double)kmers / fit));
+}
+
+inline uint32_t phase_slice_log2(PhaseShape shape, int lg, uint64_t table_bytes, uint32_t kmers)
+{
+    const PhaseRule &r = phase_rule(shape, lg);
+    const double mib = (double)table_bytes / 1048576.0;
+    const double fill = phase_fill(shape, kmers);
+    if (!r.four_mib_scaled) return mib <= r.four_mib_from_mib ? 21 : 22;
+    if (fill >= 0.9) {
+        for (const SliceStep &s : r.small_full)
+            if (s.below_mib > 0.0 && mib < s.below_mib) return s.slice_log2;
+    } else {
+        for (const SliceStep &s : r.small_partial)
+            if (s.below_mib > 0.0 && mib < s.below_mib) return s.slice_log2;
+    }
+    return mib < r.four_mib_from_mib * fill ? 21 : 22;
+}
+
+inline uint64_t phase_window_ticks(PhaseShape shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
+{
+    const PhaseRule &r = phase_rule(shape, lg);
+    const double fill = phase_fill(shape, kmers);
+    const int cls = slice_log2 <= 19 ? 0 : slice_log2 == 20 ? 1 : slice_log2 == 21 ? 2 : 3;
+    if (cls == 2 && r.partial_2mib_ticks > 0.0 && n_slices <= 4 && fill < 0.9) return (uint64_t)r.partial_2mib_ticks;
+    const Window &w = r.window[cls];
+    const uint32_t n = std::max(n_slices, 1u);
+    switch (w.kind) {
+    case Window::Steps: return (uint64_t)(n_slices <= w.n0 ? w.t0 : n_slices <= w.n1 ? w.t1 : w.t2);
+    case Window::IntCurve: return std::max<uint64_t>((uint64_t)w.floor, (uint32_t)w.cycle / n);
+    default: break;
+    }
+    if (w.full_floor_n && fill >= 0.9) return (uint64_t)std::max(w.base + w.cycle / n, n_slices <= w.full_floor_n ? w.full_floor_small : w.full_floor_large);
+    const double t = (w.base + w.cycle / n) * fill;
+    return (uint64_t)std::max(t, w.floor);
+}
+
+// from which table size on the phased form pays ...
+inline uint64_t phase_shape_min_bytes(PhaseShape shape, int lg, double fill)
+{
+    const PhaseRule &r = phase_rule(shape, lg);
+    for (const MinStep &m : r.min_bytes)
+        if (fill >= m.fill_at_least) return m.bytes;
+    return kNever;
+}
+
+// ... and up to which (profiles/r03/slice_size.txt; the plain kernel sits at the fabric-request wall from about 64 MiB on)
+inline uint64_t phase_shape_max_bytes(PhaseShape shape, int lg) { return phase_rule(shape, lg).max_bytes; }
+
+// A read needs at least one whole cycle over its table's slices, and a cycle is not shorter than the refill of the table: small
+// batches of a large table are served faster by the plain kernel (profiles/r03/phased_batch_size.txt, second part: 64 MiB
+// one-word, 250 bp, 2 049 reads per call 78 us phased against 65 plain, 4 096: 105 / 116; 120 MiB: even at 16 384 reads, 1.11-1.17 x
+// at 65 536).  Tables of up to 32 MiB pay from the first batch above the latency kernel's (rb_engine::phase_min_reads).
+inline size_t phase_min_reads_for(uint64_t table_bytes)
+{
+    if (table_bytes > (64ull << 20)) return 32768;
+    if (table_bytes > (32ull << 20)) return 4096;
+    return 0;
+}
+
+}  // namespace rbplan

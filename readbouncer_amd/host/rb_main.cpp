@@ -190,27 +190,34 @@ struct ReadState
 struct IngestOptions
 {
     size_t batch_reads = 65536;  // most reads per GPU call
-    unsigned threads = 4;        // parser threads
-    unsigned classify_threads = 2;  // threads running the chunk loop on the GPU (one engine each)
+    unsigned threads = 6;        // parser threads (one does ~3 GB/s of 250 bp FASTQ records)
+    unsigned classify_threads = 0;  // threads running the chunk loop on the GPU and formatting their segment's output (one engine
+                                    // each); 0 = [IBF] threads when the TOML sets it above 1 (the reference's meaning of that key:
+                                    // classification threads, adaptive_sampling.hpp:745), else 4
+    bool mmap_output = true;     // outputs are written through shared mappings by the classifier threads themselves (--no-mmap-output:
+                                 // positional writes of heap buffers)
     size_t segment_mb = 64;      // file bytes per parsed segment
     size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
     size_t live_batch = 64;      // usage "target" replay: chunks per micro-batch
     size_t bytes() const { return segment_bytes ? segment_bytes : (segment_mb << 20); }
 };
 
-// a classified segment on its way to the writer thread: the FASTA text of every output file (formatted by the
-// classifier thread, in read order) and the tallies of the segment
-struct WriteJob
+// what a classified segment adds to the outputs: exact byte counts per output file (target files first, unclassified.fasta last)
+// -- known before a byte is formatted, so that the files can be laid out in read order while the formatting itself runs in
+// parallel -- and the tallies of the segment
+struct SegmentOutput
 {
-    std::vector<std::string> bufs;       // one per target file, unclassified.fasta last
+    std::vector<uint64_t> bytes;         // one per target file, unclassified.fasta last
     std::vector<uint64_t> per_target;    // IBFMeta.classified increments (classify.hpp:80,288)
     std::vector<std::string> error_lines;
     uint64_t found = 0, failed = 0;
 };
 
 // classify_reads, src/main/classify.hpp:142-380, as a pipeline: parser threads cut the memory-mapped read file into
-// segments and stage the first chunk of every read (seqio::ParallelReader), classifier threads run the chunk loop on
-// the GPU, a writer thread formats the FASTA outputs -- in file order throughout.
+// segments and stage the first chunk of every read (seqio::ParallelReader); classifier threads take the segments in file
+// order, run the chunk loop on the GPU (one engine each: while one waits for the GPU the others prepare and format), size
+// their segment's share of every output file, reserve it in file order (seqio::OrderedOutput) and then format the FASTA
+// text straight into the files' page cache, all of them at once -- outputs byte-identical to a serial run.
 static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta> DepletionFilters,
                            std::vector<interleave::IBFMeta> TargetFilters, const IngestOptions& opt,
                            const std::vector<int>& devices)
@@ -234,18 +241,17 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         uint64_t classify_reads_n = 0;
         const auto wall0 = std::chrono::steady_clock::now();
 
-        std::vector<std::ofstream> targetFastas{};
-        for (size_t i = 0; i < TargetFilters.size(); ++i) {
+        const size_t n_out = TargetFilters.size() + 1;  // <target>.fasta ..., unclassified.fasta last
+        std::vector<std::unique_ptr<seqio::OrderedOutput>> outputs;
+        for (size_t i = 0; i < n_out; ++i) {
             std::filesystem::path outfile(config.output_dir);
-            outfile /= TargetFilters[i].name + ".fasta";
-            targetFastas.emplace_back(outfile, std::ios::out | std::ios::binary);
-        }
-        std::filesystem::path outfile(config.output_dir);
-        outfile /= "unclassified.fasta";
-        std::ofstream UnclassifiedOut(outfile, std::ios::out | std::ios::binary);
-        if (!UnclassifiedOut.is_open()) {
-            std::cerr << "ERROR: Unable to open the file: " << outfile.string() << std::endl;
-            return;
+            outfile /= i < TargetFilters.size() ? TargetFilters[i].name + ".fasta" : std::string("unclassified.fasta");
+            outputs.emplace_back(new seqio::OrderedOutput());
+            const bool opened = outputs.back()->open(outfile.string(), opt.mmap_output);
+            if (!opened && i + 1 == n_out) {  // (the reference checks unclassified.fasta only, classify.hpp:205-211)
+                std::cerr << "ERROR: Unable to open the file: " << outfile.string() << std::endl;
+                return;
+            }
         }
         seqio::MappedFile mapped(read_file.string());
         if (!mapped.is_open()) {
@@ -257,71 +263,58 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         const uint32_t chunk_length = (uint32_t)config.IBF_Parsed.chunk_length;
         const uint32_t max_chunks = (uint8_t)config.IBF_Parsed.max_chunks;  // "uint8_t i" in the reference
 
-        // ---- writer thread: outputs in read order, one write() per file and segment
-        std::mutex wmu;
-        std::condition_variable wcv_job, wcv_room;
-        std::deque<WriteJob> wjobs;
-        bool wdone = false;
-        std::thread writer([&] {
-            for (;;) {
-                WriteJob job;
-                {
-                    std::unique_lock<std::mutex> lock(wmu);
-                    wcv_job.wait(lock, [&] { return !wjobs.empty() || wdone; });
-                    if (wjobs.empty()) return;
-                    job = std::move(wjobs.front());
-                    wjobs.pop_front();
-                }
-                wcv_room.notify_one();
-                found += job.found;
-                failed += (uint16_t)job.failed;
-                for (const std::string& l : job.error_lines) log_line("error", l);
-                for (size_t f = 0; f < TargetFilters.size(); ++f) {
-                    TargetFilters[f].classified += job.per_target[f];
-                    if (!job.bufs[f].empty()) targetFastas[f].write(job.bufs[f].data(), (std::streamsize)job.bufs[f].size());
-                }
-                if (!job.bufs.back().empty())
-                    UnclassifiedOut.write(job.bufs.back().data(), (std::streamsize)job.bufs.back().size());
-            }
-        });
-        // the outputs of one classified segment, in read order (classify.hpp:289-316)
-        auto format_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state) {
-            WriteJob job;
-            job.bufs.resize(TargetFilters.size() + 1);
-            job.per_target.assign(TargetFilters.size(), 0);
-            size_t unclassified_bytes = 0;
+        // pass 1 over a classified segment: which file every read goes to and how many bytes it takes there (classify.hpp:289-316)
+        auto fasta_bytes = [&](const seqio::Record& r, bool one_line) -> uint64_t {
+            // target FASTAs: `targetFastas[i] << ">" << id << endl << seq << endl` -- the raw read on one line;
+            // unclassified.fasta: seqan::writeRecord(..., (seqan::Dna5String)seq) -- SeqAn's default 70-column lines
+            return 1 + (uint64_t)r.id_len + 1 + r.seq_len + (one_line ? 1 : (r.seq_len + 69) / 70);
+        };
+        auto size_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state) {
+            SegmentOutput so;
+            so.bytes.assign(n_out, 0);
+            so.per_target.assign(TargetFilters.size(), 0);
             const std::vector<seqio::Record>& recs = seg.batch.records;
-            for (size_t i = 0; i < recs.size(); ++i)
-                if (recs[i].seq_len >= chunk_length && !state[i].failed && !state[i].classified)
-                    unclassified_bytes += recs[i].id_len + recs[i].seq_len + recs[i].seq_len / 70 + 4;
-            job.bufs.back().reserve(unclassified_bytes);
             for (size_t i = 0; i < recs.size(); ++i) {
                 const seqio::Record& r = recs[i];
                 if (r.seq_len < chunk_length) continue;
                 if (state[i].failed) {  // classify.hpp:306-316
-                    job.failed++;
-                    job.error_lines.push_back("Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
+                    so.failed++;
+                    so.error_lines.push_back("Error classifying Read : " + std::string(r.id, r.id_len) + "(Len=" + std::to_string(r.seq_len) + ")");
                     continue;
                 }
-                std::string* out = &job.bufs.back();  // unclassified.fasta
                 if (state[i].classified) {
-                    job.found++;
+                    so.found++;
                     if (!(target && state[i].best >= 0)) continue;
-                    job.per_target[state[i].best] += 1;
-                    out = &job.bufs[state[i].best];
-                }
-                out->push_back('>');
-                out->append(r.id, r.id_len);
-                out->push_back('\n');
-                if (out != &job.bufs.back()) {  // target FASTAs: `targetFastas[i] << seq << std::endl` -- the raw read on one line
-                    out->append(r.seq, r.seq_len);
-                    out->push_back('\n');
+                    so.per_target[state[i].best] += 1;
+                    so.bytes[state[i].best] += fasta_bytes(r, true);
                 } else {
-                    // unclassified.fasta: seqan::writeRecord(UnclassifiedOut, id, (seqan::Dna5String)seq) (classify.hpp:301) --
-                    // the Dna5 alphabet (upper case, everything but ACGT[U] becomes N) in SeqAn's default 70-column lines
-                    const size_t at = out->size();
-                    out->resize(at + r.seq_len + (r.seq_len + 69) / 70);  // one growth per record, not one per line
-                    char* dst = &(*out)[at];
+                    so.bytes[n_out - 1] += fasta_bytes(r, false);
+                }
+            }
+            return so;
+        };
+        // pass 2: the FASTA text of the segment, written where pass 1 and the reservation said (cur[f] = this segment's share of file f)
+        auto format_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state, std::vector<char*>& cur) {
+            const std::vector<seqio::Record>& recs = seg.batch.records;
+            for (size_t i = 0; i < recs.size(); ++i) {
+                const seqio::Record& r = recs[i];
+                if (r.seq_len < chunk_length || state[i].failed) continue;
+                size_t f = n_out - 1;  // unclassified.fasta
+                if (state[i].classified) {
+                    if (!(target && state[i].best >= 0)) continue;
+                    f = (size_t)state[i].best;
+                }
+                char* dst = cur[f];
+                *dst++ = '>';
+                std::memcpy(dst, r.id, r.id_len);
+                dst += r.id_len;
+                *dst++ = '\n';
+                if (f != n_out - 1) {
+                    std::memcpy(dst, r.seq, r.seq_len);
+                    dst += r.seq_len;
+                    *dst++ = '\n';
+                } else {
+                    // the Dna5 alphabet (upper case, everything but ACGT[U] becomes N) in 70-column lines
                     for (size_t p = 0; p < r.seq_len; p += 70) {
                         const size_t n = std::min<size_t>(70, r.seq_len - p);
                         dna5_map(dst, r.seq + p, n);
@@ -329,8 +322,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                         dst += n + 1;
                     }
                 }
+                cur[f] = dst;
             }
-            return job;
         };
 
         // first chunks are staged in page-locked memory: the copy to the GPU is then a plain DMA (a pageable source is
@@ -339,7 +332,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         pinned.alloc = [](size_t bytes) -> void* { void* p = nullptr; return rb_host_alloc(bytes, &p) == RB_OK ? p : nullptr; };
         pinned.release = [](void* p) { rb_host_free(p); };
         seqio::ParallelReader reader(mapped.data(), mapped.size(), opt.threads, opt.bytes(), chunk_length, pinned);
-        double wait_reader_s = 0.0, wait_writer_s = 0.0;
+        double wait_reader_s = 0.0, wait_turn_s = 0.0, format_s = 0.0;
         auto seconds_since = [](std::chrono::steady_clock::time_point t) {
             return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count();
         };
@@ -432,27 +425,48 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     const auto t0 = std::chrono::steady_clock::now();
                     classify_segment(*seg, state);
                     const double secs = seconds_since(t0);
-                    WriteJob job = format_segment(*seg, state);
-                    seg.reset();  // the staged chunks go back to the pool before the hand-over wait
+                    SegmentOutput so = size_segment(*seg, state);
+                    std::vector<uint64_t> at(n_out, 0);
                     {
+                        // this segment's turn: its share of every output file starts where the segment before it ends
+                        const auto tw = std::chrono::steady_clock::now();
                         std::unique_lock<std::mutex> lock(omu);
                         ocv.wait(lock, [&] { return write_seq == seq || write_seq == ~0ULL; });
                         if (write_seq == ~0ULL) return;  // another worker failed
+                        wait_turn_s += seconds_since(tw);
                         classify_seconds += secs;
-                    }
-                    {
-                        const auto tw = std::chrono::steady_clock::now();
-                        std::unique_lock<std::mutex> lock(wmu);
-                        wcv_room.wait(lock, [&] { return wjobs.size() < 4; });
-                        wjobs.push_back(std::move(job));
-                        wait_writer_s += seconds_since(tw);
-                    }
-                    wcv_job.notify_one();
-                    {
-                        std::lock_guard<std::mutex> lock(omu);
-                        if (write_seq != ~0ULL) ++write_seq;
+                        for (size_t f = 0; f < n_out; ++f)
+                            if (outputs[f]->is_open()) at[f] = outputs[f]->reserve(so.bytes[f]);
+                        found += so.found;
+                        failed += (uint16_t)so.failed;
+                        for (const std::string& l : so.error_lines) log_line("error", l);
+                        for (size_t f = 0; f < TargetFilters.size(); ++f) TargetFilters[f].classified += so.per_target[f];
+                        ++write_seq;
                     }
                     ocv.notify_all();
+                    // ... and the text itself, by every classifier thread at once
+                    const auto tf = std::chrono::steady_clock::now();
+                    std::vector<seqio::OrderedOutput::Window> win(n_out);
+                    std::vector<char*> cur(n_out, nullptr);
+                    std::vector<char> sink;  // a file that could not be opened (target FASTAs are not checked by the reference): formatted into the void
+                    for (size_t f = 0; f < n_out; ++f) {
+                        if (outputs[f]->is_open()) {
+                            win[f] = outputs[f]->map(at[f], (size_t)so.bytes[f]);
+                            cur[f] = win[f].data();
+                        } else {
+                            if (sink.size() < so.bytes[f]) sink.resize((size_t)so.bytes[f]);
+                            cur[f] = sink.data();
+                        }
+                    }
+                    format_segment(*seg, state, cur);
+                    for (size_t f = 0; f < n_out; ++f)
+                        if (outputs[f]->is_open() && cur[f] != win[f].data() + so.bytes[f]) throw std::runtime_error("output layout mismatch");
+                    win.clear();  // unmap / write out
+                    seg.reset();
+                    {
+                        std::lock_guard<std::mutex> lock(omu);
+                        format_s += seconds_since(tf);
+                    }
                 }
             } catch (const std::exception& ex) {
                 std::lock_guard<std::mutex> lock(omu);
@@ -461,22 +475,21 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                 ocv.notify_all();
             }
         };
+        unsigned n_classifiers = opt.classify_threads ? opt.classify_threads
+                                                      : (config.IBF_Parsed.threads > 1 ? (unsigned)config.IBF_Parsed.threads : 4u);
         {
-            const unsigned n_classifiers = multi ? 1u : std::max(1u, opt.classify_threads);
+            // (a multi-device pool spreads every call over its devices itself; two callers keep it fed while one formats)
+            if (multi) n_classifiers = std::min(n_classifiers, 2u);
             std::vector<std::thread> workers;
             for (unsigned i = 1; i < n_classifiers; ++i) workers.emplace_back(classifier);
             classifier();
             for (std::thread& t : workers) t.join();
         }
-        {
-            std::lock_guard<std::mutex> lock(wmu);
-            wdone = true;
-        }
-        wcv_job.notify_one();
-        writer.join();
         if (!worker_error.empty()) throw std::runtime_error(worker_error);
-        for (auto& f : targetFastas) f.close();
-        UnclassifiedOut.close();
+        for (auto& o : outputs) {
+            o->close();
+            if (!o->ok()) std::cerr << "ERROR: writing an output file failed: " << o->error() << std::endl;
+        }
         const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count();
         const double avg = classify_reads_n ? classify_seconds / (double)classify_reads_n : 0.0;
         std::cout << "------------------------------- Final Results -------------------------------" << std::endl;
@@ -493,7 +506,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                   << " readCounter=" << readCounter << std::endl;
         std::cout << "THROUGHPUT reads_per_s=" << (wall > 0 ? (double)readCounter / wall : 0.0) << " wall_s=" << wall
                   << " classify_s=" << classify_seconds << " wait_reader_s=" << wait_reader_s
-                  << " wait_writer_s=" << wait_writer_s << std::endl;
+                  << " wait_turn_s=" << wait_turn_s << " format_s=" << format_s << " classifiers=" << n_classifiers
+                  << " parsers=" << opt.threads << std::endl;
         ClassificationResults_.found = found;
         ClassificationResults_.failed = failed;
         ClassificationResults_.too_short = too_short;
@@ -657,6 +671,7 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--no-mmap-output")) opt.mmap_output = false;
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-bytes") && i + 1 < argc) opt.segment_bytes = (size_t)std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--live-batch") && i + 1 < argc) opt.live_batch = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
@@ -684,7 +699,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--no-mmap-output] "
                          "[--devices 0,1,...] [--parse-stats file]\n"
                          "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;

@@ -452,6 +452,150 @@ public:
     }
 };
 
+// ---- parallel, ordered output ----------------------------------------------------------------------------------------
+// An output file that several threads fill at once, each its own byte range, in an order fixed beforehand: reserve() hands
+// out consecutive ranges (the callers take turns in file order -- a few arithmetic instructions under a lock), map() gives
+// a writable window on one range.  With `use_mmap` the window is a MAP_SHARED mapping of the file itself: the formatted text
+// is written once, straight into the page cache, by as many threads as there are windows (a single writer thread doing
+// write() tops out at a few GB/s -- every byte is formatted into a buffer and then copied again under the inode lock).
+// Without it (or when the file system refuses to map: pipes, some network mounts) a window is a heap buffer that goes out
+// with one pwrite() when it is closed.  close() cuts the file to the bytes reserved.  Errors are sticky and reported by ok().
+class OrderedOutput
+{
+    int fd_ = -1;
+    bool use_mmap_ = true;
+    std::mutex mu_;
+    uint64_t reserved_ = 0, file_len_ = 0;
+    std::atomic<bool> failed_{false};
+    std::string error_;
+    void fail(const std::string& what)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        if (!failed_.exchange(true)) error_ = what;
+    }
+
+public:
+    class Window
+    {
+        friend class OrderedOutput;
+        OrderedOutput* owner_ = nullptr;
+        char* map_base_ = nullptr;
+        size_t map_len_ = 0;
+        std::unique_ptr<char[]> heap_;
+        uint64_t off_ = 0;
+        size_t bytes_ = 0;
+        char* ptr_ = nullptr;
+    public:
+        Window() = default;
+        Window(Window&& o) noexcept { *this = std::move(o); }
+        Window& operator=(Window&& o) noexcept
+        {
+            close();
+            owner_ = o.owner_; map_base_ = o.map_base_; map_len_ = o.map_len_; heap_ = std::move(o.heap_);
+            off_ = o.off_; bytes_ = o.bytes_; ptr_ = o.ptr_;
+            o.owner_ = nullptr; o.map_base_ = nullptr; o.ptr_ = nullptr; o.bytes_ = 0;
+            return *this;
+        }
+        ~Window() { close(); }
+        char* data() const { return ptr_; }
+        size_t size() const { return bytes_; }
+        void close()
+        {
+            if (map_base_) munmap(map_base_, map_len_);
+            else if (heap_ && owner_ && bytes_) owner_->pwrite_all(heap_.get(), bytes_, off_);
+            map_base_ = nullptr;
+            heap_.reset();
+            ptr_ = nullptr;
+            bytes_ = 0;
+        }
+    };
+
+    OrderedOutput() = default;
+    ~OrderedOutput() { close(); }
+    OrderedOutput(const OrderedOutput&) = delete;
+    OrderedOutput& operator=(const OrderedOutput&) = delete;
+
+    bool open(const std::string& path, bool use_mmap)
+    {
+        use_mmap_ = use_mmap;
+        fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
+        return fd_ >= 0;
+    }
+    bool is_open() const { return fd_ >= 0; }
+    bool ok() const { return !failed_.load(); }
+    std::string error()
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        return error_;
+    }
+    uint64_t bytes() const { return reserved_; }
+
+    // the next `bytes` bytes of the file; callers take turns in output order.  The file is grown ahead in large steps
+    // (sparse: nothing is allocated until a page is written).
+    uint64_t reserve(uint64_t bytes)
+    {
+        std::lock_guard<std::mutex> lock(mu_);
+        const uint64_t off = reserved_;
+        reserved_ += bytes;
+        if (use_mmap_ && reserved_ > file_len_) {
+            uint64_t want = std::max<uint64_t>(file_len_ * 2, (uint64_t)256 << 20);
+            while (want < reserved_) want *= 2;
+            if (ftruncate(fd_, (off_t)want) != 0) {
+                use_mmap_ = false;  // e.g. a pipe: plain positional (or sequential) writes from here on
+            } else {
+                file_len_ = want;
+            }
+        }
+        return off;
+    }
+
+    Window map(uint64_t off, size_t bytes)
+    {
+        Window w;
+        w.owner_ = this;
+        w.off_ = off;
+        w.bytes_ = bytes;
+        if (bytes == 0) return w;
+        bool mm;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            mm = use_mmap_ && off + bytes <= file_len_;
+        }
+        if (mm) {
+            const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
+            const uint64_t lo = off / page * page;
+            const size_t len = (size_t)(off + bytes - lo);
+            void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd_, (off_t)lo);
+            if (p != MAP_FAILED) {
+                w.map_base_ = (char*)p;
+                w.map_len_ = len;
+                w.ptr_ = (char*)p + (off - lo);
+                return w;
+            }
+        }
+        w.heap_.reset(new char[bytes]);
+        w.ptr_ = w.heap_.get();
+        return w;
+    }
+
+    void pwrite_all(const char* p, size_t n, uint64_t off)
+    {
+        while (n) {
+            const ssize_t k = ::pwrite(fd_, p, n, (off_t)off);
+            if (k <= 0) { fail("write failed"); return; }
+            p += k; n -= (size_t)k; off += (uint64_t)k;
+        }
+    }
+
+    void close()
+    {
+        if (fd_ < 0) return;
+        if (file_len_ != reserved_ && file_len_ != 0 && ftruncate(fd_, (off_t)reserved_) != 0) fail("truncate failed");
+        ::close(fd_);
+        fd_ = -1;
+    }
+};
+
 inline void write_fasta(std::ostream& out, const char* id, size_t id_len, const char* seq, size_t seq_len)
 {
     out.put('>');

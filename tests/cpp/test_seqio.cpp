@@ -2,7 +2,9 @@
 // a page-locked allocator that refuses falls back to the heap with the same records and prefixes; an allocator that
 // throws inside a worker thread ends the stream with an error segment instead of std::terminate.
 #include <cstdio>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <new>
 #include <string>
 
@@ -65,6 +67,52 @@ int main()
         const Digest c = drain(rd, 100);
         CHECK(!c.error.empty() && c.error.find("ingest worker") != std::string::npos);
         CHECK(c.records <= a.records);
+    }
+    // OrderedOutput: ranges reserved in order, filled by several threads at once (mapped windows, or heap windows written
+    // positionally) -- the file is the concatenation of the pieces, cut to the bytes reserved
+    for (int use_mmap = 0; use_mmap < 2; ++use_mmap) {
+        const std::string path = std::string("/tmp/rb_test_ordered_output_") + std::to_string((long)getpid()) + (use_mmap ? "_m" : "_w");
+        std::string expect;
+        std::vector<std::string> pieces;
+        for (int i = 0; i < 200; ++i) {
+            pieces.emplace_back((size_t)((i * 7919) % 30011) + (i % 5 == 0 ? 0 : 1), (char)('a' + i % 26));  // some empty pieces
+            if (i % 5 == 0) pieces.back().clear();
+            expect += pieces.back();
+        }
+        {
+            seqio::OrderedOutput out;
+            CHECK(out.open(path, use_mmap != 0));
+            std::vector<uint64_t> at(pieces.size());
+            for (size_t i = 0; i < pieces.size(); ++i) at[i] = out.reserve(pieces[i].size());
+            std::vector<std::thread> th;
+            for (int t = 0; t < 4; ++t)
+                th.emplace_back([&, t] {
+                    for (size_t i = (size_t)t; i < pieces.size(); i += 4) {
+                        seqio::OrderedOutput::Window w = out.map(at[i], pieces[i].size());
+                        if (!pieces[i].empty()) std::memcpy(w.data(), pieces[i].data(), pieces[i].size());
+                    }
+                });
+            for (auto& x : th) x.join();
+            CHECK(out.bytes() == expect.size());
+            out.close();
+            CHECK(out.ok());
+        }
+        std::ifstream in(path, std::ios::binary);
+        std::stringstream got;
+        got << in.rdbuf();
+        CHECK(got.str() == expect);
+        std::remove(path.c_str());
+    }
+    {
+        seqio::OrderedOutput nothing;  // a file nobody wrote to ends up empty
+        const std::string path = std::string("/tmp/rb_test_ordered_output_") + std::to_string((long)getpid()) + "_e";
+        CHECK(nothing.open(path, true));
+        nothing.close();
+        std::ifstream in(path, std::ios::binary | std::ios::ate);
+        CHECK(in.good() && in.tellg() == 0);
+        std::remove(path.c_str());
+        seqio::OrderedOutput bad;
+        CHECK(!bad.open("/nonexistent_dir_rb/x.fasta", true));
     }
     std::cout << "seqio checks done, failures: " << failures << std::endl;
     return failures ? 1 : 0;
