@@ -164,6 +164,9 @@ def parse():
     ap.add_argument("--serial-table-mib", type=int, default=-1,
                     help="tuning: filters up to this size take turns instead of overlapping (default: the engine's 64; 0 = round 1 behaviour)")
     ap.add_argument("--no-extras", action="store_true", help="default run: leave `other_configs` out")
+    ap.add_argument("--pool", action="store_true",
+                    help="only the single-process multi-GPU legs: c3 and c4 through rb_pool_classify_batch from ONE host process "
+                         "(rank 0 drives every GPU of the job; N = 1: the one GPU) from page-locked host memory")
     return ap.parse_args()
 
 
@@ -172,6 +175,23 @@ def load_json(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return {}
+
+
+def host_wait_for_rank0(dist, rank, tag):
+    """The other ranks wait on the HOST for rank 0 (a key in the job's rendezvous store) -- not in a collective: an RCCL barrier
+    is a kernel that spins on the waiting ranks' GPUs, and rank 0 is about to measure on those very GPUs (run_pool).
+    True when the store was used."""
+    if dist is None:
+        return False
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("rb_bench_" + tag, "1")
+        else:
+            store.wait(["rb_bench_" + tag])
+        return True
+    except Exception:  # noqa: BLE001  (no store to be had: the caller's collective does the waiting)
+        return False
 
 
 class Ctx:
@@ -206,6 +226,10 @@ class Ctx:
         if self.dist is not None:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+
+    def wait_for_rank0(self, tag):
+        host_wait_for_rank0(self.dist, self.rank, tag)
+        self.barrier()  # (all ranks are here within microseconds of each other now)
 
     def max_over_ranks(self, values):
         """element-wise max of a list of floats over the ranks (the contract's max-over-ranks timing)"""
@@ -528,6 +552,82 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
     return result
 
 
+def run_pool(ctx, name, steps=3):
+    """The single-process multi-GPU form (rb_pool.cpp): ONE host process -- rank 0 -- drives every GPU of the job
+    through rb_pool_classify_batch, which is what a MinKNOW front-end or the CLI's --devices would do; the other ranks of a
+    --gpus N run sit at the barrier.  Filters are replicated device to device from rank 0's resident copies
+    (rb_pool_create_from_device: xGMI between peers); reads, offsets, lengths and every output live in page-locked host memory;
+    a call carries 1 M reads per device and is cut into one contiguous slice per device.  PCIe-inclusive by construction, so
+    never the headline `value`.  Reports reads/s, replication seconds, and per device the share of the wall time its engine
+    was busy."""
+    from readbouncer_amd import capi, synth
+    torch, world, rank = ctx.torch, ctx.world, ctx.rank
+    result = None
+    if rank == 0:
+        env = os.environ.get("RB_BENCH_POOL_DEVICES")  # test hook: "0,0" = two workers on the one GPU of the box
+        devices = [int(x) for x in env.split(",")] if env else (list(range(world)) if (world > 1 and not ctx.same_gpu) else [ctx.dev_index])
+        dep_keys, tgt_keys, wname, _, L = workload_spec(ctx, name)
+        deplete = [ctx.filter(k)[0] for k in dep_keys]
+        target = [ctx.filter(k)[0] for k in tgt_keys]
+        ref = np.concatenate([ctx.filter(k)[1] for k in dep_keys + tgt_keys])
+        nf = len(deplete) + len(target)
+        per_dev = max(8192, 1_000_000 // TEST_DIVISOR)
+        n = per_dev * len(devices)
+        t0 = time.time()
+        pool = capi.Pool.from_device(devices, deplete, target)
+        create_s = time.time() - t0
+        t_seq, _, _ = synth.make_reads_device(2000, n, L, ref, ctx.dev)
+        blocks = {"seq": capi.HostBlock(n * L, np.uint8), "off": capi.HostBlock(n, np.uint64), "len": capi.HostBlock(n, np.uint32),
+                  "max": capi.HostBlock(n * nf, np.uint16), "best": capi.HostBlock(n, np.int32), "dec": capi.HostBlock(n, np.uint8),
+                  "st": capi.HostBlock(n, np.uint8)}
+        blocks["seq"].array[:] = t_seq.cpu().numpy()
+        blocks["off"].array[:] = np.arange(n, dtype=np.uint64) * np.uint64(L)
+        blocks["len"].array[:] = L
+        del t_seq
+
+        def call():
+            pool.classify_into(blocks["seq"].ptr, blocks["off"].ptr, blocks["len"].ptr, n, blocks["max"].ptr, blocks["best"].ptr,
+                               blocks["dec"].ptr, blocks["st"].ptr)
+        call()  # engines' staging buffers, threshold tables, code objects on every device
+        pool.stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            call()
+        wall = time.perf_counter() - t0
+        st = pool.stats()
+        # parity: the pool's outputs for the first reads against ONE engine on this rank's device (same resident filters)
+        m = min(n, 200_000)
+        eng = capi.Engine(ctx.dev_index, deplete, target)
+        mc, _, dec, status = eng.classify(blocks["seq"].array[: m * L], blocks["off"].array[:m].copy(), blocks["len"].array[:m].copy())
+        eng.destroy()
+        equal = bool(np.array_equal(mc.reshape(-1), blocks["max"].array[: m * nf]) and np.array_equal(dec, blocks["dec"].array[:m])
+                     and np.array_equal(status, blocks["st"].array[:m]))
+        # ... and the LAST device's slice against the same engine (a replica that travelled device to device)
+        lo = n - min(per_dev, 50_000)
+        eng = capi.Engine(ctx.dev_index, deplete, target)
+        mc2, _, dec2, _ = eng.classify(blocks["seq"].array[lo * L:], np.arange(n - lo, dtype=np.uint64) * np.uint64(L), blocks["len"].array[lo:].copy())
+        eng.destroy()
+        equal = equal and bool(np.array_equal(mc2.reshape(-1), blocks["max"].array[lo * nf:]) and np.array_equal(dec2, blocks["dec"].array[lo:]))
+        result = {"metric": METRIC, "value": n * steps / wall, "unit": "reads/s", "n_gpus": len(devices), "steps": steps, "warmup": 1,
+                  "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                  "data": "synthetic",
+                  "config": {"workload": wname + " -- ONE process, rb_pool_classify_batch, host buffers in page-locked memory (PCIe inclusive)",
+                             "devices": devices, "reads_per_call": n, "reads_per_device_per_call": per_dev, "read_len": L,
+                             "parallelism": "one host process, read-sharded x%d, IBF replicated device to device" % len(devices)},
+                  "pool": {"create_seconds": create_s, "replication_seconds": pool.replication_seconds,
+                           "replicated_bytes_per_device": int(sum(f.info["n_blocks"] * f.device_stride() * 8 for f in deplete + target)),
+                           "per_device": [{"device": d, "busy_share": b / wall, "reads": int(r), "calls": int(c)} for d, b, r, c in st]},
+                  "parity": {"checked_reads": int(m + n - lo), "pool_outputs_equal_single_engine": equal},
+                  "roofline": None, "cpu_baseline": None}
+        pool.destroy()
+        for b in blocks.values():
+            b.free()
+        torch.cuda.empty_cache()
+    ctx._pool_legs = getattr(ctx, "_pool_legs", 0) + 1
+    ctx.wait_for_rank0("pool_%s_%d" % (name, ctx._pool_legs))
+    return result
+
+
 def replay(ctx, live_leg=True):
     """BASELINE configs[4]: 48-flowcell replay.  Poisson chunk arrivals (rate/world per GPU), 360 bp each, deplete =
     GRCh38-scale IBF + target = mock-community IBF, full check_unblock.  The dispatcher is work-conserving: whenever
@@ -734,6 +834,18 @@ def null_engine_run(args, torch, dist, world, rank, backend):
 
     def leg(name, steps, sharded):
         reduce_ok = None
+        if name.startswith("pool_"):  # rank 0 alone "measures", the others wait for it on the host (run_pool's flow)
+            t0 = time.perf_counter()
+            if rank == 0:
+                time.sleep(0.05)
+            waited = host_wait_for_rank0(dist, rank, "null_" + name)
+            if dist is not None:
+                dist.barrier()
+            elapsed = max(time.perf_counter() - t0, 1e-3)
+            return {"metric": METRIC, "value": n_reads / elapsed, "unit": "reads/s", "n_gpus": world, "steps": 1, "warmup": 0,
+                    "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+                    "data": "synthetic", "engine": note, "config": {"workload": "rank-flow test (%s)" % name},
+                    "waited_on_store": waited, "rank0_only": True, "roofline": None, "cpu_baseline": None, "parity": None}
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
@@ -773,7 +885,7 @@ def null_engine_run(args, torch, dist, world, rank, backend):
     head = leg(args.workload or "c3", args.steps, args.bin_sharded)
     others = {}
     if not args.workload and not args.bin_sharded and not args.no_extras:
-        for name in ("c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"):
+        for name in ("c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4"):
             others[name] = leg(name, 1, False)
     infos = [{"rank": rank, "device": None}]
     if dist is not None:
@@ -831,7 +943,13 @@ def main():
     ctx = Ctx(args, torch, dist, world, rank, dev_index, backend, same_gpu, force_group)
     bin_sharded = args.bin_sharded and (world > 1 or force_group)
 
-    if args.workload == "c5":
+    if args.pool:
+        result = run_pool(ctx, "c3", steps=max(1, min(args.steps, 5)))
+        r4 = run_pool(ctx, "c4", steps=max(1, min(args.steps, 5)))
+        if rank == 0:
+            result["other_configs"] = {"pool_c4": r4}
+        extras = False
+    elif args.workload == "c5":
         result = replay(ctx)
         extras = False
     else:
@@ -863,7 +981,11 @@ def main():
                 ("readme_360bp", lambda: run_throughput(ctx, "readme", read_len=360, steps=min(args.steps, 5), warmup=1, cpu_seconds=0)),
                 # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
                 ("targets3", lambda: run_throughput(ctx, "targets3", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0)),
-                ("deplete_target", lambda: run_throughput(ctx, "deplete_target", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0))]
+                ("deplete_target", lambda: run_throughput(ctx, "deplete_target", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0)),
+                # one host process driving every GPU of the job through rb_pool (rank 0; the other ranks wait): what SCALE's per-rank
+                # numbers do not show
+                ("pool_c3", lambda: run_pool(ctx, "c3")),
+                ("pool_c4", lambda: run_pool(ctx, "c4"))]
         for lname, fn in legs:
             try:
                 r = fn()
@@ -890,6 +1012,7 @@ def main():
         bad = differs(result)
         for r in (result.get("other_configs") or {}).values():
             bad |= differs(r)
+            bad |= bool(isinstance(r, dict) and (r.get("parity") or {}).get("pool_outputs_equal_single_engine") is False)
         if bad:
             sys.exit(3)
 

@@ -293,8 +293,16 @@ RB_API int rb_pool_create(const int *devices, size_t n_devices, const rb_ibf *co
 RB_API int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *const *deplete_paths, size_t n_deplete,
                                      const char *const *target_paths, size_t n_target, rb_pool **out,
                                      double *replication_seconds);
+/* The same from filters that are already resident on some device (built there, or loaded once): every entry of `devices` gets
+ * a replica of its own, copied device to device like above (the source's own device included -- the pool owns what it
+ * classifies against; the caller keeps its filters). */
+RB_API int rb_pool_create_from_device(const int *devices, size_t n_devices, rb_dibf *const *deplete, size_t n_deplete,
+                                      rb_dibf *const *target, size_t n_target, rb_pool **out, double *replication_seconds);
 RB_API void rb_pool_destroy(rb_pool *p);
 RB_API size_t rb_pool_size(const rb_pool *p);
+/* Per worker, since creation or the last reset: the device it drives, seconds spent inside its engine's rb_classify_batch, reads
+ * and parts of calls served.  busy / wall time = the share of the time that device's engine had work (bench.py --pool). */
+RB_API int rb_pool_get_stats(rb_pool *p, size_t n, int *devices, double *busy_seconds, uint64_t *reads, uint64_t *calls, int reset);
 RB_API int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device);
 /* Calls from several host threads run concurrently: each worker (engine + host thread per device) has a FIFO of its own,
  * an unsplit micro-batch goes to the least loaded worker, and callers only meet while a call's parts are queued -- K calling

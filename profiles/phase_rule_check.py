@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Guard of the phased planner (readbouncer_amd/csrc/rb_phase_plan.h): at points BETWEEN the ones its table was
+fitted on -- 13 / 45 / 80 MiB x 200 / 300 / 430 bp for one- and two-word blocks, a few three- and four-word tables -- measure
+
+  rule   K1 ms per 1 M reads with the engine left to itself (rb_engine_plan says what it chose),
+  plain  the better of the plain kernel and the both-strands round without a clock,
+  best   the best of a sweep of window length (0.5 ... 2 x the rule's) x slice size (1, 2, 4 MiB) with the phased form forced,
+
+and exit non-zero when the rule is more than TOL (8 %) slower than the best of everything measured -- i.e. when a clock, firmware or
+compiler change has moved an optimum away from the fitted constants.  A table the rule leaves to the plain kernel is checked the
+same way (the plain time against the best phased time).  The script is the calibration record too: its output is kept under
+profiles/r0N/phase_rule_check.txt.
+
+  python3 profiles/phase_rule_check.py [--tol 0.08] [--reads 500000] [--points 1:200:13,2:300:45,...]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from readbouncer_amd import capi, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--tol", type=float, default=0.08)
+ap.add_argument("--reads", type=int, default=500_000)
+ap.add_argument("--points", default="1:200:13,1:300:13,1:430:13,1:200:45,1:300:45,1:430:45,1:300:80,2:200:13,2:300:13,2:430:13,2:200:45,"
+                                    "2:300:45,2:300:80,3:200:13,4:300:24,4:200:36")
+ap.add_argument("--factors", default="0.5,0.7,0.85,1.0,1.2,1.5,2.0")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+FACTORS = [float(x) for x in args.factors.split(",")]
+
+
+def k1_ms(eng, seqs, offs, lens, n, L, mc, ref):
+    for it in range(4):
+        if it == 1:
+            eng.kernel_time()
+        eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, L, d_maxcount=mc.data_ptr())
+    torch.cuda.synchronize()
+    ms, calls = eng.kernel_time()
+    if ref[0] is None:
+        ref[0] = mc.clone()
+    assert torch.equal(ref[0], mc), "the kernel forms disagree"
+    return ms / calls * 1e6 / n
+
+
+bad = []
+reads_cache = {}
+print("K1 ms per 1 M reads; tolerance %.0f %%" % (args.tol * 100))
+for point in args.points.split(","):
+    W, L, mib = point.split(":")
+    W, L, mib = int(W), int(L), float(mib)
+    N = args.reads
+    if L not in reads_cache:
+        reads_cache[L] = synth.make_reads_device(5, N, L, None, dev)
+    seqs, offs, lens = reads_cache[L]
+    mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
+    stride = 1 if W == 1 else 2 if W == 2 else 4
+    n_blocks = int(mib * (1 << 20) / (8 * stride)) - 3
+    d = capi.DeviceIBF.create(0, 64 * W, 3, 13, W * 64 * n_blocks)
+    d.fill_synth(3)
+    ref = [None]
+    eng = capi.Engine(0, [d], [])
+    eng.set_timing(True)
+    plan = eng.plan(0, N, L)
+    t_rule = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    eng.set_phased(0, 0, 0, 0, 0)  # the plain kernel
+    t_plain = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    eng.set_phased(0, 0, 0, 0, 1)  # the both-strands round of the phased kernel without a clock (one- and two-word blocks, small wide tables)
+    t_noclock = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    t_plain = min(t_plain, t_noclock)
+    # the sweep, phased form forced: the rule's own window (or a 60 us cycle where the rule does not phase) x factors, 1-4 MiB slices
+    sweep = {}
+    for lg2 in (20, 21, 22):
+        if (mib * (1 << 20)) / (1 << lg2) > 32 or (lg2 == 20 and mib > 16):
+            continue
+        n_sl = max(1, int(-(-mib * (1 << 20) // (1 << lg2))))
+        base_ticks = plan["phase_window_ticks"] if plan["phased"] and plan["phase_slice_log2"] == lg2 else max(150, int(6000 / n_sl))
+        for fct in FACTORS:
+            ticks = int(min(2000, max(100, base_ticks * fct)))
+            if (lg2, ticks) in sweep:
+                continue
+            eng.set_phase_slices(lg2, 32)
+            eng.set_phased(1 << 18, 1 << 32, ticks, 0, 1)
+            if not eng.plan(0, N, L)["phased"]:
+                continue  # (a block width the phased form does not serve)
+            sweep[(lg2, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    eng.destroy()
+    d.free()
+    best_key = min(sweep, key=sweep.get) if sweep else None
+    t_best = min([t_plain] + ([sweep[best_key]] if best_key else []))
+    off = t_rule / t_best - 1.0
+    chose = ("phased %s, %d slices of %d KiB, %d ticks" % (plan["phase_shape_name"], plan["phase_slices"], 1 << (plan["phase_slice_log2"] - 10),
+                                                           plan["phase_window_ticks"])) if plan["phased"] else plan["kernel"] + " (no clock)"
+    verdict = "ok" if off <= args.tol else "RULE OFF"
+    if off > args.tol:
+        bad.append(point)
+    print("%d-word %3d bp %5.1f MiB: rule %6.2f (%s) | plain %6.2f | best phased %s | rule vs best %+5.1f %%  %s"
+          % (W, L, mib, t_rule, chose, t_plain,
+             ("%6.2f at %d KiB x %d ticks" % (sweep[best_key], 1 << (best_key[0] - 10), best_key[1])) if best_key else "   n/a", off * 100, verdict), flush=True)
+    if sweep:
+        for lg2 in sorted({k[0] for k in sweep}):
+            print("      slices of %4d KiB: " % (1 << (lg2 - 10)) + "  ".join("%d:%.2f" % (t, sweep[(lg2, t)]) for (l, t) in sorted(sweep) if l == lg2), flush=True)
+print("points outside the tolerance: %s" % (", ".join(bad) if bad else "none"))
+sys.exit(1 if bad else 0)

@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 if os.path.exists(os.path.join(src, "hbm_peak.txt")):
     shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
-for w in ("c2", "c3", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
+for w in ("c2", "c3", "c3np2", "grch38_f100k", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
     hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
@@ -58,7 +58,7 @@ from readbouncer_amd import synth  # noqa: E402
 
 rows, traffic = [], {}
 MOCK = ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]
-FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
+FILTERS = {"c2": ["c2"], "c3": ["c3"], "c3np2": ["c3np2"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
            "readme": MOCK, "c1_r01": ["c1"], "readme_r01": MOCK, "readme_skew": MOCK, "readme360": MOCK, "readme360_six0": MOCK,
            "readme_phased": MOCK, "readme360_phased": MOCK, "w1_64mib": ["w1_64mib"], "w1_64mib_plain": ["w1_64mib"],
            "targets3": ["mock_t1", "mock_t2", "mock_t3"], "targets3_apart": ["mock_t1", "mock_t2", "mock_t3"],
@@ -66,7 +66,7 @@ FILTERS = {"c2": ["c2"], "c3": ["c3"], "c4": ["c3", "zymo"], "grch38_f100k": ["g
 READ_LEN = {"readme": 250, "readme_r01": 250, "readme_skew": 250, "readme_phased": 250, "w1_64mib": 250, "w1_64mib_plain": 250,
             "targets3": 250, "targets3_apart": 250, "deplete_target": 250, "deplete_target_apart": 250}
 when = os.environ.get("RB_EVIDENCE_DATE", "")
-for w in ("c2", "c3", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0", "readme_phased", "readme360_phased",
+for w in ("c2", "c3", "c3np2", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0", "readme_phased", "readme360_phased",
           "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):

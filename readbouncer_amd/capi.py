@@ -97,6 +97,8 @@ SIGNATURES = {
     "rb_pool_create": (_int, [C.POINTER(_int), _sz, _pp, _sz, _pp, _sz, _pp]),
     "rb_pool_create_from_files": (_int, [C.POINTER(_int), _sz, C.POINTER(C.c_char_p), _sz, C.POINTER(C.c_char_p), _sz, _pp,
                                          C.POINTER(_dbl)]),
+    "rb_pool_create_from_device": (_int, [C.POINTER(_int), _sz, _pp, _sz, _pp, _sz, _pp, C.POINTER(_dbl)]),
+    "rb_pool_get_stats": (_int, [_vp, _sz, C.POINTER(_int), C.POINTER(_dbl), C.POINTER(_u64), C.POINTER(_u64), _int]),
     "rb_pool_destroy": (None, [_vp]),
     "rb_dibf_clone_to": (_int, [_vp, _int, _pp]),
     "rb_dibf_compare": (_int, [_vp, _vp, C.POINTER(IbfCompare)]),
@@ -528,6 +530,34 @@ class Pool:
         self.replication_seconds = secs.value
         return self
 
+    @classmethod
+    def from_device(cls, devices, deplete, target):
+        """replicas of filters that are already resident (DeviceIBF), copied device to device onto every entry of `devices`"""
+        self = cls.__new__(cls)
+        self.nd, self.nt = len(deplete), len(target)
+        self._keep = (list(deplete), list(target))
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        secs = C.c_double(0)
+        _check(lib().rb_pool_create_from_device(devs, len(devices), _handle_array(deplete), self.nd, _handle_array(target), self.nt,
+                                                C.byref(h), C.byref(secs)), "rb_pool_create_from_device")
+        self.h = h
+        self.replication_seconds = secs.value
+        return self
+
+    def stats(self, reset=False):
+        """per worker: (device, busy seconds inside its engine, reads served, parts of calls served)"""
+        n = self.size()
+        dev, busy, reads, calls = (C.c_int * n)(), (C.c_double * n)(), (C.c_uint64 * n)(), (C.c_uint64 * n)()
+        _check(lib().rb_pool_get_stats(self.h, n, dev, busy, reads, calls, int(reset)), "rb_pool_get_stats")
+        return [(dev[i], busy[i], reads[i], calls[i]) for i in range(n)]
+
+    def classify_into(self, seqs_ptr, offsets_ptr, lens_ptr, n, maxcount_ptr, best_ptr, decision_ptr, status_ptr, error_rate=0.1,
+                      significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
+        """the C call on caller-owned buffers (e.g. page-locked ones from host_alloc), no numpy copies around it"""
+        _check(lib().rb_pool_classify_batch(self.h, seqs_ptr, offsets_ptr, lens_ptr, n, error_rate, significance, mode, maxcount_ptr,
+                                            best_ptr, decision_ptr, status_ptr), "rb_pool_classify_batch")
+
     def size(self):
         return lib().rb_pool_size(self.h)
 
@@ -632,6 +662,23 @@ class Live:
             self.destroy()
         except Exception:
             pass
+
+
+class HostBlock:
+    """page-locked host memory from rb_host_alloc, seen as a numpy array of `dtype`"""
+
+    def __init__(self, count, dtype=np.uint8):
+        self.ptr = C.c_void_p()
+        nbytes = int(count) * np.dtype(dtype).itemsize
+        _check(lib().rb_host_alloc(max(1, nbytes), C.byref(self.ptr)), "rb_host_alloc")
+        buf = (C.c_uint8 * max(1, nbytes)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(count))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().rb_host_free(self.ptr)
+            self.ptr = None
 
 
 def pack_reads(seqs, offsets, lens):

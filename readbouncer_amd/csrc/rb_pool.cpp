@@ -3,6 +3,7 @@
 // The reference's scaling model is N classify threads popping one queue (src/main/adaptive_sampling.hpp:745-751);
 // here the N workers are GPUs.  Micro-batches are not split (latency): they go to one device, round-robin.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -28,6 +29,7 @@ struct Device {
     int device = 0;
     std::vector<rb_dibf *> filters;  // owned replicas, deplete first
     rb_engine *engine = nullptr;
+    std::atomic<uint64_t> busy_ns{0}, reads{0}, calls{0};  // time inside rb_classify_batch, reads and parts served (rb_pool_get_stats)
     rbq::Worker worker{[] { return std::string(rb_last_error()); }};
 };
 
@@ -51,6 +53,53 @@ struct rb_pool {
         dispatcher.reset(new rbq::Dispatcher(ws));
     }
 };
+
+extern "C" void rb_pool_destroy(rb_pool *p);
+
+// One resident filter -> a replica on each of devices[from .. n): all peers at once, one stream per destination, each copy on its
+// own xGMI link.  A device whose copy cannot be started or does not finish gets the filter by the next rung of the ladder:
+// the runtime's staged copy (rb_dibf_clone_to), then -- when the filter came from a file -- its own stream of that file.
+static int replicate(rb_pool *p, rb_dibf *first, const int *devices, size_t n_devices, size_t from, const char *path, double *copy_s)
+{
+    std::vector<void *> streams(n_devices, nullptr);
+    std::vector<bool> fallback(n_devices, false);
+    const auto t0 = std::chrono::steady_clock::now();
+    // Fault injection, compiled into the TESTING build of the library only (make testing: libreadbouncer_amd_testing.so,
+    // -DRB_TESTING): RB_POOL_TEST_FAIL_CLONE=start|finish makes every device-to-device copy "fail" at that step, so that the
+    // ladder below is walked on a box where the copies themselves cannot fail (tests/test_gpu_parity.py runs that build in a
+    // child process).  The product library has no such switch.
+#ifdef RB_TESTING
+    const char *inject = std::getenv("RB_POOL_TEST_FAIL_CLONE");
+    const bool fail_start = inject && std::strcmp(inject, "start") == 0;
+    const bool fail_finish = inject && std::strcmp(inject, "finish") == 0;
+#else
+    const bool fail_start = false, fail_finish = false;
+#endif
+    for (size_t d = from; d < n_devices; ++d) {
+        rb_dibf *f = nullptr;
+        int peer = 0;
+        if (!fail_start && rb_dibf_clone_start(first, devices[d], &f, &streams[d], &peer) == RB_OK) p->workers[d]->filters.push_back(f);
+        else fallback[d] = true;
+    }
+    for (size_t d = from; d < n_devices; ++d) {
+        if (fallback[d]) continue;
+        if (rb_dibf_clone_finish(streams[d]) != RB_OK || fail_finish) {
+            rb_dibf_free(p->workers[d]->filters.back());
+            p->workers[d]->filters.pop_back();
+            fallback[d] = true;
+        }
+    }
+    *copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t d = from; d < n_devices; ++d) {
+        if (!fallback[d]) continue;
+        rb_dibf *f = nullptr;
+        // no device-to-device path: this device streams the file itself, or (no file) takes the runtime's synchronous copy
+        const int rc = path ? rb_dibf_open(devices[d], path, &f) : rb_dibf_clone_to(first, devices[d], &f);
+        if (rc != RB_OK) return rc;
+        p->workers[d]->filters.push_back(f);
+    }
+    return RB_OK;
+}
 
 extern "C" {
 
@@ -118,43 +167,8 @@ int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *
         int rc = path ? rb_dibf_open(devices[0], path, &first) : rb::fail(RB_ERR_INVALID_ARG, "null filter path");
         if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
         p->workers[0]->filters.push_back(first);
-        // all peers at once: one stream per destination, each copy on its own xGMI link
-        std::vector<void *> streams(n_devices, nullptr);
-        std::vector<bool> need_file(n_devices, false);
-        const auto t0 = std::chrono::steady_clock::now();
-        // Fault injection, compiled into the TESTING build of the library only (make testing: libreadbouncer_amd_testing.so,
-        // -DRB_TESTING): RB_POOL_TEST_FAIL_CLONE=start|finish makes every device-to-device copy "fail" at that step, so that the
-        // ladder below -- peer copy, staged copy, own file stream -- is walked on a box where the copies themselves cannot fail
-        // (tests/test_gpu_parity.py runs that build in a child process).  The product library has no such switch.
-#ifdef RB_TESTING
-        const char *inject = std::getenv("RB_POOL_TEST_FAIL_CLONE");
-        const bool fail_start = inject && std::strcmp(inject, "start") == 0;
-        const bool fail_finish = inject && std::strcmp(inject, "finish") == 0;
-#else
-        const bool fail_start = false, fail_finish = false;
-#endif
-        for (size_t d = 1; d < n_devices; ++d) {
-            rb_dibf *f = nullptr;
-            int peer = 0;
-            if (!fail_start && rb_dibf_clone_start(first, devices[d], &f, &streams[d], &peer) == RB_OK) p->workers[d]->filters.push_back(f);
-            else need_file[d] = true;
-        }
-        for (size_t d = 1; d < n_devices; ++d) {
-            if (need_file[d]) continue;
-            if (rb_dibf_clone_finish(streams[d]) != RB_OK || fail_finish) {
-                rb_dibf_free(p->workers[d]->filters.back());
-                p->workers[d]->filters.pop_back();
-                need_file[d] = true;
-            }
-        }
-        copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        for (size_t d = 1; d < n_devices; ++d) {  // no device-to-device path: this device streams the file itself
-            if (!need_file[d]) continue;
-            rb_dibf *f = nullptr;
-            rc = rb_dibf_open(devices[d], path, &f);
-            if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
-            p->workers[d]->filters.push_back(f);
-        }
+        rc = replicate(p, first, devices, n_devices, 1, path, &copy_s);
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
     }
     for (Device *w : p->workers) {
         const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target,
@@ -164,6 +178,52 @@ int rb_pool_create_from_files(const int *devices, size_t n_devices, const char *
     p->start();
     if (replication_seconds) *replication_seconds = copy_s;
     *out = p;
+    return RB_OK;
+}
+
+int rb_pool_create_from_device(const int *devices, size_t n_devices, rb_dibf *const *deplete, size_t n_deplete, rb_dibf *const *target,
+                               size_t n_target, rb_pool **out, double *replication_seconds)
+{
+    if (!out || !devices || n_devices == 0) return rb::fail(RB_ERR_INVALID_ARG, "no devices");
+    if (n_deplete + n_target == 0) return rb::fail(RB_ERR_NULL_FILTER, "No IBF provided to classify the read!");
+    rb_pool *p = new (std::nothrow) rb_pool();
+    if (!p) return rb::fail(RB_ERR_NOMEM, "alloc");
+    p->nd = n_deplete;
+    p->nt = n_target;
+    for (size_t d = 0; d < n_devices; ++d) {
+        Device *w = new (std::nothrow) Device();
+        if (!w) { rb_pool_destroy(p); return rb::fail(RB_ERR_NOMEM, "alloc"); }
+        w->device = devices[d];
+        p->workers.push_back(w);
+    }
+    double copy_s = 0.0;
+    for (size_t i = 0; i < n_deplete + n_target; ++i) {
+        rb_dibf *src = i < n_deplete ? deplete[i] : target[i - n_deplete];
+        // every device gets a replica of its own, the source's device included: the pool owns what it classifies against
+        const int rc = src ? replicate(p, src, devices, n_devices, 0, nullptr, &copy_s) : rb::fail(RB_ERR_INVALID_ARG, "null filter");
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+    }
+    for (Device *w : p->workers) {
+        const int rc = rb_engine_create(w->device, w->filters.data(), n_deplete, w->filters.data() + n_deplete, n_target, &w->engine);
+        if (rc != RB_OK) { rb_pool_destroy(p); return rc; }
+    }
+    p->start();
+    if (replication_seconds) *replication_seconds = copy_s;
+    *out = p;
+    return RB_OK;
+}
+
+int rb_pool_get_stats(rb_pool *p, size_t n, int *devices, double *busy_seconds, uint64_t *reads, uint64_t *calls, int reset)
+{
+    if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    for (size_t i = 0; i < n && i < p->workers.size(); ++i) {
+        Device *w = p->workers[i];
+        if (devices) devices[i] = w->device;
+        if (busy_seconds) busy_seconds[i] = (double)w->busy_ns.load() * 1e-9;
+        if (reads) reads[i] = w->reads.load();
+        if (calls) calls[i] = w->calls.load();
+        if (reset) { w->busy_ns = 0; w->reads = 0; w->calls = 0; }
+    }
     return RB_OK;
 }
 
@@ -209,11 +269,17 @@ int rb_pool_classify_batch(rb_pool *p, const char *seqs, const uint64_t *offsets
     rbq::Job job;
     p->dispatcher->dispatch(parts, job, [&](size_t k, size_t w) -> std::function<int()> {
         const size_t b = k * per, e = std::min(n_reads, b + per);
-        rb_engine *eng = p->workers[w]->engine;
+        Device *dev = p->workers[w];
+        rb_engine *eng = dev->engine;
         return [=] {
-            return rb_classify_batch(eng, seqs, offsets + b, lens + b, e - b, error_rate, significance, mode,
-                                     out_maxcount ? out_maxcount + b * nf : nullptr, out_best_target ? out_best_target + b : nullptr,
-                                     out_decision ? out_decision + b : nullptr, out_status ? out_status + b : nullptr);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int rc = rb_classify_batch(eng, seqs, offsets + b, lens + b, e - b, error_rate, significance, mode,
+                                             out_maxcount ? out_maxcount + b * nf : nullptr, out_best_target ? out_best_target + b : nullptr,
+                                             out_decision ? out_decision + b : nullptr, out_status ? out_status + b : nullptr);
+            dev->busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            dev->reads += e - b;
+            dev->calls += 1;
+            return rc;
         };
     });
     job.wait();

@@ -54,9 +54,13 @@ def test_gpus2_default_line_structure_cpu():
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
                 "roofline", "cpu_baseline", "parity", "ranks", "other_configs"):
         assert key in d, key
-    assert set(d["other_configs"]) == {"c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target"}
+    assert set(d["other_configs"]) == {"c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4"}
     for sub in d["other_configs"].values():
         assert sub["n_gpus"] == 2 and sub["value"] > 0
+    # the one-process pool legs: rank 0 measures alone, the other rank waits for it on the HOST (rendezvous store), not in a
+    # collective that would spin on its GPU
+    for leg in ("pool_c3", "pool_c4"):
+        assert d["other_configs"][leg]["rank0_only"] is True and d["other_configs"][leg]["waited_on_store"] is True
     r = d["ranks"]
     assert "rccl_ranks" in r and "xgmi_preflight" in r and len(r["devices"]) == 2 and len(r["per_rank_reads_per_s"]) == 2
     assert sorted(x["rank"] for x in r["devices"]) == [0, 1]
@@ -154,6 +158,9 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
         for leg in ("c3np2", "c2", "c4", "readme", "targets3", "deplete_target"):
             par = d["other_configs"][leg]["parity"]
             assert par["decision_mismatches"] == 0 and par["raw_max_mismatches"] == 0 and par["checked_reads"] > 0, leg
+        for leg in ("pool_c3", "pool_c4"):  # one process through rb_pool: outputs equal to a single engine's
+            assert d["other_configs"][leg]["parity"]["pool_outputs_equal_single_engine"] is True, leg
+            assert d["other_configs"][leg]["pool"]["per_device"][0]["reads"] > 0
         assert "generic modulus" in d["other_configs"]["c3np2"]["config"]["workload"]
         assert d["other_configs"]["c3np2"]["config"]["filters"][0]["bytes"] % (1 << 20) != 0  # BinSizeBits x 8256: not a power of two
         # (latency SLO and keep-up of the c5 leg: wall-clock figures, asserted by test_c5_leg_meets_its_slo under -m gpuperf)
@@ -172,3 +179,18 @@ def test_c5_leg_meets_its_slo():
     p, d = _run(["--gpus", "1", "--workload", "c5"], {}, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     assert d["latency"]["slo_met"] is True and d["live_step"]["kept_up"] is True and d["live_step"]["slo_met"] is True
+
+
+@pytest.mark.gpu
+def test_pool_leg_two_workers_on_one_gpu():
+    """`bench.py --pool` with the test hook RB_BENCH_POOL_DEVICES=0,0: two workers (engine + host thread + replica each) on the one
+    GPU of the box, every call cut into two slices -- the structure of the line, both workers served reads, outputs equal to a
+    single engine's (the N-GPU form of this leg needs an N-GPU node; the pool's replication and slicing are the same code)"""
+    p, d = _run(["--gpus", "1", "--pool", "--steps", "2"], {"RB_BENCH_POOL_DEVICES": "0,0", "RB_BENCH_READS_DIVISOR": "10"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for leg in (d, d["other_configs"]["pool_c4"]):
+        assert leg["config"]["devices"] == [0, 0] and leg["n_gpus"] == 2 and leg["value"] > 0
+        assert leg["parity"]["pool_outputs_equal_single_engine"] is True
+        per = leg["pool"]["per_device"]
+        assert len(per) == 2 and all(x["reads"] > 0 and x["calls"] >= 2 and 0 < x["busy_share"] <= 1.05 for x in per)
+        assert leg["pool"]["replication_seconds"] >= 0 and leg["pool"]["replicated_bytes_per_device"] > (8 << 30)
