@@ -88,7 +88,7 @@ struct PhaseRule {
     SliceStep small_full[2];     // reads that fill the shape (>= 0.9): tables below these sizes get 512 KiB / 1 MiB slices
     SliceStep small_partial[2];  // reads that leave it partly empty: larger pieces (session 57)
     double four_mib_from_mib;    // 2 MiB slices below this table size, 4 MiB from it on
-    bool four_mib_scaled;        // ... x fill, and "below" is strict; false: the bound itself still takes 2 MiB slices (wide shapes)
+    bool four_mib_scaled;        // ... x fill, and "below" is strict; false: unscaled, and the bound itself still takes 2 MiB slices (wide rounds)
     // ---- window length by slice size: 512 KiB, 1 MiB, 2 MiB, 4 MiB and more
     Window window[4];
     double partial_2mib_ticks;   // 2 MiB slices, at most four of them, reads that leave the shape partly empty (0: no such rule)
@@ -127,7 +127,8 @@ constexpr PhaseRule kPhaseRules[] = {
      {}, {}, 10.0, true,
      {curve(450, 0), curve(450, 0), curve(450, 0), curve(200, 2500)}, 0},
     {"six tiles, two-word", PhaseShape::SixTiles, 1, 348.0,
-     {{0.9, 1280_KiB}, {0.75, 3_MiB}, {0.0, 4608_KiB}}, 64_MiB,   // 64 MiB: 22.2 against 35.1 ms plain; at 96 MiB the optimum is narrow
+     {{0.9, 1280_KiB}, {0.75, 3_MiB}, {0.0, 4608_KiB}}, 80_MiB,   // 64 MiB: 22.2 against 35.1 ms plain; 80 MiB (300 bp): 25.3-27.5 against 29.7
+                                                                  // (r04 guard run); at 96 MiB the optimum is narrow
      {{2.5, 19}, {7.0, 20}}, {{7.5, 21}}, 18.5, true,
      {constant(400), constant(400), curve(400, 0, 400), curve(150, 4400, 400)}, 600},   // (below 400 ticks the times get erratic)
     // ------------------------------------------------------------------------------- three- and four-word blocks (129-256 bins), one lane per block
@@ -136,12 +137,13 @@ constexpr PhaseRule kPhaseRules[] = {
      {}, {}, 13.0, false,
      {constant(325), constant(325), constant(325), int_curve(2400, 400)}, 0},   // (16 MiB: 600, 24 MiB: 400 -- session 50)
     {"wide, four tiles (four-word build)", PhaseShape::WideFourTiles, 2, 238.0,
-     {{0.8, 4608_KiB}, {0.0, kNever}}, 48_MiB,     // 40 MiB: 17.2 against 22.8 ms plain (250 bp)
-     {}, {}, 12.0, false,
+     {{0.75, 4608_KiB}, {0.0, kNever}}, 48_MiB,    // 40 MiB: 17.2 against 22.8 ms plain (250 bp); 200 bp reads, 36 MiB: 15.1 against 17.6 (r04 guard run)
+     {}, {}, 12.0, true,
      {constant(400), constant(400), constant(400), constant(500)}, 0},
     {"wide, four tiles (three-word build)", PhaseShape::Wide3FourTiles, 2, 238.0,
-     {{0.8, 3_MiB}, {0.0, kNever}}, 48_MiB,        // 4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB
-     {}, {}, 14.0, false,
+     {{0.75, 3_MiB}, {0.0, kNever}}, 48_MiB,       // 4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB; 200 bp reads, 13 MiB: 10.2 in
+                                                   // four slices of 4 MiB against 13.0 plain and 12.0 in slices of 2 MiB (r04 guard run: the switch scales)
+     {}, {}, 14.0, true,
      {constant(500), constant(500), constant(500), steps(4, 850, 8, 600, 500)}, 0},   // (five waves per SIMD: longer windows, session 53)
     {"wide, rounds of three tiles (three-word build)", PhaseShape::Wide3Rounds, 2, 348.0,
      {{0.0, 6_MiB}}, 48_MiB,
@@ -200,6 +202,9 @@ inline uint64_t phase_window_ticks(PhaseShape shape, int lg, uint32_t slice_log2
     }
     if (w.full_floor_n && fill >= 0.9) return (uint64_t)std::max(w.base + w.cycle / n, n_slices <= w.full_floor_n ? w.full_floor_small : w.full_floor_large);
     const double t = (w.base + w.cycle / n) * fill;
+    // (reads that leave the shape partly empty: the floor of the few-slices case shrinks with the cycle -- round 4's guard run found the
+    // scaled curve alone in a bad spot: two-word 200 bp 45 MiB 14.7 ms at 408 ticks against 11.0 at 489)
+    if (w.full_floor_n && n_slices <= w.full_floor_n) return (uint64_t)std::max(t, std::max(w.floor, w.full_floor_small * fill));
     return (uint64_t)std::max(t, w.floor);
 }
 

@@ -194,8 +194,8 @@ struct IngestOptions
     unsigned classify_threads = 0;  // threads running the chunk loop on the GPU and formatting their segment's output (one engine
                                     // each); 0 = [IBF] threads when the TOML sets it above 1 (the reference's meaning of that key:
                                     // classification threads, adaptive_sampling.hpp:745), else 4
-    bool mmap_output = true;     // outputs are written through shared mappings by the classifier threads themselves (--no-mmap-output:
-                                 // positional writes of heap buffers)
+    bool mmap_output = false;    // --mmap-output: the classifier threads write the outputs through shared mappings of the files instead of
+                                 // positional writes of a small buffer each (measured slower on tmpfs: page faults on fresh page-cache pages)
     size_t segment_mb = 64;      // file bytes per parsed segment
     size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
     size_t live_batch = 64;      // usage "target" replay: chunks per micro-batch
@@ -293,8 +293,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             }
             return so;
         };
-        // pass 2: the FASTA text of the segment, written where pass 1 and the reservation said (cur[f] = this segment's share of file f)
-        auto format_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state, std::vector<char*>& cur) {
+        // pass 2: the FASTA text of the segment, written where pass 1 and the reservation said (out[f] = cursor over this segment's share of file f)
+        auto format_segment = [&](const seqio::Segment& seg, const std::vector<ReadState>& state, std::vector<seqio::OrderedOutput::Writer>& out) {
             const std::vector<seqio::Record>& recs = seg.batch.records;
             for (size_t i = 0; i < recs.size(); ++i) {
                 const seqio::Record& r = recs[i];
@@ -304,15 +304,15 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     if (!(target && state[i].best >= 0)) continue;
                     f = (size_t)state[i].best;
                 }
-                char* dst = cur[f];
+                const bool one_line = f != n_out - 1;
+                char* dst = out[f].take((size_t)fasta_bytes(r, one_line));
                 *dst++ = '>';
                 std::memcpy(dst, r.id, r.id_len);
                 dst += r.id_len;
                 *dst++ = '\n';
-                if (f != n_out - 1) {
+                if (one_line) {
                     std::memcpy(dst, r.seq, r.seq_len);
-                    dst += r.seq_len;
-                    *dst++ = '\n';
+                    dst[r.seq_len] = '\n';
                 } else {
                     // the Dna5 alphabet (upper case, everything but ACGT[U] becomes N) in 70-column lines
                     for (size_t p = 0; p < r.seq_len; p += 70) {
@@ -322,7 +322,6 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                         dst += n + 1;
                     }
                 }
-                cur[f] = dst;
             }
         };
 
@@ -405,6 +404,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         uint64_t next_seq = 0, write_seq = 0;
         std::string worker_error;
         auto classifier = [&] {
+            std::vector<std::vector<char>> chunks(n_out);  // this thread's write buffers, one per output file, kept for all its segments
             try {
                 for (;;) {
                     std::unique_ptr<seqio::Segment> seg;
@@ -446,22 +446,17 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     ocv.notify_all();
                     // ... and the text itself, by every classifier thread at once
                     const auto tf = std::chrono::steady_clock::now();
-                    std::vector<seqio::OrderedOutput::Window> win(n_out);
-                    std::vector<char*> cur(n_out, nullptr);
-                    std::vector<char> sink;  // a file that could not be opened (target FASTAs are not checked by the reference): formatted into the void
+                    std::vector<seqio::OrderedOutput::Writer> out(n_out);
+                    seqio::OrderedOutput nowhere;  // a file that could not be opened (target FASTAs are not checked by the reference): formatted into the void
                     for (size_t f = 0; f < n_out; ++f) {
-                        if (outputs[f]->is_open()) {
-                            win[f] = outputs[f]->map(at[f], (size_t)so.bytes[f]);
-                            cur[f] = win[f].data();
-                        } else {
-                            if (sink.size() < so.bytes[f]) sink.resize((size_t)so.bytes[f]);
-                            cur[f] = sink.data();
-                        }
+                        if (outputs[f]->is_open()) out[f] = outputs[f]->writer(at[f], so.bytes[f], chunks[f]);
+                        else out[f] = nowhere.writer(0, so.bytes[f], chunks[f]);
                     }
-                    format_segment(*seg, state, cur);
-                    for (size_t f = 0; f < n_out; ++f)
-                        if (outputs[f]->is_open() && cur[f] != win[f].data() + so.bytes[f]) throw std::runtime_error("output layout mismatch");
-                    win.clear();  // unmap / write out
+                    format_segment(*seg, state, out);
+                    for (size_t f = 0; f < n_out; ++f) {
+                        const bool complete = outputs[f]->is_open() ? out[f].finish() : true;
+                        if (!complete) throw std::runtime_error("output layout mismatch");
+                    }
                     seg.reset();
                     {
                         std::lock_guard<std::mutex> lock(omu);
@@ -671,6 +666,7 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--mmap-output")) opt.mmap_output = true;
         else if (!std::strcmp(argv[i], "--no-mmap-output")) opt.mmap_output = false;
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--segment-bytes") && i + 1 < argc) opt.segment_bytes = (size_t)std::stoull(argv[++i]);
@@ -699,7 +695,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--no-mmap-output] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] "
                          "[--devices 0,1,...] [--parse-stats file]\n"
                          "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;

@@ -454,18 +454,24 @@ public:
 
 // ---- parallel, ordered output ----------------------------------------------------------------------------------------
 // An output file that several threads fill at once, each its own byte range, in an order fixed beforehand: reserve() hands
-// out consecutive ranges (the callers take turns in file order -- a few arithmetic instructions under a lock), map() gives
-// a writable window on one range.  With `use_mmap` the window is a MAP_SHARED mapping of the file itself: the formatted text
-// is written once, straight into the page cache, by as many threads as there are windows (a single writer thread doing
-// write() tops out at a few GB/s -- every byte is formatted into a buffer and then copied again under the inode lock).
-// Without it (or when the file system refuses to map: pipes, some network mounts) a window is a heap buffer that goes out
-// with one pwrite() when it is closed.  close() cuts the file to the bytes reserved.  Errors are sticky and reported by ok().
+// out consecutive ranges (the callers take turns in file order -- a few arithmetic instructions under a lock), writer()
+// gives a cursor over one range that the caller fills record by record (take(n) = the next n bytes).  Two ways to the page
+// cache behind that cursor:
+//   positional writes (default): the text is formatted into a small buffer the calling thread keeps for good (cache resident,
+//     no fresh pages) and goes out with pwrite() whenever the buffer is full -- several threads write their ranges of one
+//     file and different files at the same time; a single writer thread doing write() of whole segments topped out at
+//     ~3 GB/s, i.e. ~11 M reads/s of the narrow-filter workloads the CLI serves;
+//   a shared mapping of the file (`use_mmap`): the text is written once, straight into the page cache; the file is mapped
+//     into one reserved stretch of address space as it grows, pages come by faults.
+// close() cuts the file to the bytes reserved.  Errors are sticky and reported by ok().
 class OrderedOutput
 {
     int fd_ = -1;
-    bool use_mmap_ = true;
+    bool use_mmap_ = false;
     std::mutex mu_;
     uint64_t reserved_ = 0, file_len_ = 0;
+    char* va_ = nullptr;        // mapped mode: the reserved stretch of address space, file offset 0 at va_
+    uint64_t va_len_ = 0, mapped_len_ = 0;
     std::atomic<bool> failed_{false};
     std::string error_;
     void fail(const std::string& what)
@@ -475,38 +481,48 @@ class OrderedOutput
     }
 
 public:
-    class Window
+    static constexpr size_t kChunk = (size_t)2 << 20;  // positional writes: bytes formatted between two pwrite() calls
+
+    // cursor over one reserved range
+    class Writer
     {
         friend class OrderedOutput;
         OrderedOutput* owner_ = nullptr;
-        char* map_base_ = nullptr;
-        size_t map_len_ = 0;
-        std::unique_ptr<char[]> heap_;
-        uint64_t off_ = 0;
-        size_t bytes_ = 0;
-        char* ptr_ = nullptr;
-    public:
-        Window() = default;
-        Window(Window&& o) noexcept { *this = std::move(o); }
-        Window& operator=(Window&& o) noexcept
+        uint64_t off_ = 0;       // file offset of the next byte to go out
+        uint64_t left_ = 0;      // bytes of the range not handed out yet
+        char* map_cur_ = nullptr;
+        std::vector<char>* buf_ = nullptr;  // positional mode: the calling thread's chunk buffer
+        size_t fill_ = 0;
+        void flush()
         {
-            close();
-            owner_ = o.owner_; map_base_ = o.map_base_; map_len_ = o.map_len_; heap_ = std::move(o.heap_);
-            off_ = o.off_; bytes_ = o.bytes_; ptr_ = o.ptr_;
-            o.owner_ = nullptr; o.map_base_ = nullptr; o.ptr_ = nullptr; o.bytes_ = 0;
-            return *this;
+            if (fill_ && owner_->fd_ >= 0) owner_->pwrite_all(buf_->data(), fill_, off_);
+            off_ += fill_;
+            fill_ = 0;
         }
-        ~Window() { close(); }
-        char* data() const { return ptr_; }
-        size_t size() const { return bytes_; }
-        void close()
+    public:
+        // the next n bytes of the range, contiguous, to be filled before the next take()
+        char* take(size_t n)
         {
-            if (map_base_) munmap(map_base_, map_len_);
-            else if (heap_ && owner_ && bytes_) owner_->pwrite_all(heap_.get(), bytes_, off_);
-            map_base_ = nullptr;
-            heap_.reset();
-            ptr_ = nullptr;
-            bytes_ = 0;
+            if (n > left_) throw std::runtime_error("output layout mismatch");
+            left_ -= n;
+            if (map_cur_) {
+                char* p = map_cur_;
+                map_cur_ += n;
+                return p;
+            }
+            if (fill_ + n > buf_->size()) {
+                flush();
+                if (n > buf_->size()) buf_->resize(n);
+            }
+            char* p = buf_->data() + fill_;
+            fill_ += n;
+            return p;
+        }
+        // everything handed out has been filled: positional mode writes the rest; false if the range was not used up
+        bool finish()
+        {
+            if (owner_ && !map_cur_) flush();
+            return left_ == 0;
         }
     };
 
@@ -517,9 +533,20 @@ public:
 
     bool open(const std::string& path, bool use_mmap)
     {
-        use_mmap_ = use_mmap;
         fd_ = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);
-        return fd_ >= 0;
+        if (fd_ < 0) return false;
+        use_mmap_ = false;
+        if (use_mmap) {
+            // address space for the whole file, whatever it grows to (nothing is committed): the file is mapped into it piece by piece
+            const uint64_t want = (uint64_t)1 << 40;
+            void* p = mmap(nullptr, want, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (p != MAP_FAILED) {
+                va_ = (char*)p;
+                va_len_ = want;
+                use_mmap_ = true;
+            }
+        }
+        return true;
     }
     bool is_open() const { return fd_ >= 0; }
     bool ok() const { return !failed_.load(); }
@@ -530,51 +557,46 @@ public:
     }
     uint64_t bytes() const { return reserved_; }
 
-    // the next `bytes` bytes of the file; callers take turns in output order.  The file is grown ahead in large steps
-    // (sparse: nothing is allocated until a page is written).
+    // the next `bytes` bytes of the file; callers take turns in output order.  Mapped mode grows the file (sparse) and its
+    // mapping ahead in large steps.
     uint64_t reserve(uint64_t bytes)
     {
         std::lock_guard<std::mutex> lock(mu_);
         const uint64_t off = reserved_;
         reserved_ += bytes;
-        if (use_mmap_ && reserved_ > file_len_) {
-            uint64_t want = std::max<uint64_t>(file_len_ * 2, (uint64_t)256 << 20);
+        if (use_mmap_ && reserved_ > mapped_len_) {
+            uint64_t want = std::max<uint64_t>(mapped_len_ * 2, (uint64_t)1 << 30);
             while (want < reserved_) want *= 2;
-            if (ftruncate(fd_, (off_t)want) != 0) {
-                use_mmap_ = false;  // e.g. a pipe: plain positional (or sequential) writes from here on
-            } else {
+            bool grown = want <= va_len_ && ftruncate(fd_, (off_t)want) == 0;
+            if (grown) {
                 file_len_ = want;
+                void* p = mmap(va_ + mapped_len_, want - mapped_len_, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, fd_, (off_t)mapped_len_);
+                grown = p != MAP_FAILED;
             }
+            if (grown) mapped_len_ = want;
+            // (not grown: ranges beyond the mapping go out by positional writes -- writer() looks at mapped_len_)
         }
         return off;
     }
 
-    Window map(uint64_t off, size_t bytes)
+    // cursor over [off, off + bytes); `chunk` = the calling thread's buffer for the positional mode (kept across calls)
+    Writer writer(uint64_t off, uint64_t bytes, std::vector<char>& chunk)
     {
-        Window w;
+        Writer w;
         w.owner_ = this;
         w.off_ = off;
-        w.bytes_ = bytes;
-        if (bytes == 0) return w;
-        bool mm;
+        w.left_ = bytes;
+        bool mapped;
         {
             std::lock_guard<std::mutex> lock(mu_);
-            mm = use_mmap_ && off + bytes <= file_len_;
+            mapped = use_mmap_ && off + bytes <= mapped_len_;
         }
-        if (mm) {
-            const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
-            const uint64_t lo = off / page * page;
-            const size_t len = (size_t)(off + bytes - lo);
-            void* p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd_, (off_t)lo);
-            if (p != MAP_FAILED) {
-                w.map_base_ = (char*)p;
-                w.map_len_ = len;
-                w.ptr_ = (char*)p + (off - lo);
-                return w;
-            }
+        if (mapped) {
+            w.map_cur_ = va_ + off;
+        } else {
+            if (chunk.size() < kChunk) chunk.resize(kChunk);
+            w.buf_ = &chunk;
         }
-        w.heap_.reset(new char[bytes]);
-        w.ptr_ = w.heap_.get();
         return w;
     }
 
@@ -589,6 +611,8 @@ public:
 
     void close()
     {
+        if (va_) munmap(va_, va_len_);
+        va_ = nullptr;
         if (fd_ < 0) return;
         if (file_len_ != reserved_ && file_len_ != 0 && ftruncate(fd_, (off_t)reserved_) != 0) fail("truncate failed");
         ::close(fd_);

@@ -1,6 +1,7 @@
 // test_seqio.cpp -- CPU-only checks of the parallel ingest's failure paths (readbouncer_amd/host/seqio.hpp):
 // a page-locked allocator that refuses falls back to the heap with the same records and prefixes; an allocator that
 // throws inside a worker thread ends the stream with an error segment instead of std::terminate.
+#include <atomic>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -77,6 +78,7 @@ int main()
         for (int i = 0; i < 200; ++i) {
             pieces.emplace_back((size_t)((i * 7919) % 30011) + (i % 5 == 0 ? 0 : 1), (char)('a' + i % 26));  // some empty pieces
             if (i % 5 == 0) pieces.back().clear();
+            if (i == 77 || i == 78) pieces.back().assign(((size_t)5 << 20) + 3 + (size_t)i, (char)('A' + i % 26));  // ranges of several chunk buffers
             expect += pieces.back();
         }
         {
@@ -85,15 +87,32 @@ int main()
             std::vector<uint64_t> at(pieces.size());
             for (size_t i = 0; i < pieces.size(); ++i) at[i] = out.reserve(pieces[i].size());
             std::vector<std::thread> th;
+            std::atomic<int> short_ranges{0};
             for (int t = 0; t < 4; ++t)
                 th.emplace_back([&, t] {
+                    std::vector<char> chunk;  // this thread's write buffer (positional mode), kept across its ranges
                     for (size_t i = (size_t)t; i < pieces.size(); i += 4) {
-                        seqio::OrderedOutput::Window w = out.map(at[i], pieces[i].size());
-                        if (!pieces[i].empty()) std::memcpy(w.data(), pieces[i].data(), pieces[i].size());
+                        seqio::OrderedOutput::Writer w = out.writer(at[i], pieces[i].size(), chunk);
+                        // records of uneven sizes, some larger than nothing, one larger than the chunk buffer would be with a small kChunk
+                        size_t pos = 0, step = 1;
+                        while (pos < pieces[i].size()) {
+                            const size_t n = std::min(step, pieces[i].size() - pos);
+                            std::memcpy(w.take(n), pieces[i].data() + pos, n);
+                            pos += n;
+                            step = step * 3 + 1;
+                        }
+                        if (!w.finish()) ++short_ranges;
                     }
                 });
             for (auto& x : th) x.join();
-            CHECK(out.bytes() == expect.size());
+            CHECK(out.bytes() == expect.size() && short_ranges == 0);
+            {   // a range that is not used up is reported, one that is overrun throws
+                std::vector<char> chunk;
+                seqio::OrderedOutput::Writer w = out.writer(out.reserve(0), 0, chunk);
+                bool threw = false;
+                try { w.take(1); } catch (const std::exception&) { threw = true; }
+                CHECK(threw && w.finish());
+            }
             out.close();
             CHECK(out.ok());
         }

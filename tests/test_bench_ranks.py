@@ -193,4 +193,4 @@ def test_pool_leg_two_workers_on_one_gpu():
         assert leg["parity"]["pool_outputs_equal_single_engine"] is True
         per = leg["pool"]["per_device"]
         assert len(per) == 2 and all(x["reads"] > 0 and x["calls"] >= 2 and 0 < x["busy_share"] <= 1.05 for x in per)
-        assert leg["pool"]["replication_seconds"] >= 0 and leg["pool"]["replicated_bytes_per_device"] > (8 << 30)
+        assert leg["pool"]["replication_seconds"] >= 0 and leg["pool"]["replicated_bytes_per_device"] >= (8 << 30)
