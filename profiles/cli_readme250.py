@@ -96,20 +96,23 @@ def run(args, tag):
     a = time.time()
     p = subprocess.run([cli, "--config", cfg] + args, capture_output=True, text=True)
     wall = time.time() - a
-    lines = [l for l in p.stdout.splitlines() if l.startswith(("RESULT", "THROUGHPUT"))]
-    print("%-44s process wall %.2f s = %.2f M reads/s | %s %s" % (tag, wall, n_reads / wall / 1e6, " | ".join(lines), p.stderr.strip()[-160:]), flush=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith(("RESULT", "THROUGHPUT", "PHASES", "Real time", "CPU time"))]
+    print("%-44s process wall %.2f s = %.2f M reads/s | %s %s" % (tag, wall, n_reads / wall / 1e6, " | ".join(lines), p.stderr.strip().replace("\n", " ")[-80:]), flush=True)
 
 
 run([], "warm-up (defaults)")
-for ingest, cls in ((6, 4), (6, 4), (4, 2), (8, 4), (8, 6), (12, 4), (12, 6), (12, 8), (6, 1)):
+for ingest, cls in ((6, 4), (6, 4), (4, 2), (8, 4), (8, 6), (8, 8), (6, 8), (12, 6), (6, 1)):
     run(["--ingest-threads", str(ingest), "--classify-threads", str(cls)], "parsers %d classifiers %d" % (ingest, cls))
 run(["--ingest-threads", "8", "--classify-threads", "6", "--batch-reads", "131072"], "parsers 8 classifiers 6 batch 131072")
 run(["--ingest-threads", "8", "--classify-threads", "6", "--segment-mb", "32"], "parsers 8 classifiers 6 segment 32 MB")
+run(["--ingest-threads", "8", "--classify-threads", "6", "--segment-mb", "16", "--batch-reads", "32768"], "parsers 8 classifiers 6 segment 16 MB batch 32768")
 run(["--ingest-threads", "8", "--classify-threads", "6"], "parsers 8 classifiers 6 (outputs digested)")
 par = digest_outputs()
-run(["--ingest-threads", "8", "--classify-threads", "6", "--no-mmap-output"], "parsers 8 classifiers 6 --no-mmap-output")
-run(["--ingest-threads", "1", "--classify-threads", "1", "--no-mmap-output", "--batch-reads", "1000000"], "serial: 1 parser 1 classifier, positional writes")
+run(["--ingest-threads", "8", "--classify-threads", "6", "--mmap-output"], "parsers 8 classifiers 6 --mmap-output")
+mm = digest_outputs()
+run(["--ingest-threads", "1", "--classify-threads", "1", "--batch-reads", "1000000"], "serial: 1 parser 1 classifier")
 ser = digest_outputs()
+print("outputs byte-identical, mapped-output run against the serial run:", mm == ser and len(mm) == 4)
 print("outputs:", {k: v[0] for k, v in par.items()})
-print("outputs byte-identical between the parallel mapped run and the serial positional-write run:", par == ser and len(par) == 4)
+print("outputs byte-identical, parallel run (positional writes) against the serial run:", par == ser and len(par) == 4)
 subprocess.run(["rm", "-rf", work])
