@@ -1705,23 +1705,40 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
     // ---- large batches: the spanned byte range goes over as it is (offsets stay valid relative to a shifted base), in
     // slices of consecutive reads: slice i+1 crosses PCIe on the copy stream while slice i is counted.  A pageable
     // source makes hipMemcpyAsync block the host while it stages, which is exactly when the GPU works on the slice before.
+    // Offsets and lengths go through the engine's page-locked input block (one asynchronous copy each, ahead of the first
+    // slice), and -- up to 4 M reads per call -- the decision kernel writes its results and a copy of the maxcount rows
+    // straight into the page-locked output block, like the micro-batch path: no device-to-host copy command behind the
+    // kernels, no pageable copy that would block the calling thread four times per call while other host threads wait for
+    // the GPU (the CLI's classifier threads: one call per 32-64 k reads each).
     const uint64_t span = hi - lo;
+    const bool direct_out = !sharded && n <= ((size_t)1 << 22);
+    const size_t out_bytes = 4 * n + 2 * nf * n + 2 * n;
     {
         std::lock_guard<std::mutex> lock(e->mu);
         if ((rc = e->d_seqs.ensure(span ? span : 1)) != RB_OK) return rc;
         if ((rc = e->d_offsets.ensure(n * 8)) != RB_OK) return rc;
         if ((rc = e->d_lens.ensure(n * 4)) != RB_OK) return rc;
         if ((rc = e->d_maxcount.ensure(n * nf * 2)) != RB_OK) return rc;
-        if ((rc = e->d_best.ensure(n * 4)) != RB_OK) return rc;
-        if ((rc = e->d_decision.ensure(n)) != RB_OK) return rc;
-        if ((rc = e->d_status.ensure(n)) != RB_OK) return rc;
+        if ((rc = e->h_in.ensure(n * 12)) != RB_OK) return rc;
+        if (direct_out) {
+            if ((rc = e->h_out.ensure(out_bytes)) != RB_OK) return rc;
+        } else {
+            if ((rc = e->d_best.ensure(n * 4)) != RB_OK) return rc;
+            if ((rc = e->d_decision.ensure(n)) != RB_OK) return rc;
+            if ((rc = e->d_status.ensure(n)) != RB_OK) return rc;
+        }
     }
     char *d_seqs = (char *)e->d_seqs.p;
     uint64_t *d_off = (uint64_t *)e->d_offsets.p;
     uint32_t *d_len = (uint32_t *)e->d_lens.p;
     uint16_t *d_max = (uint16_t *)e->d_maxcount.p;
+    char *hout = (char *)e->h_out.p;
     const char *d_base = d_seqs - lo;  // device address of the caller's seqs[0]
     hipStream_t cs = e->copy_stream;
+    std::memcpy(e->h_in.p, offsets, n * 8);
+    std::memcpy((char *)e->h_in.p + n * 8, lens, n * 4);
+    RB_HIP(hipMemcpyAsync(d_off, e->h_in.p, n * 8, hipMemcpyHostToDevice, cs));
+    RB_HIP(hipMemcpyAsync(d_len, (char *)e->h_in.p + n * 8, n * 4, hipMemcpyHostToDevice, cs));
     size_t i0 = 0, slice = 0;
     while (i0 < n) {
         uint64_t bytes = 0, s_lo = ~0ULL, s_hi = 0;
@@ -1743,13 +1760,22 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         // reads that alias or interleave across slices are copied again to the same place: same bytes, no hazard for the
         // kernels already reading them
         if (s_hi > s_lo) RB_HIP(hipMemcpyAsync(d_seqs + (s_lo - lo), seqs + s_lo, s_hi - s_lo, hipMemcpyHostToDevice, cs));
-        RB_HIP(hipMemcpyAsync(d_off + i0, offsets + i0, cnt * 8, hipMemcpyHostToDevice, cs));
-        RB_HIP(hipMemcpyAsync(d_len + i0, lens + i0, cnt * 4, hipMemcpyHostToDevice, cs));
         RB_HIP(hipEventRecord(e->copy_ev[evi], cs));
         RB_HIP(hipStreamWaitEvent(st, e->copy_ev[evi], 0));
-        rc = rb_classify_batch_device(e, d_base, d_off + i0, d_len + i0, cnt, max_len, error_rate, significance, mode,
-                                      d_max + i0 * nf, (int32_t *)e->d_best.p + i0, (uint8_t *)e->d_decision.p + i0,
-                                      (uint8_t *)e->d_status.p + i0, (void *)st);
+        rb_batch_desc desc;
+        std::memset(&desc, 0, sizeof desc);
+        desc.d_seqs = d_base;
+        desc.d_offsets = d_off + i0;
+        desc.d_lens = d_len + i0;
+        desc.n_items = cnt;
+        desc.max_len = max_len;
+        if (direct_out)
+            rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max + i0 * nf, hout + 4 * i0, hout + 4 * n + 2 * nf * n + i0,
+                                      hout + 4 * n + 2 * nf * n + n + i0, (void *)st, (uint16_t *)(hout + 4 * n) + i0 * nf);
+        else
+            rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max + i0 * nf, sharded ? nullptr : (int32_t *)e->d_best.p + i0,
+                                      sharded ? nullptr : (uint8_t *)e->d_decision.p + i0, sharded ? nullptr : (uint8_t *)e->d_status.p + i0, (void *)st,
+                                      nullptr);
         if (rc != RB_OK) {
             (void)hipStreamSynchronize(cs);
             (void)hipStreamSynchronize(st);
@@ -1757,6 +1783,14 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         }
         i0 = i1;
         ++slice;
+    }
+    if (direct_out) {
+        RB_HIP(hipStreamSynchronize(st));
+        if (out_maxcount) std::memcpy(out_maxcount, hout + 4 * n, 2 * nf * n);
+        if (out_best_target) std::memcpy(out_best_target, hout, 4 * n);
+        if (out_decision) std::memcpy(out_decision, hout + 4 * n + 2 * nf * n, n);
+        if (out_status) std::memcpy(out_status, hout + 4 * n + 2 * nf * n + n, n);
+        return RB_OK;
     }
     if (out_maxcount) RB_HIP(hipMemcpyAsync(out_maxcount, d_max, n * nf * 2, hipMemcpyDeviceToHost, st));
     if (!sharded) {
