@@ -101,11 +101,13 @@ def run(args, tag):
 
 
 run([], "warm-up (defaults)")
-for ingest, cls in ((6, 4), (6, 4), (4, 2), (8, 4), (8, 6), (8, 8), (6, 8), (12, 6), (6, 1)):
-    run(["--ingest-threads", str(ingest), "--classify-threads", str(cls)], "parsers %d classifiers %d" % (ingest, cls))
-run(["--ingest-threads", "8", "--classify-threads", "6", "--batch-reads", "131072"], "parsers 8 classifiers 6 batch 131072")
-run(["--ingest-threads", "8", "--classify-threads", "6", "--segment-mb", "32"], "parsers 8 classifiers 6 segment 32 MB")
-run(["--ingest-threads", "8", "--classify-threads", "6", "--segment-mb", "16", "--batch-reads", "32768"], "parsers 8 classifiers 6 segment 16 MB batch 32768")
+run([], "defaults")
+run([], "defaults")
+for seg, batch in ((64, 65536), (16, 32768), (8, 16384), (32, 65536)):
+    for ingest, cls in ((6, 4), (6, 6), (6, 8), (4, 6), (4, 8), (8, 6)):
+        run(["--ingest-threads", str(ingest), "--classify-threads", str(cls), "--segment-mb", str(seg), "--batch-reads", str(batch)],
+            "parsers %d classifiers %d segment %d MB batch %d" % (ingest, cls, seg, batch))
+run(["--ingest-threads", "6", "--classify-threads", "1"], "parsers 6 classifiers 1")
 run(["--ingest-threads", "8", "--classify-threads", "6"], "parsers 8 classifiers 6 (outputs digested)")
 par = digest_outputs()
 run(["--ingest-threads", "8", "--classify-threads", "6", "--mmap-output"], "parsers 8 classifiers 6 --mmap-output")
