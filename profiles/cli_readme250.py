@@ -100,17 +100,20 @@ def run(args, tag):
     print("%-44s process wall %.2f s = %.2f M reads/s | %s %s" % (tag, wall, n_reads / wall / 1e6, " | ".join(lines), p.stderr.strip().replace("\n", " ")[-80:]), flush=True)
 
 
+# the floor under the output side: how fast bytes enter the page cache of this directory (unclassified.fasta is ONE file)
+probe = os.path.join(work, "pcw")
+if subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "profiles", "pagecache_write_probe.cpp"), "-o", probe]).returncode == 0:
+    print(subprocess.run([probe, work, "2700000000"], capture_output=True, text=True).stdout.strip(), flush=True)
 run([], "warm-up (defaults)")
+run([], "defaults (6 parsers, 6 classifiers, 32 MB segments)")
 run([], "defaults")
 run([], "defaults")
-for seg, batch in ((64, 65536), (16, 32768), (8, 16384), (32, 65536)):
-    for ingest, cls in ((6, 4), (6, 6), (6, 8), (4, 6), (4, 8), (8, 6)):
-        run(["--ingest-threads", str(ingest), "--classify-threads", str(cls), "--segment-mb", str(seg), "--batch-reads", str(batch)],
-            "parsers %d classifiers %d segment %d MB batch %d" % (ingest, cls, seg, batch))
-run(["--ingest-threads", "6", "--classify-threads", "1"], "parsers 6 classifiers 1")
-run(["--ingest-threads", "8", "--classify-threads", "6"], "parsers 8 classifiers 6 (outputs digested)")
+for ingest, cls, seg, batch in ((6, 4, 32, 65536), (8, 6, 32, 65536), (4, 6, 32, 65536), (6, 6, 16, 32768), (6, 6, 64, 65536), (6, 8, 32, 65536), (6, 2, 32, 65536)):
+    run(["--ingest-threads", str(ingest), "--classify-threads", str(cls), "--segment-mb", str(seg), "--batch-reads", str(batch)],
+        "parsers %d classifiers %d segment %d MB batch %d" % (ingest, cls, seg, batch))
+run([], "defaults (outputs digested)")
 par = digest_outputs()
-run(["--ingest-threads", "8", "--classify-threads", "6", "--mmap-output"], "parsers 8 classifiers 6 --mmap-output")
+run(["--mmap-output"], "defaults --mmap-output")
 mm = digest_outputs()
 run(["--ingest-threads", "1", "--classify-threads", "1", "--batch-reads", "1000000"], "serial: 1 parser 1 classifier")
 ser = digest_outputs()

@@ -5,6 +5,7 @@ fitted on -- 13 / 45 / 80 MiB x 200 / 300 / 430 bp for one- and two-word blocks,
   rule   K1 ms per 1 M reads with the engine left to itself (rb_engine_plan says what it chose),
   plain  the better of the plain kernel and the both-strands round without a clock,
   best   the best of a sweep of window length (0.5 ... 2 x the rule's) x slice size (1, 2, 4 MiB) with the phased form forced,
+         smoothed along the window length (a rule can aim for a flat optimum, not for a one-point dip),
 
 and exit non-zero when the rule is more than TOL (8 %) slower than the best of everything measured -- i.e. when a clock, firmware or
 compiler change has moved an optimum away from the fitted constants.  A table the rule leaves to the plain kernel is checked the
@@ -90,17 +91,31 @@ for point in args.points.split(","):
             sweep[(lg2, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
     eng.destroy()
     d.free()
+    # The best a window RULE can aim for is a point whose neighbours are good too: two-word and wide blocks show narrow dips between
+    # bad neighbours (r04: two-word 200 bp 13 MiB, 2 MiB slices: 350 ticks 8.33, 425 ticks 6.97, 500 ticks 7.49 ms) that no rule
+    # would hit on another box or clock.  So the yardstick is the sweep smoothed along the window length (half the point, a
+    # quarter of each neighbour); the raw best is printed beside it.
+    smooth = {}
+    for lg2 in {k[0] for k in sweep}:
+        ts = sorted(t for (l, t) in sweep if l == lg2)
+        for i, t in enumerate(ts):
+            lo = sweep[(lg2, ts[i - 1])] if i > 0 else sweep[(lg2, t)]
+            hi = sweep[(lg2, ts[i + 1])] if i + 1 < len(ts) else sweep[(lg2, t)]
+            smooth[(lg2, t)] = 0.5 * sweep[(lg2, t)] + 0.25 * lo + 0.25 * hi
     best_key = min(sweep, key=sweep.get) if sweep else None
-    t_best = min([t_plain] + ([sweep[best_key]] if best_key else []))
+    robust_key = min(smooth, key=smooth.get) if smooth else None
+    t_best = min([t_plain] + ([smooth[robust_key]] if robust_key else []))
     off = t_rule / t_best - 1.0
     chose = ("phased %s, %d slices of %d KiB, %d ticks" % (plan["phase_shape_name"], plan["phase_slices"], 1 << (plan["phase_slice_log2"] - 10),
                                                            plan["phase_window_ticks"])) if plan["phased"] else plan["kernel"] + " (no clock)"
     verdict = "ok" if off <= args.tol else "RULE OFF"
     if off > args.tol:
         bad.append(point)
-    print("%d-word %3d bp %5.1f MiB: rule %6.2f (%s) | plain %6.2f | best phased %s | rule vs best %+5.1f %%  %s"
+    print("%d-word %3d bp %5.1f MiB: rule %6.2f (%s) | plain %6.2f | best phased %s, smoothed %s | rule vs best %+5.1f %%  %s"
           % (W, L, mib, t_rule, chose, t_plain,
-             ("%6.2f at %d KiB x %d ticks" % (sweep[best_key], 1 << (best_key[0] - 10), best_key[1])) if best_key else "   n/a", off * 100, verdict), flush=True)
+             ("%6.2f at %d KiB x %d ticks" % (sweep[best_key], 1 << (best_key[0] - 10), best_key[1])) if best_key else "   n/a",
+             ("%6.2f at %d KiB x %d ticks" % (smooth[robust_key], 1 << (robust_key[0] - 10), robust_key[1])) if robust_key else "n/a",
+             off * 100, verdict), flush=True)
     if sweep:
         for lg2 in sorted({k[0] for k in sweep}):
             print("      slices of %4d KiB: " % (1 << (lg2 - 10)) + "  ".join("%d:%.2f" % (t, sweep[(lg2, t)]) for (l, t) in sorted(sweep) if l == lg2), flush=True)

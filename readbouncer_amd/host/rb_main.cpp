@@ -216,10 +216,11 @@ struct IngestOptions
     unsigned threads = 6;        // parser threads (one does ~3 GB/s of 250 bp FASTQ records)
     unsigned classify_threads = 0;  // threads running the chunk loop on the GPU and formatting their segment's output (one engine
                                     // each); 0 = [IBF] threads when the TOML sets it above 1 (the reference's meaning of that key:
-                                    // classification threads, adaptive_sampling.hpp:745), else 4
+                                    // classification threads, adaptive_sampling.hpp:745), else 6 (profiles/r04/cli_throughput_sweep.txt:
+                                    // 4 leave the GPU idle while they format, 8 only queue on the output files' inode locks)
     bool mmap_output = false;    // --mmap-output: the classifier threads write the outputs through shared mappings of the files instead of
                                  // positional writes of a small buffer each (measured slower on tmpfs: page faults on fresh page-cache pages)
-    size_t segment_mb = 64;      // file bytes per parsed segment
+    size_t segment_mb = 32;      // file bytes per parsed segment (one GPU call of ~65 k reads of 250 bp; the page-locked staging blocks scale with it)
     size_t segment_bytes = 0;    // tests: segments far smaller than a megabyte (0 = segment_mb)
     size_t live_batch = 64;      // usage "target" replay: chunks per micro-batch
     size_t bytes() const { return segment_bytes ? segment_bytes : (segment_mb << 20); }
@@ -494,7 +495,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             }
         };
         unsigned n_classifiers = opt.classify_threads ? opt.classify_threads
-                                                      : (config.IBF_Parsed.threads > 1 ? (unsigned)config.IBF_Parsed.threads : 4u);
+                                                      : (config.IBF_Parsed.threads > 1 ? (unsigned)config.IBF_Parsed.threads : 6u);
         {
             // (a multi-device pool spreads every call over its devices itself; two callers keep it fed while one formats)
             if (multi) n_classifiers = std::min(n_classifiers, 2u);

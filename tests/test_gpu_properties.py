@@ -59,6 +59,33 @@ def test_kernel_forms_and_load_policies_agree(c2):
     eng.set_nt_threshold(512 << 20)
 
 
+def test_host_batches_on_both_sides_of_the_direct_output_limit(c2):
+    """rb_classify_batch on large host batches: up to 4 M reads per call the decision kernel writes its results straight into
+    the engine's page-locked output block, beyond that they come back by device-to-host copies -- the same rows either way:
+    one call of 2^22 + 12 345 short reads against the two halves of it as calls of their own, and a sample against the oracle"""
+    d, eng, buf, offs, lens, base = c2
+    n, L = (1 << 22) + 12345, 50
+    rng = np.random.default_rng(123)
+    reads = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=n * L, dtype=np.uint8)]
+    # every 1000th read is a planted window of the batch the fixture classified (so that some maxima are large)
+    src = buf.reshape(-1, 360)
+    for i in range(0, n, 1000):
+        reads[i * L:(i + 1) * L] = src[(i // 1000) % len(src), 100:100 + L]
+    o = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    ln = np.full(n, L, dtype=np.uint32)
+    whole = eng.classify(reads, o, ln)
+    half = n // 2
+    a = eng.classify(reads, o[:half], ln[:half])
+    b = eng.classify(reads, o[half:], ln[half:])
+    for k in (0, 1, 2, 3):
+        assert np.array_equal(whole[k], np.concatenate([a[k], b[k]])), k
+    assert int(whole[0].max()) >= 30 and (whole[3] == capi.RB_OK).all()
+    host = d.download()
+    orc = po.OracleIBF.wrap(host.info["n_bins"], 3, 13, host.info["n_bits"], host.words())
+    idx = np.concatenate([np.arange(0, n, 1000)[:300], rng.choice(n, size=700, replace=False)])
+    assert np.array_equal(whole[0][idx, 0], po.batch_raw_max(orc, reads, o[idx], ln[idx], 8))
+
+
 def test_sample_against_oracle(c2):
     d, eng, buf, offs, lens, base = c2
     host = d.download()
