@@ -101,7 +101,7 @@ def run(args, tag):
 
 
 # the floor under the output side: how fast bytes enter the page cache of this directory (unclassified.fasta is ONE file)
-probe = os.path.join(work, "pcw")
+probe = "/tmp/rb_pcw_probe"  # (/dev/shm is mounted noexec on the GPU boxes)
 if subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "profiles", "pagecache_write_probe.cpp"), "-o", probe]).returncode == 0:
     print(subprocess.run([probe, work, "2700000000"], capture_output=True, text=True).stdout.strip(), flush=True)
 run([], "warm-up (defaults)")

@@ -60,25 +60,42 @@ struct FilterSet {
     IbfDev f[kMaxFused];
 };
 
-// Filters of one hash geometry merged into ONE table (rb_engine.hip, MergedGroup): which word columns of a merged block belong
-// to which filter.  By-value kernel argument of ibf_count_max_merged_kernel.
+// Filters of one hash geometry merged into ONE table (rb_engine.hip, MergedGroup): which BITS of a merged block belong to which
+// filter.  Member g owns the bins [bit_begin[g], bit_end[g]) of every block -- word-aligned when every member keeps whole word
+// columns, packed bit to bit when that saves a word column (README shape: 122 + 43 + 29 + 49 bins = 243 bits = four words instead
+// of five, which takes the table to the one-lane-per-block builds of the phased kernel).  By-value kernel argument of
+// ibf_count_max_merged_kernel.
 constexpr unsigned kMaxMerged = 16;
 struct MergeMap {
     uint32_t n;                       // filters in the merged table
-    uint32_t col_end[kMaxMerged];     // filter g owns the columns [col_end[g-1], col_end[g]) of every block
-    uint32_t rem[kMaxMerged];         // noOfBins & 63 of filter g (0: its last word is full)
+    uint32_t bit_begin[kMaxMerged];   // first bin of filter g in a merged block
+    uint32_t bit_end[kMaxMerged];     // one past its last bin
     uint32_t out_offset[kMaxMerged];  // element offset of filter g's column in a row of the output
+    uint32_t width;                   // word columns of a merged block
 };
 
-// Merged tables of at most four word columns (two to four narrow filters of one hash geometry, rb_engine.hip) are served by the
-// both-strands builds of the phased kernel, which hold a whole block in one lane: which member a column belongs to, how many
-// of its 64 bits are bins (0: the column does not exist), and where each member's maximum goes in a row of the output.  A filter
-// on its own is the case n = 1.
+// bins of member [begin, end) that lie in word column c of a merged block, as a mask of that word
+__host__ __device__ inline uint64_t member_mask(uint32_t begin, uint32_t end, uint32_t c)
+{
+    const uint32_t lo = c * 64u, hi = lo + 64u;
+    const uint32_t b = begin > lo ? begin : lo, e = end < hi ? end : hi;
+    if (b >= e) return 0ULL;
+    const uint64_t upto_e = (e - lo) >= 64u ? ~0ULL : ((1ULL << (e - lo)) - 1);
+    const uint64_t upto_b = (1ULL << (b - lo)) - 1;  // b - lo < 64
+    return upto_e & ~upto_b;
+}
+
+// Merged tables of at most four word columns (two to eight narrow filters of one hash geometry, rb_engine.hip) are served by the
+// both-strands builds of the phased kernel, which hold a whole block in one lane: which bins belong to which member (bit ranges as
+// in MergeMap), how many of a column's 64 bits are bins at all (0: the column does not exist), and where each member's maximum
+// goes in a row of the output.  A filter on its own is the case n = 1.
+constexpr unsigned kMaxNarrow = 8;
 struct NarrowMerge {
-    uint32_t n;              // members (1..4)
-    uint32_t col_member[4];  // word column -> member
-    uint32_t col_bits[4];    // word column -> bins in it (64: all; 0: no such column)
-    uint32_t out_offset[4];  // member -> element offset in a row of the output
+    uint32_t n;                       // members (1..8)
+    uint32_t bit_begin[kMaxNarrow];   // member -> first bin in a block
+    uint32_t bit_end[kMaxNarrow];     // member -> one past its last bin
+    uint32_t col_bits[4];             // word column -> bins in it (64: all; 0: no such column)
+    uint32_t out_offset[kMaxNarrow];  // member -> element offset in a row of the output
 };
 
 struct CountLaunch {
@@ -125,8 +142,9 @@ struct DecideParams {
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
 hipError_t launch_ibf_count_max_merged(const CountLaunch &a, const MergeMap &map, hipStream_t st);
-hipError_t launch_merge_columns(const uint64_t *src, uint32_t s_src, uint32_t width, uint64_t *dst, uint32_t s_dst, uint32_t dst_col,
-                                uint64_t n_blocks, hipStream_t st);
+// block b of a filter (width words at stride s_src, n_bins bins) -> bits [dst_bit, dst_bit + n_bins) of block b of dst (ORed in: dst starts zeroed)
+hipError_t launch_merge_bits(const uint64_t *src, uint32_t s_src, uint32_t width, uint32_t n_bins, uint64_t *dst, uint32_t s_dst, uint32_t dst_bit,
+                             uint64_t n_blocks, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);
 int split_waves_cap(int wpl, int planes, int lg);
 int split_parts_plan(int wpl, int planes, uint32_t max_kmers, int lg, uint32_t n_items, uint32_t max_parts, uint32_t max_sub,

@@ -97,8 +97,10 @@ struct PinnedBuf {
 // (the filters are borrowed); it is rebuilt when a member's bits have changed since it was made.
 struct MergedGroup {
     std::vector<uint32_t> members;  // filter indices, engine order
+    std::vector<uint32_t> bit_begin;  // per member: its first bin in a merged block (multiples of 64 unless `packed`)
+    bool packed = false;            // members sit bit to bit: fewer word columns per block (README shape: 243 bins in four words, not five)
     uint64_t *d_words = nullptr;
-    uint64_t stride = 0, width = 0, n_blocks = 0;
+    uint64_t stride = 0, width = 0, n_blocks = 0;  // width: word columns of a merged block as it is laid out (packed or not)
     IbfDev dev{};
     MergeMap map{};
     std::vector<uint64_t> versions;  // rb_dibf::version of each member when the copy was made
@@ -1056,6 +1058,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     // columns -> members for the one-lane-per-block builds of the phased kernel: a filter on its own is one member
     a.narrow = NarrowMerge{};
     a.narrow.n = 1;
+    a.narrow.bit_begin[0] = 0;
+    a.narrow.bit_end[0] = (uint32_t)f->geo.n_bins;
     for (uint32_t c = 0; c < 4; ++c)
         a.narrow.col_bits[c] = c >= W ? 0u : (c + 1 == W && (f->geo.n_bins & 63)) ? (uint32_t)(f->geo.n_bins & 63) : 64u;
     a.split_parts = 1;
@@ -1252,6 +1256,16 @@ static void plan_merged(rb_engine *e)
             width += gj.bin_width;
         }
         if (members.size() < 2) continue;
+        // Bit-packed layout: when the members' bins, put side by side bit to bit, need fewer word columns than their whole words do AND
+        // that brings the block down to the four words one lane can hold, the merged table is a "filter" of that width for the
+        // both-strands builds of the phased kernel (README shape: 2 + 1 + 1 + 1 = 5 words -> 243 bits = 4 words: a 40 MB table in ten
+        // L2-sized slices instead of an 80 MB one at the fabric's line rate).  Per-bin counting does not care where a member's bins
+        // start; the per-member maxima are taken over bit ranges (NarrowMerge / MergeMap).
+        uint64_t bins_total = 0;
+        for (uint32_t m : members) bins_total += e->filters[m]->geo.n_bins;
+        const uint64_t packed_width = (bins_total + 63) / 64;
+        const bool packed = packed_width < width && packed_width <= 4 && members.size() <= kMaxNarrow;
+        if (packed) width = packed_width;
         double apart = 0.0;
         for (uint32_t m : members) apart += est_filter_ms(e, e->filters[m]);
         // (a merged table of two to four words is served by the phased kernel like a filter of that width)
@@ -1266,6 +1280,12 @@ static void plan_merged(rb_engine *e)
         if (!g) return;
         g->members = members;
         g->width = width;
+        g->packed = packed;
+        uint32_t at = 0;
+        for (uint32_t m : members) {
+            g->bit_begin.push_back(at);
+            at += packed ? (uint32_t)e->filters[m]->geo.n_bins : (uint32_t)e->filters[m]->geo.bin_width * 64u;
+        }
         g->n_blocks = gi.n_blocks;
         for (uint32_t m : members) e->merged_of[m] = (int)e->merged.size();
         e->merged.push_back(g);
@@ -1292,17 +1312,16 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
     }
     RB_HIP(hipMemsetAsync(g->d_words, 0, (g->n_blocks * g->stride + 8) * 8, st));
     g->versions.assign(g->members.size(), 0);
-    uint32_t col = 0;
     g->map = MergeMap{};
     g->map.n = (uint32_t)g->members.size();
+    g->map.width = (uint32_t)g->width;
     for (size_t i = 0; i < g->members.size(); ++i) {
         rb_dibf *f = e->filters[g->members[i]];
         g->versions[i] = f->version.load();
-        RB_HIP(launch_merge_columns(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, g->d_words, (uint32_t)g->stride, col,
-                                    g->n_blocks, st));
-        col += (uint32_t)f->geo.bin_width;
-        g->map.col_end[i] = col;
-        g->map.rem[i] = (uint32_t)(f->geo.n_bins & 63);
+        RB_HIP(launch_merge_bits(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, (uint32_t)f->geo.n_bins, g->d_words,
+                                 (uint32_t)g->stride, g->bit_begin[i], g->n_blocks, st));
+        g->map.bit_begin[i] = g->bit_begin[i];
+        g->map.bit_end[i] = g->bit_begin[i] + (uint32_t)f->geo.n_bins;
         g->map.out_offset[i] = g->members[i];
     }
     rb_ibf_info geo = e->filters[g->members[0]]->geo;  // noOfBlocks, k, h of the members
@@ -1411,18 +1430,22 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
                 CountLaunch p = a;
                 const bool planned = plan_geometry(e, &as_filter, n_reads, max_len, p);
                 const bool one_lane = (p.lg == 1 && p.short_only >= 1 && p.short_only <= 3) || (p.lg == 2 && (p.short_only == 4 || p.short_only == 5));
-                if (planned && p.phase.n_slices && p.split_waves < 2 && p.planes <= 10 && one_lane) {
+                if (planned && p.phase.n_slices && p.split_waves < 2 && p.planes <= 10 && one_lane && g->map.n <= kMaxNarrow) {
                     p.f = g->dev;
                     p.f.comp_n = e->revcomp_of_n;
                     p.narrow = NarrowMerge{};
                     p.narrow.n = g->map.n;
-                    for (uint32_t c = 0; c < 4; ++c) {
-                        uint32_t m = 0;
-                        while (m < g->map.n && c >= g->map.col_end[m]) ++m;
-                        p.narrow.col_member[c] = m < g->map.n ? m : 0xFFFFFFFFu;
-                        p.narrow.col_bits[c] = m >= g->map.n ? 0u : (c + 1 == g->map.col_end[m] && g->map.rem[m]) ? g->map.rem[m] : 64u;
+                    for (uint32_t c = 0; c < 4; ++c) {  // bins of a column are its low bits in both layouts: up to the end of the last member in it
+                        uint32_t top = 0;
+                        for (uint32_t m = 0; m < g->map.n; ++m)
+                            if (g->map.bit_begin[m] < (c + 1) * 64u && g->map.bit_end[m] > c * 64u) top = std::max(top, std::min(g->map.bit_end[m], (c + 1) * 64u) - c * 64u);
+                        p.narrow.col_bits[c] = c < g->width ? top : 0u;
                     }
-                    for (uint32_t m = 0; m < g->map.n; ++m) p.narrow.out_offset[m] = g->map.out_offset[m];
+                    for (uint32_t m = 0; m < g->map.n; ++m) {
+                        p.narrow.bit_begin[m] = g->map.bit_begin[m];
+                        p.narrow.bit_end[m] = g->map.bit_end[m];
+                        p.narrow.out_offset[m] = g->map.out_offset[m];
+                    }
                     p.out = maxcount;
                     p.out_read_stride = (uint32_t)nf;
                     p.out_slice_stride = 0;

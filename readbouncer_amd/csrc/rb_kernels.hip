@@ -756,20 +756,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_merged_kern
     const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
     if (read >= n_reads) return;  // wave-uniform; no block-level barriers below
     LaneCols<1> lc = make_lane_cols<LG, 1>(f, lane, 0u, f.bin_width, 0u);
-    // which filter this lane's word column belongs to, and which of its bins exist
+    // which bins of this lane's word column exist at all: the union of the members' bit ranges (word-aligned or packed)
     const uint32_t col = (uint32_t)lane & ((1u << LG) - 1u);
-    uint32_t fid = 0xFFFFFFFFu, begin = 0;
     uint64_t valid = 0;
-    for (uint32_t g = 0; g < map.n; ++g) {
-        const uint32_t end = map.col_end[g];
-        if (col >= begin && col < end) {
-            fid = g;
-            valid = (col == end - 1 && map.rem[g]) ? ((1ULL << map.rem[g]) - 1) : ~0ULL;
-        }
-        begin = end;
-    }
+    for (uint32_t g = 0; g < map.n; ++g) valid |= member_mask(map.bit_begin[g], map.bit_end[g], col);
+    if (col >= map.width) valid = 0;
     lc.valid[0] = valid;
-    lc.colok = fid != 0xFFFFFFFFu;
+    lc.colok = valid != 0;
     lc.safe_base = lc.colok ? lc.lane_base : f.words;
     uint32_t len;
     const BaseSrc seq = make_base_src(src, read, &len);
@@ -781,7 +774,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_merged_kern
         count_strand<LG, 1, NP, 3, NT>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0, TileShape<LG>::STEPS / 8,
                                        s_stage[wave], lane);
         for (uint32_t g = 0; g < map.n; ++g) {
-            const uint64_t mine[1] = {fid == g ? valid : 0ULL};
+            const uint64_t mine[1] = {col < map.width ? member_mask(map.bit_begin[g], map.bit_end[g], col) : 0ULL};
             const uint32_t m = planes_max<NP, 1>(pl, mine);
             if ((uint32_t)lane == g) best = m > best ? m : best;
         }
@@ -789,16 +782,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void ibf_count_max_merged_kern
     if ((uint32_t)lane < map.n) out[(size_t)read * out_read_stride + map.out_offset[lane]] = (uint16_t)best;
 }
 
-// merged table: block b of a filter (width words at stride s_src) -> columns [dst_col, dst_col + width) of block b of dst
-__global__ void merge_columns_kernel(const uint64_t *__restrict__ src, uint32_t s_src, uint32_t width, uint64_t *__restrict__ dst,
-                                     uint32_t s_dst, uint32_t dst_col, uint64_t n_blocks)
+// merged table: block b of a filter (width words at stride s_src, n_bins bins) -> bits [dst_bit, dst_bit + n_bins) of block b of dst.
+// One thread per (block, source word): the word is masked to the bins that exist and ORed into the one or two destination words it
+// lands in (atomically: members that share a destination word are merged by separate launches on one stream, but two source words
+// of ONE member can meet in a destination word when dst_bit is not a multiple of 64).
+__global__ void merge_bits_kernel(const uint64_t *__restrict__ src, uint32_t s_src, uint32_t width, uint32_t n_bins, uint64_t *__restrict__ dst,
+                                  uint32_t s_dst, uint32_t dst_bit, uint64_t n_blocks)
 {
     const uint64_t total = n_blocks * width;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const uint64_t b = i / width;
         const uint32_t c = (uint32_t)(i - b * width);
-        dst[b * s_dst + dst_col + c] = src[b * s_src + c];
+        uint64_t v = src[b * s_src + c] & member_mask(0u, n_bins, c);
+        if (v == 0) continue;
+        const uint32_t at = dst_bit + c * 64u;
+        const uint32_t w = at >> 6, sh = at & 63u;
+        atomicOr(reinterpret_cast<unsigned long long *>(dst + b * s_dst + w), (unsigned long long)(v << sh));
+        if (sh && (v >> (64u - sh))) atomicOr(reinterpret_cast<unsigned long long *>(dst + b * s_dst + w + 1), (unsigned long long)(v >> (64u - sh)));
     }
 }
 
@@ -817,14 +818,18 @@ __global__ void merge_columns_kernel(const uint64_t *__restrict__ src, uint32_t 
 __device__ __forceinline__ uint64_t col_bits_mask(uint32_t bits) { return bits >= 64 ? ~0ULL : ((1ULL << bits) - 1); }
 
 // The end of the one-lane-per-block rounds: lane b holds, per word column c, the larger of the two strands' counts of bin 64 c + b;
-// every member of the (possibly merged) table gets the maximum over its columns and the wave.
+// every member of the (possibly merged) table gets the maximum over ITS bins -- the bit range [bit_begin, bit_end) of the block,
+// word-aligned or packed -- and the wave.
 template <int NC>
 __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC], const NarrowMerge &nm, int lane, uint16_t *out)
 {
     for (uint32_t g = 0; g < nm.n; ++g) {
         uint32_t m = 0;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) m = (nm.col_member[c] == g && colmax[c] > m) ? colmax[c] : m;
+        for (int c = 0; c < NC; ++c) {
+            const uint32_t bin = (uint32_t)(c * 64 + lane);
+            m = (bin >= nm.bit_begin[g] && bin < nm.bit_end[g] && colmax[c] > m) ? colmax[c] : m;
+        }
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
             const uint32_t o = shfl32(m, lane ^ sft);
@@ -1832,17 +1837,17 @@ static hipError_t launch_merged_lg(const CountLaunch &a, const MergeMap &map, hi
 hipError_t launch_ibf_count_max_merged(const CountLaunch &a, const MergeMap &map, hipStream_t st)
 {
     if (a.n_reads == 0) return hipSuccess;
-    if (a.f.n_hash != 3 || a.wpl != 1 || map.n == 0 || map.n > kMaxMerged || map.col_end[map.n - 1] > (1u << a.lg)) return hipErrorInvalidValue;
+    if (a.f.n_hash != 3 || a.wpl != 1 || map.n == 0 || map.n > kMaxMerged || map.width == 0 || map.width > (1u << a.lg)) return hipErrorInvalidValue;
     return a.planes <= 10 ? launch_merged_lg<10>(a, map, st) : launch_merged_lg<16>(a, map, st);
 }
 
-hipError_t launch_merge_columns(const uint64_t *src, uint32_t s_src, uint32_t width, uint64_t *dst, uint32_t s_dst, uint32_t dst_col,
-                                uint64_t n_blocks, hipStream_t st)
+hipError_t launch_merge_bits(const uint64_t *src, uint32_t s_src, uint32_t width, uint32_t n_bins, uint64_t *dst, uint32_t s_dst, uint32_t dst_bit,
+                             uint64_t n_blocks, hipStream_t st)
 {
     if (n_blocks == 0 || width == 0) return hipSuccess;
     uint64_t blocks = (n_blocks * width + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(merge_columns_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, width, dst, s_dst, dst_col, n_blocks);
+    hipLaunchKernelGGL(merge_bits_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, width, n_bins, dst, s_dst, dst_bit, n_blocks);
     return hipGetLastError();
 }
 

@@ -1163,8 +1163,8 @@ def test_a_merged_copy_beyond_the_cap_is_not_made(monkeypatch):
     reads = make_reads(rng, ref, 2300, lo=20, hi=400, err=0.08, n_frac=0.1)
     buf, offs, lens = H.pack_reads(reads)
     exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
-    copy_bytes = (n_blocks * 8 + 8) * 8  # five words, padded to eight
-    small_copy = (n_blocks * 4 + 8) * 8  # the three one-word targets alone: three words, padded to four
+    copy_bytes = (n_blocks * 4 + 8) * 8  # 100 + 30 + 30 + 30 bins side by side, bit to bit: three words, padded to four (whole words: five -> eight)
+    small_copy = (n_blocks * 2 + 8) * 8  # the three 30-bin targets alone: 90 bins in two words
     for cap, expect in ((copy_bytes, (1, 4, copy_bytes)), (copy_bytes - 1, (1, 3, small_copy)), (1000, (0, 0, 0))):
         monkeypatch.setenv("RB_MERGE_MAX_BYTES", str(cap))
         eng = capi.Engine(0, filters[:1], filters[1:])
