@@ -428,7 +428,6 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         uint64_t next_seq = 0, write_seq = 0;
         std::string worker_error;
         auto classifier = [&] {
-            std::vector<std::vector<char>> chunks(n_out);  // this thread's write buffers, one per output file, kept for all its segments
             try {
                 for (;;) {
                     std::unique_ptr<seqio::Segment> seg;
@@ -471,11 +470,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                     // ... and the text itself, by every classifier thread at once
                     const auto tf = std::chrono::steady_clock::now();
                     std::vector<seqio::OrderedOutput::Writer> out(n_out);
-                    seqio::OrderedOutput nowhere;  // a file that could not be opened (target FASTAs are not checked by the reference): formatted into the void
-                    for (size_t f = 0; f < n_out; ++f) {
-                        if (outputs[f]->is_open()) out[f] = outputs[f]->writer(at[f], so.bytes[f], chunks[f]);
-                        else out[f] = nowhere.writer(0, so.bytes[f], chunks[f]);
-                    }
+                    // (a file that could not be opened -- target FASTAs are not checked by the reference -- is formatted into the void)
+                    for (size_t f = 0; f < n_out; ++f) out[f] = outputs[f]->writer(at[f], so.bytes[f]);
                     format_segment(*seg, state, out);
                     for (size_t f = 0; f < n_out; ++f) {
                         const bool complete = outputs[f]->is_open() ? out[f].finish() : true;

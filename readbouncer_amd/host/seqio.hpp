@@ -457,15 +457,28 @@ public:
 // out consecutive ranges (the callers take turns in file order -- a few arithmetic instructions under a lock), writer()
 // gives a cursor over one range that the caller fills record by record (take(n) = the next n bytes).  Two ways to the page
 // cache behind that cursor:
-//   positional writes (default): the text is formatted into a small buffer the calling thread keeps for good (cache resident,
-//     no fresh pages) and goes out with pwrite() whenever the buffer is full -- several threads write their ranges of one
-//     file and different files at the same time; a single writer thread doing write() of whole segments topped out at
-//     ~3 GB/s, i.e. ~11 M reads/s of the narrow-filter workloads the CLI serves;
+//   positional writes (default): the text is formatted into 2 MiB buffers from a small pool that belongs to the file; a full
+//     buffer is handed to the file's OWN writer thread, which issues the pwrite() and returns the buffer to the pool.  Buffered
+//     writes to one inode are serialised by its lock whoever makes them (measured on the GPU box's tmpfs: 8.4 GB/s from one
+//     thread, 5.4-7.8 GB/s from two to six; 27-40 GB/s into a file per thread), so one thread per file is all a file can use --
+//     and the formatting threads never queue on that lock (six of them calling pwrite() themselves swung between 14 and
+//     23 M reads/s from run to run);
 //   a shared mapping of the file (`use_mmap`): the text is written once, straight into the page cache; the file is mapped
-//     into one reserved stretch of address space as it grows, pages come by faults.
-// close() cuts the file to the bytes reserved.  Errors are sticky and reported by ok().
+//     into one reserved stretch of address space as it grows, pages come by faults (slower on tmpfs: every fresh page is a fault).
+// close() waits for the writer thread and cuts the file to the bytes reserved.  Errors are sticky and reported by ok().
 class OrderedOutput
 {
+public:
+    static constexpr size_t kChunk = (size_t)2 << 20;  // positional writes: bytes formatted between two hand-overs
+    static constexpr size_t kPoolBuffers = 12;         // per file: formatting threads stall when all of them wait to be written
+
+private:
+    struct Job
+    {
+        std::vector<char>* buf;
+        size_t n;
+        uint64_t off;
+    };
     int fd_ = -1;
     bool use_mmap_ = false;
     std::mutex mu_;
@@ -474,15 +487,70 @@ class OrderedOutput
     uint64_t va_len_ = 0, mapped_len_ = 0;
     std::atomic<bool> failed_{false};
     std::string error_;
+    // positional mode: the file's writer thread, its queue and the buffer pool
+    std::thread writer_;
+    std::mutex qmu_;
+    std::condition_variable qcv_, pool_cv_;
+    std::deque<Job> queue_;
+    std::vector<std::unique_ptr<std::vector<char>>> buffers_;
+    std::vector<std::vector<char>*> free_;
+    bool stop_ = false;
+
     void fail(const std::string& what)
     {
         std::lock_guard<std::mutex> lock(mu_);
         if (!failed_.exchange(true)) error_ = what;
     }
+    void writer_loop()
+    {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lock(qmu_);
+                qcv_.wait(lock, [&] { return !queue_.empty() || stop_; });
+                if (queue_.empty()) return;
+                j = queue_.front();
+                queue_.pop_front();
+            }
+            if (fd_ >= 0) pwrite_all(j.buf->data(), j.n, j.off);
+            {
+                std::lock_guard<std::mutex> lock(qmu_);
+                free_.push_back(j.buf);
+            }
+            pool_cv_.notify_one();
+        }
+    }
+    std::vector<char>* acquire()
+    {
+        std::unique_lock<std::mutex> lock(qmu_);
+        if (free_.empty() && buffers_.size() < kPoolBuffers) {
+            buffers_.emplace_back(new std::vector<char>(kChunk));
+            return buffers_.back().get();
+        }
+        pool_cv_.wait(lock, [&] { return !free_.empty(); });
+        std::vector<char>* b = free_.back();
+        free_.pop_back();
+        return b;
+    }
+    void release(std::vector<char>* b)
+    {
+        {
+            std::lock_guard<std::mutex> lock(qmu_);
+            free_.push_back(b);
+        }
+        pool_cv_.notify_one();
+    }
+    void submit(std::vector<char>* b, size_t n, uint64_t off)
+    {
+        {
+            std::lock_guard<std::mutex> lock(qmu_);
+            if (!writer_.joinable()) writer_ = std::thread([this] { writer_loop(); });
+            queue_.push_back(Job{b, n, off});
+        }
+        qcv_.notify_one();
+    }
 
 public:
-    static constexpr size_t kChunk = (size_t)2 << 20;  // positional writes: bytes formatted between two pwrite() calls
-
     // cursor over one reserved range
     class Writer
     {
@@ -491,15 +559,35 @@ public:
         uint64_t off_ = 0;       // file offset of the next byte to go out
         uint64_t left_ = 0;      // bytes of the range not handed out yet
         char* map_cur_ = nullptr;
-        std::vector<char>* buf_ = nullptr;  // positional mode: the calling thread's chunk buffer
+        std::vector<char>* buf_ = nullptr;  // positional mode: the buffer being filled (from the file's pool)
         size_t fill_ = 0;
-        void flush()
+        void flush(bool more)
         {
-            if (fill_ && owner_->fd_ >= 0) owner_->pwrite_all(buf_->data(), fill_, off_);
-            off_ += fill_;
-            fill_ = 0;
+            if (fill_) {
+                owner_->submit(buf_, fill_, off_);
+                off_ += fill_;
+                fill_ = 0;
+                buf_ = more ? owner_->acquire() : nullptr;
+            } else if (!more && buf_) {
+                owner_->release(buf_);
+                buf_ = nullptr;
+            }
         }
     public:
+        Writer() = default;
+        Writer(const Writer&) = delete;
+        Writer& operator=(const Writer&) = delete;
+        Writer(Writer&& o) noexcept { *this = std::move(o); }
+        Writer& operator=(Writer&& o) noexcept
+        {
+            owner_ = o.owner_; off_ = o.off_; left_ = o.left_; map_cur_ = o.map_cur_; buf_ = o.buf_; fill_ = o.fill_;
+            o.owner_ = nullptr; o.buf_ = nullptr; o.map_cur_ = nullptr; o.fill_ = 0; o.left_ = 0;
+            return *this;
+        }
+        ~Writer()
+        {
+            if (owner_ && !map_cur_) flush(false);  // (an abandoned range: what was filled still goes out, the buffer goes home)
+        }
         // the next n bytes of the range, contiguous, to be filled before the next take()
         char* take(size_t n)
         {
@@ -510,18 +598,19 @@ public:
                 map_cur_ += n;
                 return p;
             }
+            if (!buf_) buf_ = owner_->acquire();
             if (fill_ + n > buf_->size()) {
-                flush();
+                flush(true);
                 if (n > buf_->size()) buf_->resize(n);
             }
             char* p = buf_->data() + fill_;
             fill_ += n;
             return p;
         }
-        // everything handed out has been filled: positional mode writes the rest; false if the range was not used up
+        // everything handed out has been filled: positional mode hands the rest over; false if the range was not used up
         bool finish()
         {
-            if (owner_ && !map_cur_) flush();
+            if (owner_ && !map_cur_) flush(false);
             return left_ == 0;
         }
     };
@@ -579,8 +668,8 @@ public:
         return off;
     }
 
-    // cursor over [off, off + bytes); `chunk` = the calling thread's buffer for the positional mode (kept across calls)
-    Writer writer(uint64_t off, uint64_t bytes, std::vector<char>& chunk)
+    // cursor over [off, off + bytes)
+    Writer writer(uint64_t off, uint64_t bytes)
     {
         Writer w;
         w.owner_ = this;
@@ -591,12 +680,7 @@ public:
             std::lock_guard<std::mutex> lock(mu_);
             mapped = use_mmap_ && off + bytes <= mapped_len_;
         }
-        if (mapped) {
-            w.map_cur_ = va_ + off;
-        } else {
-            if (chunk.size() < kChunk) chunk.resize(kChunk);
-            w.buf_ = &chunk;
-        }
+        if (mapped) w.map_cur_ = va_ + off;
         return w;
     }
 
@@ -611,6 +695,12 @@ public:
 
     void close()
     {
+        {
+            std::lock_guard<std::mutex> lock(qmu_);
+            stop_ = true;
+        }
+        qcv_.notify_all();
+        if (writer_.joinable()) writer_.join();  // everything queued is written first
         if (va_) munmap(va_, va_len_);
         va_ = nullptr;
         if (fd_ < 0) return;

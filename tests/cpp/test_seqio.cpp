@@ -90,9 +90,8 @@ int main()
             std::atomic<int> short_ranges{0};
             for (int t = 0; t < 4; ++t)
                 th.emplace_back([&, t] {
-                    std::vector<char> chunk;  // this thread's write buffer (positional mode), kept across its ranges
                     for (size_t i = (size_t)t; i < pieces.size(); i += 4) {
-                        seqio::OrderedOutput::Writer w = out.writer(at[i], pieces[i].size(), chunk);
+                        seqio::OrderedOutput::Writer w = out.writer(at[i], pieces[i].size());
                         // records of uneven sizes, some larger than nothing, one larger than the chunk buffer would be with a small kChunk
                         size_t pos = 0, step = 1;
                         while (pos < pieces[i].size()) {
@@ -107,8 +106,7 @@ int main()
             for (auto& x : th) x.join();
             CHECK(out.bytes() == expect.size() && short_ranges == 0);
             {   // a range that is not used up is reported, one that is overrun throws
-                std::vector<char> chunk;
-                seqio::OrderedOutput::Writer w = out.writer(out.reserve(0), 0, chunk);
+                seqio::OrderedOutput::Writer w = out.writer(out.reserve(0), 0);
                 bool threw = false;
                 try { w.take(1); } catch (const std::exception&) { threw = true; }
                 CHECK(threw && w.finish());
