@@ -23,8 +23,8 @@ from readbouncer_amd import capi, synth  # noqa: E402
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 L = 250
 need = n_reads * (2 * L + 17) * 1.7  # FASTQ + outputs
-work = sys.argv[2] if len(sys.argv) > 2 else "/dev/shm/rb_cli250"
-if len(sys.argv) <= 2:
+work = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else "/dev/shm/rb_cli250"
+if len(sys.argv) <= 2 or sys.argv[2] == "-":
     st = os.statvfs("/dev/shm")
     if st.f_bavail * st.f_frsize < need:  # a container with a small /dev/shm: the file system of /tmp (page cache after the first pass)
         work = "/tmp/rb_cli250"
@@ -104,6 +104,13 @@ def run(args, tag):
 probe = "/tmp/rb_pcw_probe"  # (/dev/shm is mounted noexec on the GPU boxes)
 if subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "profiles", "pagecache_write_probe.cpp"), "-o", probe]).returncode == 0:
     print(subprocess.run([probe, work, "2700000000"], capture_output=True, text=True).stdout.strip(), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "quick":  # a long file, the defaults only: how the fixed costs of a run amortise
+    for i in range(4):
+        run([], "defaults (6 parsers, 6 classifiers, 32 MB segments)")
+    run(["--classify-threads", "4"], "4 classifiers")
+    run(["--ingest-threads", "1", "--classify-threads", "1", "--batch-reads", "1000000"], "serial: 1 parser 1 classifier")
+    subprocess.run(["rm", "-rf", work])
+    sys.exit(0)
 run([], "warm-up (defaults)")
 run([], "defaults (6 parsers, 6 classifiers, 32 MB segments)")
 run([], "defaults")
