@@ -477,6 +477,8 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                         const bool complete = outputs[f]->is_open() ? out[f].finish() : true;
                         if (!complete) throw std::runtime_error("output layout mismatch");
                     }
+                    out.clear();            // (the cursors first: their buffers are on their way to the files' writer threads)
+                    seg->release_mapping();  // the records of this segment are not looked at again
                     seg.reset();
                     {
                         std::lock_guard<std::mutex> lock(omu);

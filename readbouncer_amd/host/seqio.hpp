@@ -247,6 +247,8 @@ public:
 
 struct Segment
 {
+    const char* map_begin = nullptr;   // the stretch of the mapped file this segment was parsed from
+    const char* map_end = nullptr;
     Batch batch;                       // every record of the segment (views into the mapping / the arena)
     char* prefix = nullptr;            // prefix_len bases of each record with seq_len >= prefix_len, back to back
     size_t prefix_cap = 0;
@@ -258,6 +260,18 @@ struct Segment
     ~Segment()
     {
         if (prefix && pool) pool->put(prefix, prefix_cap);
+    }
+    // The consumer is done with the records (their views die with this call): the whole pages of this segment's stretch are dropped
+    // from the address space (the data stays in the page cache).  A 30 GB read file otherwise ends the run with 8 M page-table
+    // entries to tear down at once -- and a resident set the size of the file.
+    void release_mapping()
+    {
+        if (!map_begin) return;
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t lo = ((uintptr_t)map_begin + page - 1) / page * page, hi = (uintptr_t)map_end / page * page;
+        if (hi > lo) madvise((void*)lo, hi - lo, MADV_DONTNEED);
+        batch.records.clear();
+        map_begin = map_end = nullptr;
     }
 };
 
@@ -338,6 +352,8 @@ class ParallelReader
                 if (stop_) return;
             }
             std::unique_ptr<Segment> seg(new Segment());
+            seg->map_begin = data_ + starts_[s];
+            seg->map_end = data_ + starts_[s + 1];
             // nothing may escape a worker thread (std::terminate, with the consumers blocked in next()): a failure becomes
             // a segment whose batch.error is set -- the consumer's ordinary error path, and the last segment it sees
             try {
