@@ -950,6 +950,53 @@ def test_bin_sharded_rank_with_odd_stride_keeps_the_plain_kernel():
         eng.set_column_shard(0, 1)
 
 
+def test_pool_from_resident_filters_and_its_statistics():
+    """rb_pool_create_from_device: replicas of filters that are already in HBM, copied device to device onto every listed device
+    (the one GPU of the box, three times); outputs equal a single engine's; rb_pool_get_stats accounts for every read"""
+    rng = np.random.default_rng(5150)
+    ref = H.random_dna(rng, 30000)
+    filters = []
+    for n_bins, lo in ((300, 0), (64, 15000)):
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * 50021)
+        d.add_sequence(ref[lo:lo + 15000], 700)
+        filters.append(d)
+    reads = make_reads(rng, ref, 9000, lo=30, hi=420)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, filters[:1], filters[1:])
+    exp = eng.classify(buf, offs, lens)
+    pool = capi.Pool.from_device([0, 0, 0], filters[:1], filters[1:])
+    assert pool.size() == 3 and pool.replication_seconds >= 0.0
+    pool.set_min_split(1000)
+    got = pool.classify(buf, offs, lens)
+    for a, b in zip(got, exp):
+        assert np.array_equal(a, b)
+    st = pool.stats()
+    assert len(st) == 3 and sum(r for _, _, r, _ in st) == len(lens) and all(c >= 1 and b > 0 for _, b, _, c in st)
+    assert pool.stats(reset=True) == st and all(r == 0 for _, _, r, _ in pool.stats())
+    pool.destroy()
+    # the source filters are untouched and still the caller's
+    assert np.array_equal(eng.classify(buf, offs, lens)[0], exp[0])
+
+
+def test_measurement_aids_answer():
+    """rb_dibf_probe_read_peak, rb_engine_plan and rb_dibf_touch do what their headers say (no timing asserted)"""
+    d = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * 20011)
+    gbps, ms = d.probe_read_peak(1024, False, 12, target_ms=5.0)
+    assert gbps > 0 and ms > 0
+    with pytest.raises(capi.RBError):
+        d.probe_read_peak(100, False)  # rows of 128, 1024 or 4096 bytes
+    eng = capi.Engine(0, [d], [])
+    pl = eng.plan(0, 100000, 360)
+    assert pl["kernel"] == "ibf_count_max_kernel" and pl["lanes_per_block_log2"] == 6 and pl["words_per_lane"] == 2 and not pl["phased"]
+    assert eng.plan(0, 64, 360)["kernel"] == "ibf_count_max_split_kernel"
+    small = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 1310000)  # 10 MiB of one-word blocks
+    e2 = capi.Engine(0, [small], [])
+    pl = e2.plan(0, 100000, 250)
+    assert pl["kernel"] == "ibf_count_max_phased_kernel" and pl["phased"] == 1 and pl["phase_shape_name"].startswith("four tiles")
+    assert pl["phase_slices"] * (1 << pl["phase_slice_log2"]) >= pl["table_bytes"] and 100 <= pl["phase_window_ticks"] <= 2000
+    assert capi.lib().rb_dibf_touch(small.h) == 0 and capi.lib().rb_dibf_touch(None) != 0
+
+
 def _pool_threads_run(timed):
     """The reference's N classification threads behind one queue (adaptive_sampling.hpp:745-751): K host threads calling
     rb_pool_classify_batch keep K engines busy.  4 threads x 500 micro-batches on a pool of four engines (one GPU, listed
@@ -1038,7 +1085,10 @@ def test_pool_concurrency_speedup():
 
 
 @pytest.mark.parametrize("widths", [(122, 43, 29, 49), (64, 64, 64, 64, 10), (130, 200), (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64),
-                                    (60, 50), (60, 50, 40), (100, 60, 30), (64, 64, 64, 64), (129, 3)])
+                                    (60, 50), (60, 50, 40), (100, 60, 30), (64, 64, 64, 64), (129, 3),
+                                    # bit-packed layouts: eight members in four words, members that straddle word boundaries, exactly 256 bins,
+                                    # three small targets in two words (the engine packs when that brings a group down to <= 4 words)
+                                    (30, 30, 30, 30, 30, 30, 30, 30), (10, 200), (64, 1, 63, 128), (250, 6), (43, 29, 49), (70, 50)])
 def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
     """Filters built with one fragment_size have the same noOfBlocks whatever their bin count (IBFBuild.cpp:404-413), so a k-mer
     hashes to the same block in all of them: the engine merges their blocks into one table and serves every member with ONE
@@ -1080,7 +1130,19 @@ def test_filters_of_one_hash_geometry_share_a_merged_table(widths):
     # these (L2-resident on their own and merged) always pay, so mode 1 merges what mode 2 does
     expect = {(122, 43, 29, 49): (1, 4), (64, 64, 64, 64, 10): (1, 5), (130, 200): (1, 2),
               (40, 50, 60, 70, 80, 90, 100, 110, 120, 128, 5, 64): (2, 12),
-              (60, 50): (1, 2), (60, 50, 40): (1, 3), (100, 60, 30): (1, 3), (64, 64, 64, 64): (1, 4), (129, 3): (1, 2)}[widths]
+              (60, 50): (1, 2), (60, 50, 40): (1, 3), (100, 60, 30): (1, 3), (64, 64, 64, 64): (1, 4), (129, 3): (1, 2),
+              (30, 30, 30, 30, 30, 30, 30, 30): (1, 8), (10, 200): (1, 2), (64, 1, 63, 128): (1, 4), (250, 6): (1, 2), (43, 29, 49): (1, 3),
+              (70, 50): (1, 2)}[widths]
+    # the layout the engine chose, as it reports it: bins side by side bit to bit when whole words would need more columns and
+    # the packed block fits the four words of the one-lane builds
+    packed_words = (sum(widths) + 63) // 64
+    whole_words = sum((b + 63) // 64 for b in widths)
+    if len(widths) <= 8 and packed_words <= 4 and packed_words < whole_words:
+        stride = {1: 1, 2: 2, 3: 4, 4: 4}[packed_words]
+        eng.set_merge(2)
+        assert eng.merge_info()[2] == (n_blocks * stride + 8) * 8, (eng.merge_info(), packed_words)
+        pl = eng.plan(0, len(lens), 400)
+        assert pl["merged_members"] == len(widths) and pl["block_words"] == packed_words and pl["table_bytes"] == n_blocks * stride * 8
     for mode in (0, 1, 2):
         eng.set_merge(mode)
         assert eng.merge_info()[:2] == ((0, 0) if mode == 0 else expect), (mode, eng.merge_info())
