@@ -562,8 +562,7 @@ def run_pool(ctx, name, steps=3):
     was busy."""
     from readbouncer_amd import capi, synth
     torch, world, rank = ctx.torch, ctx.world, ctx.rank
-    result = None
-    if rank == 0:
+    def measure():
         env = os.environ.get("RB_BENCH_POOL_DEVICES")  # test hook: "0,0" = two workers on the one GPU of the box
         devices = [int(x) for x in env.split(",")] if env else (list(range(world)) if (world > 1 and not ctx.same_gpu) else [ctx.dev_index])
         dep_keys, tgt_keys, wname, _, L = workload_spec(ctx, name)
@@ -576,6 +575,7 @@ def run_pool(ctx, name, steps=3):
         t0 = time.time()
         pool = capi.Pool.from_device(devices, deplete, target)
         create_s = time.time() - t0
+        torch.cuda.set_device(ctx.dev_index)  # (creating replicas on other devices moved this thread's current device)
         t_seq, _, _ = synth.make_reads_device(2000, n, L, ref, ctx.dev)
         blocks = {"seq": capi.HostBlock(n * L, np.uint8), "off": capi.HostBlock(n, np.uint64), "len": capi.HostBlock(n, np.uint32),
                   "max": capi.HostBlock(n * nf, np.uint16), "best": capi.HostBlock(n, np.int32), "dec": capi.HostBlock(n, np.uint8),
@@ -622,7 +622,23 @@ def run_pool(ctx, name, steps=3):
         pool.destroy()
         for b in blocks.values():
             b.free()
+        torch.cuda.set_device(ctx.dev_index)  # (creating replicas on other devices moved this thread's current device)
         torch.cuda.empty_cache()
+        return result
+
+    result = None
+    if rank == 0:
+        # never raises: on a multi-GPU node the other ranks are waiting for this rank on the rendezvous store, and the first run on
+        # such a node is the first time the peer copies and the pool on distinct devices execute at all
+        try:
+            result = measure()
+        except Exception as ex:  # noqa: BLE001
+            result = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300]), "value": 0.0, "n_gpus": world,
+                      "config": {"workload": "one-process pool leg (%s)" % name}, "parity": None, "roofline": None, "cpu_baseline": None}
+        try:
+            torch.cuda.set_device(ctx.dev_index)
+        except Exception:  # noqa: BLE001
+            pass
     ctx._pool_legs = getattr(ctx, "_pool_legs", 0) + 1
     ctx.wait_for_rank0("pool_%s_%d" % (name, ctx._pool_legs))
     return result
