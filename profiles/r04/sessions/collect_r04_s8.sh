@@ -10,4 +10,4 @@ T="timeout 1800"
 tail -n 5 $OUT/pytest_gpu.txt | cut -c1-300
 ( time $T python3 profiles/cli_readme250.py ) > $OUT/cli_throughput.txt 2>&1
 cut -c1-420 $OUT/cli_throughput.txt
-bash profiles/collect_r04_s7.sh $TAG
+bash profiles/r04/sessions/collect_r04_s7.sh $TAG

@@ -26,3 +26,18 @@ def test_every_shape_has_a_named_row():
     assert "shape == 1" not in hdr and "shape == 5" not in hdr  # no integer-coded shapes left
     eng = open(os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_engine.hip")).read()
     assert "shape == 5" not in eng and "shape == 6" not in eng
+
+
+import sys
+
+import pytest
+
+
+@pytest.mark.gpu
+@pytest.mark.gpuperf
+def test_phase_rules_hold_between_the_fitted_points():
+    """the planner guard as a test (timing: -m gpuperf only): profiles/phase_rule_check.py at its default 16 points exits 0, i.e. the
+    rule is within 8 % of the best of a fresh sweep (and never slower than the plain kernel) on THIS box"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "phase_rule_check.py")], capture_output=True, text=True, timeout=1500)
+    print(p.stdout[-3000:])
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
