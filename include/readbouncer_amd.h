@@ -433,9 +433,19 @@ typedef struct rb_plan_info {
     uint32_t phased;             /* 1: clock-phased gathers */
     uint32_t phase_shape;        /* rbplan::PhaseShape */
     char phase_shape_name[64];
-    uint32_t phase_slice_log2, phase_slices, phase_window_ticks;  /* window length in 10 ns ticks */
+    uint32_t phase_slice_log2, phase_slices, phase_window_ticks;  /* window length in effect, in 10 ns ticks */
+    uint32_t phase_rule_ticks;   /* what the planner's table alone gives (differs after rb_engine_calibrate) */
 } rb_plan_info;
 RB_API int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads, uint32_t max_len, rb_plan_info *out);
+/* Fits the window lengths of the clock-phased gathers to THIS device: the planner's table was measured on one box, and clocks,
+ * firmware and compilers move the optima.  For every table the engine would serve with the phased form on batches of n_reads reads
+ * of read_len bases, K1 is timed on synthetic reads with the table's window and with 0.7 / 0.85 / 1.2 / 1.45 x that (same slice
+ * size); the fastest replaces the rule for that table and kernel shape when it wins by more than 2 %, until the engine goes away
+ * or rb_engine_set_phased / rb_engine_set_phase_slices is called.  Stops trying new windows after max_ms (0 = no limit); a few
+ * launches per table, tens of milliseconds in all.  Results never depend on it; call it on an idle engine.  n_tables: phased
+ * tables found; n_changed: how many got a new window.  No reference counterpart (profiles/phase_rule_check.py is the
+ * offline form of the same sweep, with an exit code). */
+RB_API int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_len, double max_ms, uint32_t *n_tables, uint32_t *n_changed);
 
 /* How the phased form cuts a table, for tests and experiments: slices of 2^slice_log2 bytes (0 = the built-in rule, 0.5 to 4 MiB
  * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and

@@ -29,7 +29,8 @@ class PlanInfo(C.Structure):
                 ("merged_members", C.c_uint32), ("lanes_per_block_log2", C.c_uint32), ("words_per_lane", C.c_uint32),
                 ("column_slices", C.c_uint32), ("counter_planes", C.c_uint32), ("nontemporal", C.c_uint32), ("split_waves", C.c_uint32),
                 ("phased", C.c_uint32), ("phase_shape", C.c_uint32), ("phase_shape_name", C.c_char * 64),
-                ("phase_slice_log2", C.c_uint32), ("phase_slices", C.c_uint32), ("phase_window_ticks", C.c_uint32)]
+                ("phase_slice_log2", C.c_uint32), ("phase_slices", C.c_uint32), ("phase_window_ticks", C.c_uint32),
+                ("phase_rule_ticks", C.c_uint32)]
 
 
 class IbfCompare(C.Structure):
@@ -131,6 +132,7 @@ SIGNATURES = {
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
     "rb_engine_plan": (_int, [_vp, _sz, _sz, _u32, C.POINTER(PlanInfo)]),
+    "rb_engine_calibrate": (_int, [_vp, _sz, _u32, _dbl, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "rb_dibf_probe_read_peak": (_int, [_vp, _u64, _u32, _int, _u32, _dbl, C.POINTER(_dbl), C.POINTER(_dbl)]),
 }
 
@@ -453,6 +455,12 @@ class Engine:
         d = {k: getattr(p, k) for k, _ in PlanInfo._fields_}
         d["kernel"], d["phase_shape_name"] = p.kernel.decode(), p.phase_shape_name.decode()
         return d
+
+    def calibrate(self, n_reads=262144, read_len=250, max_ms=0.0):
+        """fit the phased windows to this device -> (phased tables found, tables whose window changed)"""
+        nt, nc = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().rb_engine_calibrate(self.h, n_reads, read_len, max_ms, C.byref(nt), C.byref(nc)), "rb_engine_calibrate")
+        return nt.value, nc.value
 
     def set_split_threshold(self, max_reads):
         _check(lib().rb_engine_set_split_threshold(self.h, max_reads), "rb_engine_set_split_threshold")

@@ -109,7 +109,8 @@ struct CountLaunch {
     PhaseCfg phase;               // throughput form on narrow filters: clock-phased gathers (n_slices == 0: off)
     NarrowMerge narrow;           // phased form on two- to four-word blocks: columns -> members (the engine fills it; n = 1: one filter)
     int phase_shape;              // engine bookkeeping (rbplan::PhaseShape of the planner's row for this launch; the kernels do not read it)
-    uint32_t phase_slice_log2, phase_ticks;  // ... the slice size and window length the planner chose (10 ns ticks), for rb_engine_plan
+    uint32_t phase_slice_log2, phase_ticks;  // ... the slice size and window length in effect (10 ns ticks), for rb_engine_plan
+    uint32_t phase_rule_ticks;               // ... and what the planner's table alone would give (rb_engine_calibrate may have replaced it)
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
@@ -162,6 +163,7 @@ hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, c
 hipError_t launch_restride_blocks(const uint64_t *src, uint32_t s_src, uint64_t *dst, uint32_t s_dst, uint32_t w_copy,
                                   uint64_t n_blocks, hipStream_t st);
 hipError_t launch_compare_bits(const uint64_t *a, const uint64_t *b, uint64_t n_words, uint64_t *out3, hipStream_t st);
+hipError_t launch_fill_reads(uint8_t *seqs, uint64_t *offsets, uint32_t *lens, size_t n_reads, uint32_t read_len, uint64_t seed, hipStream_t st);
 hipError_t launch_fill_synth(uint64_t *words, uint64_t used_words, uint32_t bin_width, uint32_t stride_words,
                              uint64_t last_mask, uint64_t seed, hipStream_t st);
 

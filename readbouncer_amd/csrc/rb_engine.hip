@@ -141,6 +141,13 @@ struct rb_engine {
     uint32_t phase_max_slices = 32;   // slices a table is cut into (<= 32: a wave keeps a bit per slice)
     uint32_t phase_slice_log2 = 0;    // slices of 2^n bytes instead of the rule of phase_slice_log2(); 1-5: as small as phase_max_slices allows
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
+    // rb_engine_calibrate: window lengths measured on this device that replace the planner's for a (table, kernel shape, slice size)
+    struct PhaseOverride {
+        uint64_t table_bytes;
+        uint32_t stride, slice_log2, ticks;
+        int shape, lg;
+    };
+    std::vector<PhaseOverride> phase_overrides;
     uint32_t phase_min_reads = 2049;  // everything above the latency kernel's batches: README shape at 2 049 reads per call 8.7 -> 9.2 M reads/s, 4 096: 11.6 -> 16.5 M, 65 536: 16.0 -> 28.3 M (profiles/r03/phased_batch_size.txt)
     bool short_read_kernel = true;
     int six_tile_kernel = 1;  // reads of 257-384 k-mers (360 bp): one round of six tiles per strand (RB_SIX_TILES=0: two rounds of four)
@@ -825,6 +832,7 @@ int rb_engine_set_phased(rb_engine *e, uint64_t min_table_bytes, uint64_t max_ta
         e->phase_explicit = false;
     }
     e->phase_min_reads = min_reads;
+    e->phase_overrides.clear();
     e->short_read_kernel = !(min_table_bytes == 0 && max_table_bytes == 0 && base_ticks == 0 && ticks_per_mib == 0 && min_reads == 0);
     return RB_OK;
 }
@@ -835,6 +843,7 @@ int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_s
     std::lock_guard<std::mutex> lock(e->mu);
     e->phase_slice_log2 = slice_log2;
     e->phase_max_slices = max_slices;
+    e->phase_overrides.clear();
     return RB_OK;
 }
 
@@ -1036,6 +1045,10 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             const uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
                                                : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
+            a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
+            if (!e->phase_explicit)  // a window measured on this device for exactly this table, shape and slice size (rb_engine_calibrate)
+                for (const rb_engine::PhaseOverride &o : e->phase_overrides)
+                    if (o.table_bytes == table_bytes && o.stride == f->stride && o.shape == (int)shape && o.lg == a.lg && o.slice_log2 == slice_log2) ticks = o.ticks;
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             a.phase_slice_log2 = slice_log2;
             a.phase_ticks = (uint32_t)ticks;
@@ -1601,9 +1614,111 @@ extern "C" int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads,
             out->phased = 1;
             out->phase_slice_log2 = a.phase_slice_log2;
             out->phase_window_ticks = a.phase_ticks;
+            out->phase_rule_ticks = a.phase_rule_ticks;
         }
     }
     return RB_OK;
+}
+
+// Fits the windows of the clock-phased gathers to THIS device: the planner's table was measured on one box;
+// clocks, firmware and compilers move the optima.  For every table the engine would serve with the phased form on a batch of
+// n_reads reads of read_len bases, K1 of the whole engine is timed on synthetic reads with the rule's window and with the window
+// x 0.7 / 0.85 / 1.2 / 1.45 (same slice size); the fastest -- if it beats the rule by more than 2 % -- replaces the rule for that
+// table, kernel shape and slice size.  Results never depend on it.  Call it on an idle engine.
+extern "C" int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_len, double max_ms, uint32_t *n_tables, uint32_t *n_changed)
+{
+    if (!e || n_reads == 0 || n_reads >= (1ULL << 28) || read_len == 0 || read_len > 100000) return rb::fail(RB_ERR_INVALID_ARG, "rb_engine_calibrate: bad argument");
+    if (n_tables) *n_tables = 0;
+    if (n_changed) *n_changed = 0;
+    int rc = check_device(e->device);
+    if (rc != RB_OK) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto elapsed_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    // which tables are phased, and with what: the engine's own answer per filter (merged groups answer for all their members)
+    struct Key { uint64_t table_bytes; uint32_t stride, slice_log2, rule_ticks; int shape, lg; };
+    std::vector<Key> keys;
+    for (size_t fi = 0; fi < e->filters.size(); ++fi) {
+        rb_plan_info pl;
+        if ((rc = rb_engine_plan(e, fi, n_reads, read_len, &pl)) != RB_OK) return rc;
+        if (!pl.phased) continue;
+        Key k{pl.table_bytes, pl.stride_words, pl.phase_slice_log2, pl.phase_rule_ticks, (int)pl.phase_shape, (int)pl.lanes_per_block_log2};
+        bool seen = false;
+        for (const Key &o : keys) seen |= o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2;
+        if (!seen) keys.push_back(k);
+    }
+    if (n_tables) *n_tables = (uint32_t)keys.size();
+    if (keys.empty()) return RB_OK;
+    // synthetic batch on the device: uniform ACGT (the lookups of a read are uniform over the table whatever its bases are)
+    DevBuf d_reads, d_off, d_len, d_max;
+    const size_t nf = e->filters.size();
+    if ((rc = d_reads.ensure(n_reads * (size_t)read_len)) != RB_OK || (rc = d_off.ensure(n_reads * 8)) != RB_OK || (rc = d_len.ensure(n_reads * 4)) != RB_OK ||
+        (rc = d_max.ensure(n_reads * nf * 2)) != RB_OK) {
+        d_reads.release(); d_off.release(); d_len.release(); d_max.release();
+        return rc;
+    }
+    hipError_t he = launch_fill_reads((uint8_t *)d_reads.p, (uint64_t *)d_off.p, (uint32_t *)d_len.p, n_reads, read_len, 0x5eedULL, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    auto cleanup = [&] { d_reads.release(); d_off.release(); d_len.release(); d_max.release(); };
+    if (he != hipSuccess) { cleanup(); return rb::fail(RB_ERR_HIP, std::string("calibrate: ") + hipGetErrorString(he)); }
+    rb_batch_desc desc;
+    std::memset(&desc, 0, sizeof desc);
+    desc.d_seqs = d_reads.p;
+    desc.d_offsets = d_off.p;
+    desc.d_lens = d_len.p;
+    desc.n_items = n_reads;
+    desc.max_len = read_len;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); return rb::fail(RB_ERR_HIP, "calibrate: events"); }
+    auto k1_ms = [&](double *out) -> int {  // one untimed launch, then the mean of two
+        for (int it = 0; it < 3; ++it) {
+            if (it == 1) (void)hipEventRecord(ev0, e->stream);
+            const int r = classify_device_impl(e, &desc, 0.1, 0.95, RB_MODE_CHECK_UNBLOCK, d_max.p, nullptr, nullptr, nullptr, (void *)e->stream, nullptr);
+            if (r != RB_OK) return r;
+        }
+        (void)hipEventRecord(ev1, e->stream);
+        if (hipEventSynchronize(ev1) != hipSuccess) return rb::fail(RB_ERR_HIP, "calibrate: sync");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev0, ev1);
+        *out = ms / 2.0;
+        return RB_OK;
+    };
+    static const double kFactors[] = {1.0, 0.85, 1.2, 0.7, 1.45};
+    uint32_t changed = 0;
+    for (const Key &k : keys) {
+        double best_ms = 0.0, rule_ms = 0.0;
+        uint32_t best_ticks = k.rule_ticks;
+        for (double fct : kFactors) {
+            if (fct != 1.0 && max_ms > 0 && elapsed_ms() > max_ms) break;
+            const uint32_t ticks = (uint32_t)std::min(2000.0, std::max(100.0, k.rule_ticks * fct));
+            {
+                std::lock_guard<std::mutex> lock(e->mu);
+                auto &ov = e->phase_overrides;
+                ov.erase(std::remove_if(ov.begin(), ov.end(), [&](const rb_engine::PhaseOverride &o) {
+                             return o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2; }), ov.end());
+                ov.push_back(rb_engine::PhaseOverride{k.table_bytes, k.stride, k.slice_log2, ticks, k.shape, k.lg});
+            }
+            double ms = 0.0;
+            if ((rc = k1_ms(&ms)) != RB_OK) break;
+            if (fct == 1.0) rule_ms = ms;
+            if (best_ms == 0.0 || ms < best_ms) { best_ms = ms; best_ticks = ticks; }
+        }
+        {
+            std::lock_guard<std::mutex> lock(e->mu);
+            auto &ov = e->phase_overrides;
+            ov.erase(std::remove_if(ov.begin(), ov.end(), [&](const rb_engine::PhaseOverride &o) {
+                         return o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2; }), ov.end());
+            if (rc == RB_OK && best_ticks != k.rule_ticks && best_ms < 0.98 * rule_ms) {
+                ov.push_back(rb_engine::PhaseOverride{k.table_bytes, k.stride, k.slice_log2, best_ticks, k.shape, k.lg});
+                ++changed;
+            }
+        }
+        if (rc != RB_OK) break;
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    cleanup();
+    if (n_changed) *n_changed = changed;
+    return rc;
 }
 
 extern "C" {

@@ -1526,6 +1526,22 @@ __global__ void fill_synth_kernel(uint64_t *__restrict__ words, uint64_t used_wo
     }
 }
 
+// synthetic batch for rb_engine_calibrate: n_reads reads of read_len uniform ACGT bases, back to back
+__global__ void fill_reads_kernel(uint8_t *__restrict__ seqs, uint64_t *__restrict__ offsets, uint32_t *__restrict__ lens, uint64_t n_reads,
+                                  uint32_t read_len, uint64_t seed)
+{
+    const uint64_t total = n_reads * read_len;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const uint64_t w = rbspec::synth_word(seed, i >> 5);  // 32 bases per 64-bit word
+        seqs[i] = (uint8_t)"ACGT"[(w >> ((i & 31u) * 2u)) & 3u];
+        if (i < n_reads) {
+            offsets[i] = i * read_len;
+            lens[i] = read_len;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 template <int LG, int WPL, int NP, int H, bool NT>
@@ -1909,6 +1925,15 @@ hipError_t launch_compare_bits(const uint64_t *a, const uint64_t *b, uint64_t n_
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(compare_bits_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, a, b, n_words,
                        reinterpret_cast<unsigned long long *>(out3));
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_reads(uint8_t *seqs, uint64_t *offsets, uint32_t *lens, size_t n_reads, uint32_t read_len, uint64_t seed, hipStream_t st)
+{
+    if (n_reads == 0 || read_len == 0) return hipSuccess;
+    uint64_t blocks = ((uint64_t)n_reads * read_len + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(fill_reads_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, seqs, offsets, lens, (uint64_t)n_reads, read_len, seed);
     return hipGetLastError();
 }
 

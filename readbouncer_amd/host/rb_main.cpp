@@ -218,6 +218,8 @@ struct IngestOptions
                                     // each); 0 = [IBF] threads when the TOML sets it above 1 (the reference's meaning of that key:
                                     // classification threads, adaptive_sampling.hpp:745), else 6 (profiles/r04/cli_throughput_sweep.txt:
                                     // 4 leave the GPU idle while they format, 8 only queue on the output files' inode locks)
+    bool calibrate = false;      // --calibrate: every classifier thread's engine fits the windows of its clock-phased gathers to this device first
+                                 // (rb_engine_calibrate, one engine after the other: ~30 ms each; pays on long runs over narrow filters)
     bool mmap_output = false;    // --mmap-output: the classifier threads write the outputs through shared mappings of the files instead of
                                  // positional writes of a small buffer each (measured slower on tmpfs: page faults on fresh page-cache pages)
     size_t segment_mb = 32;      // file bytes per parsed segment (one GPU call of ~65 k reads of 250 bp; the page-locked staging blocks scale with it)
@@ -427,8 +429,17 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         std::condition_variable ocv;
         uint64_t next_seq = 0, write_seq = 0;
         std::string worker_error;
+        std::mutex cal_mu;
         auto classifier = [&] {
             try {
+                if (opt.calibrate && !multi) {  // one engine at a time: they would spoil each other's timings
+                    std::lock_guard<std::mutex> lock(cal_mu);
+                    uint32_t n_tables = 0, n_changed = 0;
+                    const int rc = rb_engine_calibrate(interleave::detail::engine_for(DepletionFilters, TargetFilters), opt.batch_reads, chunk_length, 40.0,
+                                                       &n_tables, &n_changed);
+                    if (rc != RB_OK) log_line("warn", std::string("calibration skipped: ") + rb_last_error());
+                    else log_line("info", "calibrated " + std::to_string(n_tables) + " phased table(s), " + std::to_string(n_changed) + " window(s) changed");
+                }
                 for (;;) {
                     std::unique_ptr<seqio::Segment> seg;
                     uint64_t seq = 0;
@@ -693,6 +704,7 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--batch-reads") && i + 1 < argc) opt.batch_reads = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
+        else if (!std::strcmp(argv[i], "--calibrate")) opt.calibrate = true;
         else if (!std::strcmp(argv[i], "--mmap-output")) opt.mmap_output = true;
         else if (!std::strcmp(argv[i], "--no-mmap-output")) opt.mmap_output = false;
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
@@ -722,7 +734,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] [--calibrate] "
                          "[--devices 0,1,...] [--parse-stats file]\n"
                          "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;

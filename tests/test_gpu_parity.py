@@ -995,6 +995,27 @@ def test_measurement_aids_answer():
     assert pl["kernel"] == "ibf_count_max_phased_kernel" and pl["phased"] == 1 and pl["phase_shape_name"].startswith("four tiles")
     assert pl["phase_slices"] * (1 << pl["phase_slice_log2"]) >= pl["table_bytes"] and 100 <= pl["phase_window_ticks"] <= 2000
     assert capi.lib().rb_dibf_touch(small.h) == 0 and capi.lib().rb_dibf_touch(None) != 0
+    # rb_engine_calibrate: windows measured on this device replace the table's for exactly that table and shape; results stay
+    rng = np.random.default_rng(99)
+    ref = H.random_dna(rng, 20000)
+    small.add_sequence(ref, 400)
+    reads = make_reads(rng, ref, 3000, lo=100, hi=250)
+    buf, offs, lens = H.pack_reads(reads)
+    before = e2.classify(buf, offs, lens)
+    rule = e2.plan(0, 100000, 250)
+    assert rule["phase_rule_ticks"] == rule["phase_window_ticks"]
+    n_tables, n_changed = e2.calibrate(100000, 250)
+    assert n_tables == 1 and n_changed in (0, 1)
+    after = e2.plan(0, 100000, 250)
+    assert after["phase_rule_ticks"] == rule["phase_rule_ticks"] and after["phase_slice_log2"] == rule["phase_slice_log2"]
+    assert 0.69 * rule["phase_rule_ticks"] <= after["phase_window_ticks"] <= 1.46 * rule["phase_rule_ticks"]
+    assert (after["phase_window_ticks"] != rule["phase_window_ticks"]) == (n_changed == 1)
+    got = e2.classify(buf, offs, lens)
+    for a, b in zip(got, before):
+        assert np.array_equal(a, b)
+    e2.set_phased()  # the setters drop what calibration found
+    assert e2.plan(0, 100000, 250)["phase_window_ticks"] == rule["phase_rule_ticks"]
+    assert eng.calibrate(50000, 360) == (0, 0)  # nothing phased in an engine of wide filters
 
 
 def _pool_threads_run(timed):
