@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from readbouncer_amd import capi, synth
 dev = torch.device("cuda:0")
 which = sys.argv[1]
-N, L = 200000, int(sys.argv[2])
+N, L = int(os.environ.get("RB_N", "200000")), int(sys.argv[2])
 mock = {}
 for i, key in enumerate(("mock_deplete", "mock_t1", "mock_t2", "mock_t3")):
     mock[key] = synth.build_device_filter(0, synth.WORKLOADS[key], fill_seed=11 + i, plant_seed=110 + i, n_segments=512)[0]
