@@ -27,14 +27,19 @@ def k1(eng, seqs, offs, lens, L, mc):
 def case(name, deplete, target, L):
     seqs, offs, lens = synth.make_reads_device(5, N, L, None, dev)
     mc = torch.zeros((N, len(deplete) + len(target)), dtype=torch.int16, device=dev)
+    trace = os.environ.get("RB_TRACE") == "1"
     eng = capi.Engine(0, deplete, target)
     eng.set_timing(True)
     before = k1(eng, seqs, offs, lens, L, mc)
+    if trace: print("  before ok", flush=True)
     ref = mc.clone()
     plan0 = eng.plan(0, N, L)
     nt, nc = eng.calibrate(262144, L, 0.0)
+    torch.cuda.synchronize()
+    if trace: print("  calibrate ok", nt, nc, flush=True)
     plan1 = eng.plan(0, N, L)
     after = k1(eng, seqs, offs, lens, L, mc)
+    if trace: print("  after ok", flush=True)
     assert torch.equal(ref, mc)
     print("%-44s %3d bp: %6.2f ms -> %6.2f ms (%+5.1f %%)  tables %d changed %d  window %d -> %d ticks (%s)"
           % (name, L, before, after, (after / before - 1) * 100, nt, nc, plan0["phase_window_ticks"], plan1["phase_window_ticks"], plan0["phase_shape_name"]), flush=True)
