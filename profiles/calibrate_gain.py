@@ -34,7 +34,7 @@ def case(name, deplete, target, L):
     if trace: print("  before ok", flush=True)
     ref = mc.clone()
     plan0 = eng.plan(0, N, L)
-    nt, nc = eng.calibrate(262144, L, 0.0)
+    nt, nc = (0, 0) if os.environ.get("RB_NO_CAL") == "1" else eng.calibrate(int(os.environ.get("RB_CAL_N", "262144")), L, 0.0)
     torch.cuda.synchronize()
     if trace: print("  calibrate ok", nt, nc, flush=True)
     plan1 = eng.plan(0, N, L)
