@@ -19,6 +19,9 @@ def k1(eng, seqs, offs, lens, L, mc):
         if it == 1:
             eng.kernel_time()
         eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), N, L, d_maxcount=mc.data_ptr())
+        if os.environ.get("RB_TRACE") == "1":
+            torch.cuda.synchronize()
+            print("    call", it, "ok", eng.merge_info(), flush=True)
     torch.cuda.synchronize()
     ms, calls = eng.kernel_time()
     return ms / calls
@@ -29,6 +32,7 @@ def case(name, deplete, target, L):
     mc = torch.zeros((N, len(deplete) + len(target)), dtype=torch.int16, device=dev)
     trace = os.environ.get("RB_TRACE") == "1"
     eng = capi.Engine(0, deplete, target)
+    if trace: print("  engine", name, L, eng.plan(0, N, L), flush=True)
     eng.set_timing(True)
     before = k1(eng, seqs, offs, lens, L, mc)
     if trace: print("  before ok", flush=True)
