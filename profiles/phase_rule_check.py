@@ -57,6 +57,7 @@ for point in args.points.split(","):
     N = args.reads
     if L not in reads_cache:
         reads_cache[L] = synth.make_reads_device(5, N, L, None, dev)
+        torch.cuda.synchronize()  # torch filled these on ITS stream; the engine launches on its own (non-blocking) stream
     seqs, offs, lens = reads_cache[L]
     mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
     stride = 1 if W == 1 else 2 if W == 2 else 4

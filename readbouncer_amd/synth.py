@@ -154,7 +154,13 @@ def make_reads_device(seed, n_reads, read_len, ref, device, positive_fraction=0.
             out[perm[b:b + m]] = pos
     lens = torch.full((n_reads,), read_len, dtype=torch.int32, device=device)
     offs = torch.arange(n_reads, dtype=torch.int64, device=device) * read_len
-    return out.reshape(-1).contiguous(), offs, lens
+    out = out.reshape(-1).contiguous()
+    if torch.device(device).type == "cuda":
+        # torch filled these on ITS current stream; the engine launches on streams of its own (non-blocking: no implicit order with
+        # the default stream).  A caller that goes straight to rb_classify_batch_device would race the fill -- lengths still holding a
+        # freed tensor's bytes made K1 read far outside the batch (round 4, a profiling script) -- so the batch is complete on return.
+        torch.cuda.synchronize(device)
+    return out, offs, lens
 
 
 def algorithmic_bytes_per_read(read_len, filters):
