@@ -32,6 +32,8 @@ struct ReadSrc {
     const uint64_t *nmask_offsets;  // per READ: byte offset of its N bitmap
     const uint32_t *ids;            // optional item -> read indirection (nullptr = identity)
     uint32_t base_off;              // bases skipped at the start of every read (chunk start)
+    uint32_t max_len;               // declared upper bound of the item lengths: K1 never looks at more bases of an item than this (a longer
+                                    // item is answered with RB_ERR_INVALID_ARG by the decision kernel; 0 = no bound given)
 };
 
 // Clock-phased gathers for tables of a few L2 sizes (narrow filters; rb_kernels.hip, "phased form"): the table is cut into

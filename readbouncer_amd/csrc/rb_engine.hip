@@ -1430,6 +1430,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
             a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
             a.src.ids = (const uint32_t *)desc->d_read_ids;
             a.src.base_off = desc->chunk_start;
+            a.src.max_len = max_len;
             a.n_reads = (uint32_t)n_reads;
             if (g->width <= 4) {
                 // a merged block of two to four words is held by ONE lane of the both-strands builds of the phased kernel: the
@@ -1475,6 +1476,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
             a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
             a.src.ids = (const uint32_t *)desc->d_read_ids;
             a.src.base_off = desc->chunk_start;
+            a.src.max_len = max_len;
             a.n_reads = (uint32_t)n_reads;
             a.wpl = 1;
             a.lg = 0;
@@ -1516,6 +1518,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         a.src.nmask_offsets = (const uint64_t *)desc->d_nmask_offsets;
         a.src.ids = (const uint32_t *)desc->d_read_ids;
         a.src.base_off = desc->chunk_start;
+            a.src.max_len = max_len;
         a.n_reads = (uint32_t)n_reads;
         if (!plan_geometry(e, f, n_reads, max_len, a)) {
             // this rank holds no column of this filter: its partial maxima are 0

@@ -685,7 +685,10 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
 __device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item, uint32_t *len_out)
 {
     const uint32_t rid = r.ids ? r.ids[item] : item;
-    *len_out = r.lens[item];  // effective length of this work item (chunked or whole read)
+    const uint32_t len = r.lens[item];  // effective length of this work item (chunked or whole read)
+    // never beyond the declared bound: lengths above it are the caller's error (the decision kernel says so per read), and lengths
+    // that are not lengths at all -- a buffer the caller has not finished writing -- must not send K1 reading gigabytes away
+    *len_out = (r.max_len && len > r.max_len) ? r.max_len : len;
     BaseSrc b;
     if (r.nmask) {
         b.bytes = r.seqs + r.offsets[rid];
