@@ -440,8 +440,10 @@ RB_API int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads, uin
 /* Fits the window lengths of the clock-phased gathers to THIS device: the planner's table was measured on one box, and clocks,
  * firmware and compilers move the optima.  For every table the engine would serve with the phased form on batches of n_reads reads
  * of read_len bases, K1 is timed on synthetic reads with the table's window and with 0.7 / 0.85 / 1.2 / 1.45 x that (same slice
- * size); the fastest replaces the rule for that table and kernel shape when it wins by more than 2 %, until the engine goes away
- * or rb_engine_set_phased / rb_engine_set_phase_slices is called.  Stops trying new windows after max_ms (0 = no limit); a few
+ * size); the best point of the curve smoothed along the window length replaces the rule for that table and kernel shape when it
+ * wins by 4 % and a second measurement confirms it, until the engine goes away or rb_engine_set_phased /
+ * rb_engine_set_phase_slices is called.  Calibrate at the batch size the engine will be given: where the dips and cliffs of the
+ * two-word and wide shapes lie moves with it.  Stops trying new windows after max_ms (0 = no limit); a few
  * launches per table, tens of milliseconds in all.  Results never depend on it; call it on an idle engine.  n_tables: phased
  * tables found; n_changed: how many got a new window.  No reference counterpart (profiles/phase_rule_check.py is the
  * offline form of the same sweep, with an exit code). */

@@ -33,7 +33,7 @@ def case(name, deplete, target, L):
     before = k1(eng, seqs, offs, lens, L, mc)
     ref = mc.clone()
     plan0 = eng.plan(0, N, L)
-    nt, nc = (0, 0) if os.environ.get("RB_NO_CAL") == "1" else eng.calibrate(int(os.environ.get("RB_CAL_N", "262144")), L, 0.0)
+    nt, nc = (0, 0) if os.environ.get("RB_NO_CAL") == "1" else eng.calibrate(int(os.environ.get("RB_CAL_N", str(N))), L, 0.0)  # at the batch size it is then run with
     torch.cuda.synchronize()
     plan1 = eng.plan(0, N, L)
     after = k1(eng, seqs, offs, lens, L, mc)

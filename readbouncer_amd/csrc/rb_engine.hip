@@ -1685,36 +1685,52 @@ extern "C" int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_l
         *out = ms / 2.0;
         return RB_OK;
     };
-    static const double kFactors[] = {1.0, 0.85, 1.2, 0.7, 1.45};
+    // Windows around the rule's, in order.  Two-word and wide blocks show narrow dips and cliffs along the window length (a neighbour
+    // of the best point can be 30 % slower), and where they lie moves with the batch size: the winner is the best point of the
+    // SMOOTHED curve (half the point, a quarter of each neighbour), it has to beat the rule's smoothed time by 4 %, and a second
+    // measurement of rule and winner has to confirm 3 % -- otherwise the rule stays.
+    static const double kFactors[] = {0.7, 0.85, 1.0, 1.2, 1.45};
+    constexpr int kN = 5, kRule = 2;
+    auto set_trial = [&](const Key &k, uint32_t ticks, bool install) {
+        std::lock_guard<std::mutex> lock(e->mu);
+        auto &ov = e->phase_overrides;
+        ov.erase(std::remove_if(ov.begin(), ov.end(), [&](const rb_engine::PhaseOverride &o) {
+                     return o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2; }), ov.end());
+        if (install) ov.push_back(rb_engine::PhaseOverride{k.table_bytes, k.stride, k.slice_log2, ticks, k.shape, k.lg});
+    };
     uint32_t changed = 0;
     for (const Key &k : keys) {
-        double best_ms = 0.0, rule_ms = 0.0;
-        uint32_t best_ticks = k.rule_ticks;
-        for (double fct : kFactors) {
-            if (fct != 1.0 && max_ms > 0 && elapsed_ms() > max_ms) break;
-            const uint32_t ticks = (uint32_t)std::min(2000.0, std::max(100.0, k.rule_ticks * fct));
-            {
-                std::lock_guard<std::mutex> lock(e->mu);
-                auto &ov = e->phase_overrides;
-                ov.erase(std::remove_if(ov.begin(), ov.end(), [&](const rb_engine::PhaseOverride &o) {
-                             return o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2; }), ov.end());
-                ov.push_back(rb_engine::PhaseOverride{k.table_bytes, k.stride, k.slice_log2, ticks, k.shape, k.lg});
-            }
-            double ms = 0.0;
-            if ((rc = k1_ms(&ms)) != RB_OK) break;
-            if (fct == 1.0) rule_ms = ms;
-            if (best_ms == 0.0 || ms < best_ms) { best_ms = ms; best_ticks = ticks; }
+        double t[kN] = {0, 0, 0, 0, 0};
+        uint32_t ticks[kN];
+        bool complete = true;
+        for (int i = 0; i < kN && rc == RB_OK; ++i) {
+            ticks[i] = (uint32_t)std::min(2000.0, std::max(100.0, k.rule_ticks * kFactors[i]));
+            if (max_ms > 0 && elapsed_ms() > max_ms) { complete = false; break; }
+            set_trial(k, ticks[i], true);
+            rc = k1_ms(&t[i]);
         }
-        {
-            std::lock_guard<std::mutex> lock(e->mu);
-            auto &ov = e->phase_overrides;
-            ov.erase(std::remove_if(ov.begin(), ov.end(), [&](const rb_engine::PhaseOverride &o) {
-                         return o.table_bytes == k.table_bytes && o.stride == k.stride && o.shape == k.shape && o.lg == k.lg && o.slice_log2 == k.slice_log2; }), ov.end());
-            if (rc == RB_OK && best_ticks != k.rule_ticks && best_ms < 0.98 * rule_ms) {
-                ov.push_back(rb_engine::PhaseOverride{k.table_bytes, k.stride, k.slice_log2, best_ticks, k.shape, k.lg});
-                ++changed;
+        int best = kRule;
+        if (rc == RB_OK && complete) {
+            double sm[kN];
+            for (int i = 0; i < kN; ++i) sm[i] = 0.5 * t[i] + 0.25 * t[i > 0 ? i - 1 : i] + 0.25 * t[i + 1 < kN ? i + 1 : i];
+            for (int i = 0; i < kN; ++i)
+                if (sm[i] < sm[best]) best = i;
+            if (best != kRule && !(sm[best] < 0.96 * sm[kRule])) best = kRule;
+            if (best != kRule && ticks[best] != ticks[kRule]) {  // confirm on fresh measurements
+                double t_rule = 0.0, t_best = 0.0;
+                set_trial(k, ticks[kRule], true);
+                rc = k1_ms(&t_rule);
+                if (rc == RB_OK) {
+                    set_trial(k, ticks[best], true);
+                    rc = k1_ms(&t_best);
+                }
+                if (rc != RB_OK || !(t_best < 0.97 * t_rule)) best = kRule;
+            } else {
+                best = kRule;
             }
         }
+        set_trial(k, ticks[best < kN ? best : kRule], rc == RB_OK && best != kRule);
+        if (rc == RB_OK && best != kRule) ++changed;
         if (rc != RB_OK) break;
     }
     (void)hipEventDestroy(ev0);

@@ -489,8 +489,9 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
                         if (!complete) throw std::runtime_error("output layout mismatch");
                     }
                     out.clear();            // (the cursors first: their buffers are on their way to the files' writer threads)
-                    seg->release_mapping();  // the records of this segment are not looked at again
+                    const size_t seg_index = seg->index;
                     seg.reset();
+                    reader.release(seg_index);  // the records of this segment are not looked at again
                     {
                         std::lock_guard<std::mutex> lock(omu);
                         format_s += seconds_since(tf);

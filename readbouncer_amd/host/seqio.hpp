@@ -247,8 +247,6 @@ public:
 
 struct Segment
 {
-    const char* map_begin = nullptr;   // the stretch of the mapped file this segment was parsed from
-    const char* map_end = nullptr;
     Batch batch;                       // every record of the segment (views into the mapping / the arena)
     char* prefix = nullptr;            // prefix_len bases of each record with seq_len >= prefix_len, back to back
     size_t prefix_cap = 0;
@@ -261,18 +259,7 @@ struct Segment
     {
         if (prefix && pool) pool->put(prefix, prefix_cap);
     }
-    // The consumer is done with the records (their views die with this call): the whole pages of this segment's stretch are dropped
-    // from the address space (the data stays in the page cache).  A 30 GB read file otherwise ends the run with 8 M page-table
-    // entries to tear down at once -- and a resident set the size of the file.
-    void release_mapping()
-    {
-        if (!map_begin) return;
-        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
-        const uintptr_t lo = ((uintptr_t)map_begin + page - 1) / page * page, hi = (uintptr_t)map_end / page * page;
-        if (hi > lo) madvise((void*)lo, hi - lo, MADV_DONTNEED);
-        batch.records.clear();
-        map_begin = map_end = nullptr;
-    }
+    size_t index = 0;                  // position of this segment in the file (ParallelReader::release)
 };
 
 namespace detail
@@ -340,6 +327,9 @@ class ParallelReader
     bool stop_ = false;
     std::mutex mu_;
     std::condition_variable cv_ready_, cv_room_;
+    std::mutex rel_mu_;
+    std::vector<bool> done_;      // segments whose records nobody looks at any more
+    size_t released_ = 0;         // segments [0, released_) have left the address space
 
     void work()
     {
@@ -352,8 +342,7 @@ class ParallelReader
                 if (stop_) return;
             }
             std::unique_ptr<Segment> seg(new Segment());
-            seg->map_begin = data_ + starts_[s];
-            seg->map_end = data_ + starts_[s + 1];
+            seg->index = s;
             // nothing may escape a worker thread (std::terminate, with the consumers blocked in next()): a failure becomes
             // a segment whose batch.error is set -- the consumer's ordinary error path, and the last segment it sees
             try {
@@ -429,6 +418,33 @@ public:
     ParallelReader& operator=(const ParallelReader&) = delete;
 
     size_t segments() const { return slots_.size(); }
+
+    // The consumer is done with the records of segment `index` (their views into the mapping are dead).  Once a stretch of at least
+    // 512 MB of consecutive finished segments has built up from the front of the file, its whole pages are dropped from the address
+    // space (the data stays in the page cache): a 30 GB read file otherwise ends the run with 8 M page-table entries to tear down at
+    // once and a resident set the size of the file.  In large steps on purpose: every MADV_DONTNEED is a TLB shoot-down on all the
+    // process's CPUs (per 32 MB segment it cost the pipeline 10-15 % of its rate).
+    void release(size_t index)
+    {
+        const char *lo = nullptr, *hi = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(rel_mu_);
+            if (done_.size() < slots_.size()) done_.resize(slots_.size(), false);
+            if (index >= done_.size()) return;
+            done_[index] = true;
+            size_t upto = released_;
+            while (upto < done_.size() && done_[upto]) ++upto;
+            if (upto == released_) return;
+            const size_t bytes = starts_[upto] - starts_[released_];
+            if (bytes < ((size_t)512 << 20) && upto != done_.size()) return;
+            lo = data_ + starts_[released_];
+            hi = data_ + starts_[upto];
+            released_ = upto;
+        }
+        const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+        const uintptr_t a = ((uintptr_t)lo + page - 1) / page * page, b = (uintptr_t)hi / page * page;
+        if (b > a) madvise((void*)a, b - a, MADV_DONTNEED);
+    }
 
     // the next segment in file order; nullptr after the last one.  A segment whose batch.error is set is the last.
     std::unique_ptr<Segment> next()
