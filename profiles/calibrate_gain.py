@@ -14,14 +14,22 @@ dev = torch.device("cuda:0")
 N = 1_000_000
 
 
+SPREAD = {}
+
+
 def k1(eng, seqs, offs, lens, L, mc):
-    for it in range(5):
-        if it == 1:
-            eng.kernel_time()
+    """median K1 ms of seven launches after one untimed (the spread is kept for the report)"""
+    ts = []
+    for it in range(8):
+        eng.kernel_time()
         eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), N, L, d_maxcount=mc.data_ptr())
-    torch.cuda.synchronize()
-    ms, calls = eng.kernel_time()
-    return ms / calls
+        torch.cuda.synchronize()
+        ms, calls = eng.kernel_time()
+        if it:
+            ts.append(ms / calls)
+    ts.sort()
+    SPREAD["last"] = (ts[0], ts[-1])
+    return ts[len(ts) // 2]
 
 
 def case(name, deplete, target, L):
@@ -31,6 +39,7 @@ def case(name, deplete, target, L):
     eng = capi.Engine(0, deplete, target)
     eng.set_timing(True)
     before = k1(eng, seqs, offs, lens, L, mc)
+    sp0 = SPREAD["last"]
     ref = mc.clone()
     plan0 = eng.plan(0, N, L)
     nt, nc = (0, 0) if os.environ.get("RB_NO_CAL") == "1" else eng.calibrate(int(os.environ.get("RB_CAL_N", str(N))), L, 0.0)  # at the batch size it is then run with
@@ -38,8 +47,10 @@ def case(name, deplete, target, L):
     plan1 = eng.plan(0, N, L)
     after = k1(eng, seqs, offs, lens, L, mc)
     assert torch.equal(ref, mc)
-    print("%-44s %3d bp: %6.2f ms -> %6.2f ms (%+5.1f %%)  tables %d changed %d  window %d -> %d ticks (%s)"
-          % (name, L, before, after, (after / before - 1) * 100, nt, nc, plan0["phase_window_ticks"], plan1["phase_window_ticks"], plan0["phase_shape_name"]), flush=True)
+    sp1 = SPREAD["last"]
+    print("%-44s %3d bp: %6.2f ms [%.2f-%.2f] -> %6.2f ms [%.2f-%.2f] (%+5.1f %%)  tables %d changed %d  window %d -> %d ticks (%s)"
+          % (name, L, before, sp0[0], sp0[1], after, sp1[0], sp1[1], (after / before - 1) * 100, nt, nc, plan0["phase_window_ticks"],
+             plan1["phase_window_ticks"], plan0["phase_shape_name"]), flush=True)
     eng.destroy()
 
 

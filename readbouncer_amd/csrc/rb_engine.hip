@@ -1672,17 +1672,21 @@ extern "C" int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_l
     desc.max_len = read_len;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { cleanup(); return rb::fail(RB_ERR_HIP, "calibrate: events"); }
-    auto k1_ms = [&](double *out) -> int {  // one untimed launch, then the mean of two
-        for (int it = 0; it < 3; ++it) {
-            if (it == 1) (void)hipEventRecord(ev0, e->stream);
+    auto k1_ms = [&](double *out) -> int {  // one untimed launch, then the MEDIAN of five, each timed on its own: single launches of the
+                                            // two-word shapes can land 10-15 % off their usual time (a mean of two picked such outliers)
+        double ms[5];
+        for (int it = 0; it < 6; ++it) {
+            (void)hipEventRecord(ev0, e->stream);
             const int r = classify_device_impl(e, &desc, 0.1, 0.95, RB_MODE_CHECK_UNBLOCK, d_max.p, nullptr, nullptr, nullptr, (void *)e->stream, nullptr);
             if (r != RB_OK) return r;
+            (void)hipEventRecord(ev1, e->stream);
+            if (hipEventSynchronize(ev1) != hipSuccess) return rb::fail(RB_ERR_HIP, "calibrate: sync");
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, ev0, ev1);
+            if (it > 0) ms[it - 1] = t;
         }
-        (void)hipEventRecord(ev1, e->stream);
-        if (hipEventSynchronize(ev1) != hipSuccess) return rb::fail(RB_ERR_HIP, "calibrate: sync");
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ev0, ev1);
-        *out = ms / 2.0;
+        std::sort(ms, ms + 5);
+        *out = ms[2];
         return RB_OK;
     };
     // Windows around the rule's, in order.  Two-word and wide blocks show narrow dips and cliffs along the window length (a neighbour
