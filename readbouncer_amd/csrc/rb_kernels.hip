@@ -1536,7 +1536,10 @@ __global__ void fill_reads_kernel(uint8_t *__restrict__ seqs, uint64_t *__restri
     const uint64_t total = n_reads * read_len;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const uint64_t w = rbspec::synth_word(seed, i >> 5);  // 32 bases per 64-bit word
+        // 32 bases per 64-bit word of a UNIFORM mixer (not synth_word: its bits are set with the filters' design load, 0.215 -- reads
+        // of 62 % A would repeat their k-mers, hit the caches and mislead the calibration: round 4 saw it pick windows that were 13 %
+        // slower on real reads)
+        const uint64_t w = rbspec::mix64(seed + ((i >> 5) + 1) * 0x9E3779B97F4A7C15ULL);
         seqs[i] = (uint8_t)"ACGT"[(w >> ((i & 31u) * 2u)) & 3u];
         if (i < n_reads) {
             offsets[i] = i * read_len;
