@@ -41,3 +41,47 @@ def test_phase_rules_hold_between_the_fitted_points():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "phase_rule_check.py")], capture_output=True, text=True, timeout=1500)
     print(p.stdout[-3000:])
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+@pytest.mark.gpu
+@pytest.mark.gpuperf
+def test_calibration_never_makes_it_slower():
+    """rb_engine_calibrate on the shapes where round 4's first versions went wrong (a window measured on low-entropy reads, or at
+    another batch size, walked two-word tables off a cliff: +13 ... +35 %): K1 after calibration is at most 3 % above K1 before"""
+    import numpy as np
+    torch = pytest.importorskip("torch")
+    from readbouncer_amd import capi, synth
+    dev = torch.device("cuda:0")
+    N = 500_000
+    cases = []
+    targets = [synth.build_device_filter(0, synth.WORKLOADS[k], fill_seed=12 + i, plant_seed=111 + i, n_segments=512)[0]
+               for i, k in enumerate(("mock_t1", "mock_t2", "mock_t3"))]
+    cases.append(("three targets, packed two-word table", [], targets, 200))
+    big = capi.DeviceIBF.create(0, 128, 3, 13, 128 * (int(45 * (1 << 20) / 16) - 3))
+    big.fill_synth(3)
+    cases.append(("two-word filter of 45 MiB", [big], [], 250))
+    for name, dep, tgt, L in cases:
+        seqs, offs, lens = synth.make_reads_device(5, N, L, None, dev)
+        mc = torch.zeros((N, len(dep) + len(tgt)), dtype=torch.int16, device=dev)
+        eng = capi.Engine(0, dep, tgt)
+        eng.set_timing(True)
+
+        def k1():
+            ts = []
+            for it in range(6):
+                eng.kernel_time()
+                eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), N, L, d_maxcount=mc.data_ptr())
+                torch.cuda.synchronize()
+                ms, calls = eng.kernel_time()
+                if it:
+                    ts.append(ms / calls)
+            return float(np.median(ts))
+        before = k1()
+        ref = mc.clone()
+        n_tables, n_changed = eng.calibrate(N, L)
+        after = k1()
+        print("%s: %.2f ms -> %.2f ms, %d table(s), %d changed, window %d ticks" % (name, before, after, n_tables, n_changed,
+                                                                                    eng.plan(0, N, L)["phase_window_ticks"]))
+        assert n_tables == 1 and torch.equal(ref, mc)
+        assert after <= 1.03 * before, (name, before, after)
+        eng.destroy()
