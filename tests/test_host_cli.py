@@ -333,7 +333,10 @@ def test_pipeline_settings_do_not_change_the_outputs(tmp_path):
     outputs = []
     for tag, extra in (("a", ("--ingest-threads", "1", "--batch-reads", "1000000")),
                        ("b", ("--ingest-threads", "4", "--segment-bytes", "150000", "--batch-reads", "777")),
-                       ("c", ("--ingest-threads", "3", "--segment-bytes", "20000", "--batch-reads", "64"))):
+                       ("c", ("--ingest-threads", "3", "--segment-bytes", "20000", "--batch-reads", "64")),
+                       # one and many classifier threads, outputs through shared mappings of the files, engines calibrated first
+                       ("d", ("--classify-threads", "1", "--segment-bytes", "90000", "--batch-reads", "5000")),
+                       ("e", ("--classify-threads", "7", "--segment-bytes", "30000", "--mmap-output", "--calibrate"))):
         out = tmp_path / ("out_" + tag)
         cfg = tmp_path / (tag + ".toml")
         write_config(cfg, "classify", out, kmer_size=13, fragment_size=1000, deplete_files=[tmp_path / "dep.fasta"],
@@ -342,7 +345,7 @@ def test_pipeline_settings_do_not_change_the_outputs(tmp_path):
         line = [l for l in stdout.splitlines() if l.startswith("RESULT")][0]
         files = {p.name: p.read_bytes() for p in sorted(out.glob("*.fasta"))}
         outputs.append((line, files))
-    assert outputs[0] == outputs[1] == outputs[2]
+    assert all(o == outputs[0] for o in outputs[1:])
     line, files = outputs[0]
     # the oracle's chunk driver on filters built like the reference builds them
     od = H.build_filter_like_reference([dep_seq], k=13, fragment_length=1000)
