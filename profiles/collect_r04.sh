@@ -26,6 +26,7 @@ $T python3 bench.py --workload c1 --steps 5 --warmup 1 --cpu-seconds 5 --no-late
 RB_BENCH_BACKEND=gloo RB_BENCH_SAME_GPU=1 RB_BENCH_DUMP_DECISIONS=1 RB_BENCH_READS_DIVISOR=20 $T python3 bench.py --gpus 2 --steps 3 --warmup 1 --cpu-seconds 3 > $OUT/bench_gpus2_same_gpu_default.json 2> $OUT/bench_gpus2_same_gpu_default.err
 RB_BENCH_DUMP_DECISIONS=1 RB_BENCH_READS_DIVISOR=20 $T python3 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-seconds 3 > $OUT/bench_gpus1_default_div20.json 2> /dev/null
 ( time $T python3 profiles/engines_on_one_gpu.py ) > $OUT/engines_on_one_gpu.txt 2>&1
+$T python3 profiles/calibrate_gain.py > $OUT/calibrate_gain.txt 2>&1
 ( time $T python3 profiles/cli_readme250.py ) > $OUT/cli_throughput.txt 2>&1
 ( time $T python3 profiles/cli_readme250.py 64000000 - quick ) > $OUT/cli_throughput_64M_reads.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
