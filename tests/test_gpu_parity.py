@@ -329,6 +329,23 @@ def test_device_pointer_api_and_column_shards():
     torch.cuda.synchronize()
     too_long = lens > 200
     assert (t_st2.cpu().numpy()[too_long] == capi.RB_ERR_INVALID_ARG).all() and (t_st2.cpu().numpy()[~too_long] == exp_st[~too_long]).all()
+    # lengths that are not lengths at all (a buffer the caller has not finished writing: 2^31 - 1, 10^9): K1 never looks past the
+    # declared max_len of an item, the decision kernel reports the read, its neighbours are classified as ever
+    wild = lens.copy()
+    wild[[3, 77, n - 5]] = [2**31 - 1, 10**9, 4 * 10**9]  # (not the last reads: a clamped item still spans max_len bytes of the buffer)
+    t_wild = torch.from_numpy(wild.view(np.int32)).to(dev)
+    t_st3 = torch.zeros(n, dtype=torch.uint8, device=dev)
+    t_max3 = torch.zeros((n, 1), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()
+    for thr in (2048, 0):  # latency and throughput forms
+        eng.set_split_threshold(thr)
+        eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_wild.data_ptr(), n, int(lens.max()), d_maxcount=t_max3.data_ptr(),
+                            d_decision=t_dec.data_ptr(), d_status=t_st3.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        sane = wild == lens
+        assert (t_st3.cpu().numpy()[~sane] == capi.RB_ERR_INVALID_ARG).all() and (t_st3.cpu().numpy()[sane] == exp_st[sane]).all()
+        assert np.array_equal(t_max3.cpu().numpy().view(np.uint16)[sane, 0], expect[sane])
+    eng.set_split_threshold(2048)
     # bin-sharded layout: per-rank partial maxima, element-wise max == unsharded result
     for world in (2, 3, 8):
         acc = np.zeros(n, dtype=np.uint16)
