@@ -35,9 +35,9 @@ dev = torch.device("cuda:0")
 FACTORS = [float(x) for x in args.factors.split(",")]
 
 
-def k1_ms(eng, seqs, offs, lens, n, L, mc, ref):
-    for it in range(4):
-        if it == 1:
+def k1_ms(eng, seqs, offs, lens, n, L, mc, ref, warm=1):
+    for it in range(3 + warm):
+        if it == warm:
             eng.kernel_time()
         eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), n, L, d_maxcount=mc.data_ptr())
     torch.cuda.synchronize()
@@ -68,7 +68,7 @@ for point in args.points.split(","):
     eng = capi.Engine(0, [d], [])
     eng.set_timing(True)
     plan = eng.plan(0, N, L)
-    t_rule = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    t_rule = k1_ms(eng, seqs, offs, lens, N, L, mc, ref, warm=4)  # (the first measurement of a point: clocks and code objects warm first)
     eng.set_phased(0, 0, 0, 0, 0)  # the plain kernel
     t_plain = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
     eng.set_phased(0, 0, 0, 0, 1)  # the both-strands round of the phased kernel without a clock (one- and two-word blocks, small wide tables)
@@ -90,6 +90,11 @@ for point in args.points.split(","):
             if not eng.plan(0, N, L)["phased"]:
                 continue  # (a block width the phased form does not serve)
             sweep[(lg2, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    # the rule once more at the end (a 5 ms kernel measured first read up to 10 % high against the same setting inside the sweep)
+    eng.set_phase_slices(0, 32)
+    eng.set_phased()
+    assert eng.plan(0, N, L)["phase_window_ticks"] == plan["phase_window_ticks"] and eng.plan(0, N, L)["phased"] == plan["phased"]
+    t_rule = min(t_rule, k1_ms(eng, seqs, offs, lens, N, L, mc, ref))
     eng.destroy()
     d.free()
     # The best a window RULE can aim for is a point whose neighbours are good too: two-word and wide blocks show narrow dips between

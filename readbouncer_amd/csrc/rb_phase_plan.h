@@ -141,7 +141,8 @@ constexpr PhaseRule kPhaseRules[] = {
      {}, {}, 12.0, true,
      {constant(400), constant(400), constant(400), constant(500)}, 0},
     {"wide, four tiles (three-word build)", PhaseShape::Wide3FourTiles, 2, 238.0,
-     {{0.75, 3_MiB}, {0.0, kNever}}, 48_MiB,       // 4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB; 200 bp reads, 13 MiB: 10.2 in
+     {{0.75, 3_MiB}, {0.55, 12_MiB}, {0.0, kNever}}, 48_MiB,   // 4 MiB table: 7.4 ms without a clock, 6.3 in two slices of 2 MiB; 150 bp reads pay on
+                                                   // larger tables only (16 MiB: 9.4 against 10.3 ms plain, r04 wide-grid guard run); 200 bp reads, 13 MiB: 10.2 in
                                                    // four slices of 4 MiB against 13.0 plain and 12.0 in slices of 2 MiB (r04 guard run: the switch scales)
      {}, {}, 14.0, true,
      {constant(500), constant(500), constant(500), steps(4, 850, 8, 600, 500)}, 0},   // (five waves per SIMD: longer windows, session 53)
