@@ -631,7 +631,7 @@ def run_pool(ctx, name, steps=3):
         # never raises: on a multi-GPU node the other ranks are waiting for this rank on the rendezvous store, and the first run on
         # such a node is the first time the peer copies and the pool on distinct devices execute at all
         try:
-            result = measure()
+            result = pool_child(ctx, steps)["pool_" + name] if pool_in_child(ctx) else measure()
         except Exception as ex:  # noqa: BLE001
             result = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300]), "value": 0.0, "n_gpus": world,
                       "config": {"workload": "one-process pool leg (%s)" % name}, "parity": None, "roofline": None, "cpu_baseline": None}
@@ -642,6 +642,57 @@ def run_pool(ctx, name, steps=3):
     ctx._pool_legs = getattr(ctx, "_pool_legs", 0) + 1
     ctx.wait_for_rank0("pool_%s_%d" % (name, ctx._pool_legs))
     return result
+
+
+def pool_in_child(ctx):
+    """On a node with several GPUs the one-process legs run in a CHILD of rank 0: the pool over distinct devices and the
+    device-to-device copies have never executed on the boxes this was developed on (one GPU each), and a fault or a hang there
+    must cost the line two sub-legs, not the headline.  RB_BENCH_POOL_CHILD=1 forces the child on a one-GPU box (tests)."""
+    if os.environ.get("RB_BENCH_POOL_CHILD") is not None:
+        return os.environ["RB_BENCH_POOL_CHILD"] == "1"
+    return ctx.world > 1 and not ctx.same_gpu
+
+
+def pool_child(ctx, steps, timeout_s=900):
+    """rank 0: `bench.py --pool` as a child process over every GPU of the job (its own HIP contexts, its own filters, no
+    process group), once per run; returns {"pool_c3": leg, "pool_c4": leg, "xgmi_preflight": record}.  Reports, never raises."""
+    import subprocess
+    if getattr(ctx, "_pool_child", None) is not None:
+        return ctx._pool_child
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "RB_BENCH_SELF_LAUNCHED", "RB_BENCH_BACKEND", "RB_BENCH_SAME_GPU", "RB_BENCH_FORCE_GROUP")}
+    env["RB_BENCH_POOL_CHILD"] = "0"
+    env["RB_BENCH_POOL_PREFLIGHT"] = "1"
+    if "RB_BENCH_POOL_DEVICES" not in env:
+        env["RB_BENCH_POOL_DEVICES"] = ",".join(str(d) for d in (range(ctx.world) if (ctx.world > 1 and not ctx.same_gpu) else [ctx.dev_index]))
+    cmd = [sys.executable, os.path.abspath(__file__), "--pool", "--steps", str(steps)]
+    t0 = time.time()
+
+    def failed(why):
+        leg = {"error": why, "value": 0.0, "n_gpus": ctx.world, "config": {"workload": "one-process pool leg (child of rank 0)"},
+               "parity": None, "roofline": None, "cpu_baseline": None}
+        return {"pool_c3": dict(leg), "pool_c4": dict(leg), "xgmi_preflight": {"ran": False, "error": why}}
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            out = failed("child exit code %d, no line; stderr tail: %s" % (p.returncode, p.stderr.strip()[-300:]))
+        else:
+            head = json.loads(lines[-1])
+            c4 = (head.pop("other_configs", None) or {}).get("pool_c4")
+            pre = head.pop("xgmi_preflight", {"ran": False, "why": "the child did not report one"})
+            for leg in (head, c4):
+                if isinstance(leg, dict):
+                    leg["in_child_process"] = True
+                    leg["child_seconds"] = time.time() - t0
+            out = {"pool_c3": head, "pool_c4": c4, "xgmi_preflight": pre}
+    except subprocess.TimeoutExpired:
+        out = failed("child killed after %d s" % timeout_s)
+    except Exception as ex:  # noqa: BLE001
+        out = failed("%s: %s" % (type(ex).__name__, str(ex)[:300]))
+    ctx._pool_child = out
+    return out
 
 
 def replay(ctx, live_leg=True):
@@ -964,6 +1015,8 @@ def main():
         r4 = run_pool(ctx, "c4", steps=max(1, min(args.steps, 5)))
         if rank == 0:
             result["other_configs"] = {"pool_c4": r4}
+            if os.environ.get("RB_BENCH_POOL_PREFLIGHT") == "1":  # (set by pool_child: this process is rank 0's child)
+                result["xgmi_preflight"] = xgmi_preflight(ctx)
         extras = False
     elif args.workload == "c5":
         result = replay(ctx)
@@ -974,7 +1027,9 @@ def main():
         if os.environ.get("RB_BENCH_NO_PREFLIGHT") == "1":
             pre = {"ran": False, "why": "RB_BENCH_NO_PREFLIGHT=1"}
         else:
-            pre = xgmi_preflight(ctx) if (rank == 0 and extras) else {"ran": False, "why": "default run on rank 0 only"}
+            pre = {"ran": False, "why": "default run on rank 0 only"}
+            if rank == 0 and extras:
+                pre = {"ran": False, "why": "in the child process of the pool legs (filled in below)"} if pool_in_child(ctx) else xgmi_preflight(ctx)
         result = run_throughput(ctx, name, n_reads=args.reads, read_len=args.read_len, latency=True, bin_sharded=bin_sharded)
         infos = rank_diagnostics(ctx, time.time() - t_start)
         if rank == 0:
@@ -1015,6 +1070,8 @@ def main():
                 others[lname] = r
         if rank == 0:
             result["other_configs"] = others
+            if getattr(ctx, "_pool_child", None) is not None and "ranks" in result:
+                result["ranks"]["xgmi_preflight"] = ctx._pool_child["xgmi_preflight"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

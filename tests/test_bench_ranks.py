@@ -194,3 +194,40 @@ def test_pool_leg_two_workers_on_one_gpu():
         per = leg["pool"]["per_device"]
         assert len(per) == 2 and all(x["reads"] > 0 and x["calls"] >= 2 and 0 < x["busy_share"] <= 1.05 for x in per)
         assert leg["pool"]["replication_seconds"] >= 0 and leg["pool"]["replicated_bytes_per_device"] >= (8 << 30)
+
+
+@pytest.mark.gpu
+def test_pool_legs_in_a_child_of_rank0():
+    """On a node with several GPUs rank 0 runs the one-process legs (and the device-to-device pre-flight) in a CHILD process, so
+    that a fault in code that has never met distinct devices costs two sub-legs and not the headline.  Forced here on the one
+    GPU of the box (RB_BENCH_POOL_CHILD=1) over two workers: the legs come back through the child's line, marked as such."""
+    p, d = _run(["--gpus", "1", "--pool", "--steps", "2"],
+                {"RB_BENCH_POOL_CHILD": "1", "RB_BENCH_POOL_DEVICES": "0,0", "RB_BENCH_READS_DIVISOR": "10"}, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for leg in (d, d["other_configs"]["pool_c4"]):
+        assert leg["in_child_process"] is True and leg["child_seconds"] > 0
+        assert leg["config"]["devices"] == [0, 0] and leg["n_gpus"] == 2 and leg["value"] > 0
+        assert leg["parity"]["pool_outputs_equal_single_engine"] is True
+
+
+def test_pool_child_that_dies_costs_only_its_legs():
+    """no GPU here: the child of pool_child cannot even select a device and exits without a line -- the caller gets two legs
+    that say so (and a pre-flight record that says so), nothing is raised"""
+    sys.path.insert(0, ROOT)
+    try:
+        import bench
+    finally:
+        sys.path.pop(0)
+
+    class Ctx:
+        world, same_gpu, dev_index = 2, False, 0
+    out = bench.pool_child(Ctx(), steps=1, timeout_s=300)
+    if out["pool_c3"].get("error") is None:
+        pytest.skip("a GPU is present: the child ran")
+    assert set(out) == {"pool_c3", "pool_c4", "xgmi_preflight"}
+    for k in ("pool_c3", "pool_c4"):
+        assert out[k]["value"] == 0.0 and "child" in out[k]["error"]
+    assert out["xgmi_preflight"]["ran"] is False
+    assert bench.pool_in_child(Ctx()) is True
+    Ctx.world = 1
+    assert bench.pool_in_child(Ctx()) is False
