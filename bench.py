@@ -429,6 +429,41 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
             roof["read_peak_probe"] = probe
             if probe.get("GBps"):
                 roof["frac_of_measured_read_peak"] = achieved / probe["GBps"]
+        # Narrow filters (blocks of less than a cache line, tables of a few L2 sizes) are bound by REQUESTS, not bytes: every lookup is
+        # one request to an XCD's L2, and every miss one 128-byte line request to the fabric.  Their roofline is
+        #   t >= hits / (L2-resident line rate) + misses / (fabric line rate),
+        # both rates measured now with the no-compute probe on random single lines (a 4 MiB table = L2 resident; a scratch table
+        # of the kernel's table size, corrected for the L2's share of it), hits and misses per read replayed from the counter
+        # passes of profiles/traffic.json (TCC_HIT / TCC_MISS = TCC_EA0_RDREQ).
+        tj_req = load_json("traffic.json").get("readme360" if (name == "readme" and read_len == 360) else name, {}) \
+            if (read_len == default_len or (name == "readme" and read_len == 360)) else {}
+        narrow = bool(plans) and all(pl.get("phased") or "merged" in pl.get("kernel", "") for pl in plans)
+        if narrow and tj_req.get("TCC_EA0_RDREQ") and tj_req.get("l2_hit_rate") is not None and not bin_sharded \
+                and not os.environ.get("RB_BENCH_NO_PROBE"):
+            try:
+                ktab = max(int(pl.get("table_bytes", 0)) for pl in plans)
+                scratch = capi.DeviceIBF.create(ctx.dev_index, 256, 3, 13, 256 * max(1 << 17, ktab // 32))
+                scratch.fill_synth(7)
+                torch.cuda.synchronize()
+                l2_bytes = 4 << 20
+                r_hit = max(scratch.probe_read_peak(128, 0, 24, l2_bytes, 60.0)[0] for _ in range(2)) / 128.0
+                r_full = max(scratch.probe_read_peak(128, 0, 24, 0, 100.0)[0] for _ in range(2)) / 128.0
+                scratch.free()
+                share = min(1.0, l2_bytes / float(ktab))
+                r_miss = (1.0 - share) / max(1e-9, 1.0 / r_full - share / r_hit) if share < 1.0 else r_full
+                miss_pr = tj_req["TCC_EA0_RDREQ"] / tj_req["reads_per_launch"]
+                hr = tj_req["l2_hit_rate"]
+                hit_pr = miss_pr * hr / max(1e-9, 1.0 - hr)
+                model_ms = n_reads * (hit_pr / r_hit + miss_pr / r_miss) / 1e6  # (rates in G lines/s)
+                roof["request_roofline"] = {
+                    "bound": "L2 requests + fabric line requests", "l2_resident_Glines_per_s": r_hit, "fabric_Glines_per_s": r_miss,
+                    "probe_table_bytes": ktab, "probe_full_table_Glines_per_s": r_full,
+                    "l2_requests_per_read": hit_pr + miss_pr, "l2_hits_per_read": hit_pr, "fabric_lines_per_read": miss_pr,
+                    "model_ms_per_launch": model_ms, "frac": model_ms / (avg_kernel_s * 1e3),
+                    "source": "rates: rb_dibf_probe_read_peak with 128-byte rows, this run (4 MiB table; a scratch table of the kernel's "
+                              "table size, corrected for the L2's share); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
+            except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
+                roof["request_roofline"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
         if table_bytes < (256 << 20) * 4:
             roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
