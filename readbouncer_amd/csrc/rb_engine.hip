@@ -12,8 +12,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
+#include <shared_mutex>
 
 #include "rb_device.h"
 #include "rb_phase_plan.h"
@@ -95,19 +97,71 @@ struct PinnedBuf {
 // padded to 8: one 64-byte gather), and ONE lookup per (k-mer, hash function) serves every member -- the path is bound by
 // requests, so a read costs 1 428 requests instead of 5 712 on the reference's README shape.  The copy belongs to the engine
 // (the filters are borrowed); it is rebuilt when a member's bits have changed since it was made.
+//
+// The copy itself (MergedTable) is shared by the engines of a process: engines that were given the same filters in the same order
+// on one device -- the reference's N classification threads, one engine each (adaptive_sampling.hpp:745-751) -- gather from ONE
+// merged table.  With a copy per engine, K engines on a GPU put K x 40 MB tables through the 4 MiB L2s at once and the
+// clock-phased slices of one evicted those of the others (README shape, four engines: 0.78 x the rate of one).  A registry of
+// weak references hands out the table; a per-device reader/writer lock keeps a call's "is the copy fresh? -> enqueue the kernel"
+// (shared) apart from "make the copy again" (exclusive, after hipDeviceSynchronize: kernels of other engines may be reading it).
+struct MergedTable {
+    int device = 0;
+    std::vector<const rb_dibf *> key_filters;  // the members, in the order their bins sit in a merged block
+    std::vector<uint32_t> key_bit_begin;
+    uint64_t *d_words = nullptr;
+    uint64_t stride = 0, width = 0, n_blocks = 0;
+    IbfDev dev{};
+    std::vector<uint64_t> versions;  // rb_dibf::version of each member when the copy was made
+    ~MergedTable()
+    {
+        if (!d_words) return;
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        (void)hipSetDevice(device);
+        (void)hipFree(d_words);
+        if (have) (void)hipSetDevice(cur);
+    }
+};
+constexpr int kMergedLockDevices = 64;
+static std::shared_mutex &merged_rw(int device)
+{
+    static std::shared_mutex locks[kMergedLockDevices];
+    return locks[(unsigned)device % kMergedLockDevices];
+}
+static std::shared_ptr<MergedTable> merged_table_for(int device, const std::vector<const rb_dibf *> &filters,
+                                                     const std::vector<uint32_t> &bit_begin, uint64_t width)
+{
+    static std::mutex mu;
+    static std::vector<std::weak_ptr<MergedTable>> known;
+    std::lock_guard<std::mutex> lock(mu);
+    std::shared_ptr<MergedTable> found;
+    size_t keep = 0;
+    for (size_t i = 0; i < known.size(); ++i) {
+        std::shared_ptr<MergedTable> t = known[i].lock();
+        if (!t) continue;  // its last engine is gone
+        known[keep++] = known[i];
+        if (!found && t->device == device && t->width == width && t->key_filters == filters && t->key_bit_begin == bit_begin) found = t;
+    }
+    known.resize(keep);
+    if (found) return found;
+    std::shared_ptr<MergedTable> t(new (std::nothrow) MergedTable());
+    if (!t) return t;
+    t->device = device;
+    t->key_filters = filters;
+    t->key_bit_begin = bit_begin;
+    t->width = width;
+    known.push_back(t);
+    return t;
+}
+
 struct MergedGroup {
     std::vector<uint32_t> members;  // filter indices, engine order
     std::vector<uint32_t> bit_begin;  // per member: its first bin in a merged block (multiples of 64 unless `packed`)
     bool packed = false;            // members sit bit to bit: fewer word columns per block (README shape: 243 bins in four words, not five)
-    uint64_t *d_words = nullptr;
+    std::shared_ptr<MergedTable> tab;  // the copy (shared with every engine that merges the same filters the same way)
     uint64_t stride = 0, width = 0, n_blocks = 0;  // width: word columns of a merged block as it is laid out (packed or not)
-    IbfDev dev{};
-    MergeMap map{};
-    std::vector<uint64_t> versions;  // rb_dibf::version of each member when the copy was made
-    ~MergedGroup()
-    {
-        if (d_words) (void)hipFree(d_words);
-    }
+    IbfDev dev{};                   // = tab->dev once the copy exists
+    MergeMap map{};                 // this engine's view: where each member's maximum goes
 };
 
 struct rb_engine {
@@ -1308,42 +1362,67 @@ static void plan_merged(rb_engine *e)
 // the merged copy of a group, made (or made again after a member changed) on `st`.  kMergeNoMemory: the device has no room
 // for the copy -- the caller dissolves the group and its members are served one by one as before.
 static constexpr int kMergeNoMemory = -1000;
+static bool merged_table_fresh(const rb_engine *e, const MergedGroup *g)
+{
+    const MergedTable *t = g->tab.get();
+    if (!t || !t->d_words || t->versions.size() != g->members.size() || g->dev.words != t->d_words) return false;
+    for (size_t i = 0; i < g->members.size(); ++i)
+        if (t->versions[i] != e->filters[g->members[i]]->version.load()) return false;
+    return true;
+}
+
+// caller holds merged_rw(e->device) EXCLUSIVELY: no call of any engine on this device is between its freshness check and its launch
 static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
 {
-    bool fresh = g->d_words != nullptr && g->versions.size() == g->members.size();
-    for (size_t i = 0; fresh && i < g->members.size(); ++i) fresh = g->versions[i] == e->filters[g->members[i]]->version.load();
-    if (fresh) return RB_OK;
-    if (!g->d_words) {
-        g->stride = hbm_stride(g->width);
-        if (hipMalloc((void **)&g->d_words, (g->n_blocks * g->stride + 8) * 8) != hipSuccess) {
-            (void)hipGetLastError();
-            g->d_words = nullptr;
-            return kMergeNoMemory;
-        }
-    } else {
-        RB_HIP(hipDeviceSynchronize());  // made again: a kernel of an earlier call (on any stream) may still read the old copy
+    if (!g->tab) {
+        std::vector<const rb_dibf *> key;
+        for (uint32_t m : g->members) key.push_back(e->filters[m]);
+        g->tab = merged_table_for(e->device, key, g->bit_begin, g->width);
+        if (!g->tab) return kMergeNoMemory;
     }
-    RB_HIP(hipMemsetAsync(g->d_words, 0, (g->n_blocks * g->stride + 8) * 8, st));
-    g->versions.assign(g->members.size(), 0);
+    MergedTable *t = g->tab.get();
+    // this engine's view of the block layout
     g->map = MergeMap{};
     g->map.n = (uint32_t)g->members.size();
     g->map.width = (uint32_t)g->width;
     for (size_t i = 0; i < g->members.size(); ++i) {
-        rb_dibf *f = e->filters[g->members[i]];
-        g->versions[i] = f->version.load();
-        RB_HIP(launch_merge_bits(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, (uint32_t)f->geo.n_bins, g->d_words,
-                                 (uint32_t)g->stride, g->bit_begin[i], g->n_blocks, st));
         g->map.bit_begin[i] = g->bit_begin[i];
-        g->map.bit_end[i] = g->bit_begin[i] + (uint32_t)f->geo.n_bins;
+        g->map.bit_end[i] = g->bit_begin[i] + (uint32_t)e->filters[g->members[i]]->geo.n_bins;
         g->map.out_offset[i] = g->members[i];
     }
-    rb_ibf_info geo = e->filters[g->members[0]]->geo;  // noOfBlocks, k, h of the members
-    geo.bin_width = g->width;
-    geo.n_bins = g->width * 64;
-    int rc = make_dev_desc(geo, g->d_words, g->stride, &g->dev);
-    if (rc != RB_OK) return rc;
-    // made once per engine (and again when a member changed): wait here, so that calls on other streams find it complete
-    RB_HIP(hipStreamSynchronize(st));
+    bool fresh = t->d_words != nullptr && t->versions.size() == g->members.size();
+    for (size_t i = 0; fresh && i < g->members.size(); ++i) fresh = t->versions[i] == e->filters[g->members[i]]->version.load();
+    if (!fresh) {
+        if (!t->d_words) {
+            t->stride = hbm_stride(g->width);
+            t->n_blocks = g->n_blocks;
+            if (hipMalloc((void **)&t->d_words, (t->n_blocks * t->stride + 8) * 8) != hipSuccess) {
+                (void)hipGetLastError();
+                t->d_words = nullptr;
+                g->tab.reset();
+                return kMergeNoMemory;
+            }
+        } else {
+            RB_HIP(hipDeviceSynchronize());  // made again: a kernel of an earlier call (of any engine, on any stream) may still read the old copy
+        }
+        RB_HIP(hipMemsetAsync(t->d_words, 0, (t->n_blocks * t->stride + 8) * 8, st));
+        t->versions.assign(g->members.size(), 0);
+        for (size_t i = 0; i < g->members.size(); ++i) {
+            rb_dibf *f = e->filters[g->members[i]];
+            t->versions[i] = f->version.load();
+            RB_HIP(launch_merge_bits(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, (uint32_t)f->geo.n_bins, t->d_words,
+                                     (uint32_t)t->stride, g->bit_begin[i], t->n_blocks, st));
+        }
+        rb_ibf_info geo = e->filters[g->members[0]]->geo;  // noOfBlocks, k, h of the members
+        geo.bin_width = g->width;
+        geo.n_bins = g->width * 64;
+        int rc = make_dev_desc(geo, t->d_words, t->stride, &t->dev);
+        if (rc != RB_OK) return rc;
+        // made once (and again when a member changed): wait here, so that calls on other streams and of other engines find it complete
+        RB_HIP(hipStreamSynchronize(st));
+    }
+    g->stride = t->stride;
+    g->dev = t->dev;
     return RB_OK;
 }
 
@@ -1416,7 +1495,21 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         for (size_t gi = 0; gi < e->merged.size(); ++gi) {
             MergedGroup *g = e->merged[gi];
             if (g->members.empty()) continue;  // dissolved
-            if ((rc = ensure_merged_table(e, g, st)) == kMergeNoMemory) {
+            // shared: from "the copy is fresh" to "the kernel that reads it is queued"; a stale (or missing) copy is made under the
+            // exclusive lock, after which the check is repeated (bounded: a filter that is inserted into without pause does not
+            // stall its readers, they go on with the copy of the moment)
+            std::shared_lock<std::shared_mutex> reading(merged_rw(e->device));
+            rc = RB_OK;
+            for (int attempt = 0; attempt < 4 && !merged_table_fresh(e, g); ++attempt) {
+                reading.unlock();
+                {
+                    std::unique_lock<std::shared_mutex> writing(merged_rw(e->device));
+                    rc = ensure_merged_table(e, g, st);
+                }
+                reading.lock();
+                if (rc != RB_OK) break;
+            }
+            if (rc == kMergeNoMemory || (rc == RB_OK && !g->tab)) {
                 for (uint32_t m : g->members) e->merged_of[m] = -1;
                 g->members.clear();
                 continue;

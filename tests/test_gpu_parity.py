@@ -1351,3 +1351,76 @@ def test_c_abi_refuses_null_buffers_behind_valid_handles():
     r = subprocess.run([sys.executable, "-c", HANDLE_SWEEP], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "CALLED" in r.stdout
+
+
+def test_engines_of_one_device_share_the_merged_copy():
+    """The reference's N classification threads (adaptive_sampling.hpp:745-751) are N engines over the same filters: they gather from
+    ONE merged table (a registry hands the copy out; K copies of a 40 MB table evicted each other's slices from the L2s), an
+    insert into a member is followed by every engine, and an engine that merges the same filters in ANOTHER order has its own."""
+    import threading
+    import torch
+    rng = np.random.default_rng(4242)
+    ref = H.random_dna(rng, 40000)
+    n_blocks = 1_000_003  # 4 words x 8 B x 1 M blocks = 32 MB per merged copy
+    filters, views, keep = [], [], []
+
+    def view_all():
+        views.clear()
+        keep.clear()
+        for d in filters:
+            h = d.download()
+            keep.append(h)
+            views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+
+    for i, bins in enumerate((122, 43, 29, 49)):
+        W = (bins + 63) // 64
+        d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks)
+        d.add_sequence(ref[i * 6000:i * 6000 + 9000], 400)
+        filters.append(d)
+    view_all()
+    reads = make_reads(rng, ref, 2600, lo=20, hi=250, err=0.06)
+    buf, offs, lens = H.pack_reads(reads)
+    exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    copy_bytes = (n_blocks * 4 + 8) * 8
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    engines = [capi.Engine(0, filters[:1], filters[1:]) for _ in range(4)]
+    for e in engines:
+        assert e.merge_info() == (1, 4, copy_bytes)
+        assert np.array_equal(e.classify(buf, offs, lens)[0], exp)
+    used = free0 - torch.cuda.mem_get_info(0)[0]
+    assert copy_bytes <= used < 3 * copy_bytes, (used, copy_bytes)  # one copy (+ the engines' small staging buffers), not four
+    # the same filters merged in another order: another block layout, another copy
+    other = capi.Engine(0, filters[1:2], [filters[0]] + filters[2:])
+    assert np.array_equal(other.classify(buf, offs, lens)[0], exp[:, [1, 0, 2, 3]])
+    used2 = free0 - torch.cuda.mem_get_info(0)[0]
+    assert used2 - used >= copy_bytes - (4 << 20), (used, used2)
+    # an insert into a member while the engines classify on threads of their own: every engine ends on the new bits
+    errors = []
+
+    def worker(e):
+        try:
+            for _ in range(12):
+                e.classify(buf, offs, lens)
+        except Exception as ex:  # noqa: BLE001
+            errors.append(repr(ex))
+    threads = [threading.Thread(target=worker, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    filters[2].add_sequence(ref[30000:38000], 300)
+    for t in threads:
+        t.join()
+    assert errors == []
+    view_all()
+    exp2 = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    assert not np.array_equal(exp, exp2)
+    for e in engines:
+        assert np.array_equal(e.classify(buf, offs, lens)[0], exp2)
+    assert np.array_equal(other.classify(buf, offs, lens)[0], exp2[:, [1, 0, 2, 3]])
+    # the copy goes with its last engine
+    for e in engines + [other]:
+        e.destroy()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info(0)[0] < copy_bytes // 2
+    for d in filters:
+        d.free()
