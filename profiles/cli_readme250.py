@@ -104,15 +104,21 @@ def run(args, tag):
 probe = "/tmp/rb_pcw_probe"  # (/dev/shm is mounted noexec on the GPU boxes)
 if subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "profiles", "pagecache_write_probe.cpp"), "-o", probe]).returncode == 0:
     print(subprocess.run([probe, work, "2700000000"], capture_output=True, text=True).stdout.strip(), flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "classifiers":  # how many classifier threads: alternating, three rounds
+    for i in range(3):
+        for c in (4, 5, 6):
+            run(["--classify-threads", str(c)], "%d classifiers (round %d)" % (c, i + 1))
+    subprocess.run(["rm", "-rf", work])
+    sys.exit(0)
 if len(sys.argv) > 3 and sys.argv[3] == "quick":  # a long file, the defaults only: how the fixed costs of a run amortise
     for i in range(4):
-        run([], "defaults (6 parsers, 6 classifiers, 32 MB segments)")
+        run([], "defaults (6 parsers, 4 classifiers, 32 MB segments)")
     run(["--classify-threads", "4"], "4 classifiers")
     run(["--ingest-threads", "1", "--classify-threads", "1", "--batch-reads", "1000000"], "serial: 1 parser 1 classifier")
     subprocess.run(["rm", "-rf", work])
     sys.exit(0)
 run([], "warm-up (defaults)")
-run([], "defaults (6 parsers, 6 classifiers, 32 MB segments)")
+run([], "defaults (6 parsers, 4 classifiers, 32 MB segments)")
 run([], "defaults")
 run([], "defaults")
 for ingest, cls, seg, batch in ((6, 4, 32, 65536), (8, 6, 32, 65536), (4, 6, 32, 65536), (6, 6, 16, 32768), (6, 6, 64, 65536), (6, 8, 32, 65536), (6, 2, 32, 65536)):

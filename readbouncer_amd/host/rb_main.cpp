@@ -216,8 +216,11 @@ struct IngestOptions
     unsigned threads = 6;        // parser threads (one does ~3 GB/s of 250 bp FASTQ records)
     unsigned classify_threads = 0;  // threads running the chunk loop on the GPU and formatting their segment's output (one engine
                                     // each); 0 = [IBF] threads when the TOML sets it above 1 (the reference's meaning of that key:
-                                    // classification threads, adaptive_sampling.hpp:745), else 6 (profiles/r04/cli_throughput_sweep.txt:
-                                    // 4 leave the GPU idle while they format, 8 only queue on the output files' inode locks)
+                                    // classification threads, adaptive_sampling.hpp:745), else 4: since the engines of a device share
+                                    // the merged copy of their filters the GPU side of a segment is short, and what a fifth and sixth
+                                    // thread add is contention among the formatters (profiles/r04/cli_classifier_threads_*.txt, README
+                                    // shape, M reads/s in-process with 4 / 5 / 6 threads: 23.8 / 21.9 / 21.2 on 16 M reads, 29.6 / 31.6 /
+                                    // 28.0 on 64 M)
     bool calibrate = false;      // --calibrate: every classifier thread's engine fits the windows of its clock-phased gathers to this device first
                                  // (rb_engine_calibrate, one engine after the other: ~30 ms each; pays on long runs over narrow filters)
     bool mmap_output = false;    // --mmap-output: the classifier threads write the outputs through shared mappings of the files instead of
@@ -505,7 +508,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
             }
         };
         unsigned n_classifiers = opt.classify_threads ? opt.classify_threads
-                                                      : (config.IBF_Parsed.threads > 1 ? (unsigned)config.IBF_Parsed.threads : 6u);
+                                                      : (config.IBF_Parsed.threads > 1 ? (unsigned)config.IBF_Parsed.threads : 4u);
         {
             // (a multi-device pool spreads every call over its devices itself; two callers keep it fed while one formats)
             if (multi) n_classifiers = std::min(n_classifiers, 2u);
