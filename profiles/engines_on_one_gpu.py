@@ -33,6 +33,7 @@ ap.add_argument("--forms", default="device,host")
 ap.add_argument("--batch", type=int, default=65536)
 ap.add_argument("--batches", type=int, default=24)
 ap.add_argument("--read-len", type=int, default=0)
+ap.add_argument("--host-slice-mib", type=float, default=0.0, help="host form: rb_engine_set_host_slice_bytes (0: the engine's default)")
 args = ap.parse_args()
 
 import torch  # noqa: E402  (device memory for the resident form)
@@ -70,6 +71,8 @@ def run(name, form, K, expect):
         e = capi.Engine(0, d, t)
         if name == "readme_unmerged":
             e.set_merge(0)
+        if args.host_slice_mib:
+            e.set_host_slice_bytes(int(args.host_slice_mib * (1 << 20)))
         engines.append(e)
         # every thread has the same reads (seed 99): outputs must equal the K = 1 run whatever ran beside them
         t_seq, t_off, t_len = synth.make_reads_device(99, n, L, ref, dev)
