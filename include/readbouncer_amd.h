@@ -378,7 +378,9 @@ RB_API int rb_engine_set_revcomp_of_n(rb_engine *e, uint32_t ordinal);
  * follows changes of its members (rb_dibf_insert ...).  Results are identical. */
 RB_API int rb_engine_set_merge(rb_engine *e, int mode);
 /* What the engine has merged (or will, at its next large batch): the number of merged tables, the filters they serve and the HBM
- * bytes of the copies, which the engine owns beside the members.  A copy larger than 16 GiB (RB_MERGE_MAX_BYTES) is not made,
+ * bytes of the copies, which live beside the members and are SHARED by every engine of the process that merges the same filters in
+ * the same order on the same device (N threads with an engine each -- adaptive_sampling.hpp:745-751 -- gather from one copy; it
+ * is freed with its last engine).  A copy larger than 16 GiB (RB_MERGE_MAX_BYTES) is not made,
  * and a group whose copy the device has no room for dissolves at its first call: its members are then served one by one.
  * Any out pointer may be NULL. */
 RB_API int rb_engine_merge_info(rb_engine *e, uint32_t *n_tables, uint32_t *n_filters, uint64_t *copy_bytes);
