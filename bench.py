@@ -188,7 +188,8 @@ def host_wait_for_rank0(dist, rank, tag):
         if rank == 0:
             store.set("rb_bench_" + tag, "1")
         else:
-            store.wait(["rb_bench_" + tag])
+            import datetime
+            store.wait(["rb_bench_" + tag], datetime.timedelta(seconds=1500))  # (longer than any leg rank 0 runs alone, child included)
         return True
     except Exception:  # noqa: BLE001  (no store to be had: the caller's collective does the waiting)
         return False
@@ -688,7 +689,7 @@ def pool_in_child(ctx):
     return ctx.world > 1 and not ctx.same_gpu
 
 
-def pool_child(ctx, steps, timeout_s=900):
+def pool_child(ctx, steps, timeout_s=600):
     """rank 0: `bench.py --pool` as a child process over every GPU of the job (its own HIP contexts, its own filters, no
     process group), once per run; returns {"pool_c3": leg, "pool_c4": leg, "xgmi_preflight": record}.  Reports, never raises."""
     import subprocess
