@@ -432,10 +432,13 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 roof["frac_of_measured_read_peak"] = achieved / probe["GBps"]
         # Narrow filters (blocks of less than a cache line, tables of a few L2 sizes) are bound by REQUESTS, not bytes: every lookup is
         # one request to an XCD's L2, and every miss one 128-byte line request to the fabric.  Their roofline is
-        #   t >= hits / (L2-resident line rate) + misses / (fabric line rate),
-        # both rates measured now with the no-compute probe on random single lines (a 4 MiB table = L2 resident; a scratch table
-        # of the kernel's table size, corrected for the L2's share of it), hits and misses per read replayed from the counter
-        # passes of profiles/traffic.json (TCC_HIT / TCC_MISS = TCC_EA0_RDREQ).
+        #   t >= max( misses / (fabric line rate),  (hits + misses) / (L2 request rate) ),
+        # a true lower bound: the no-compute probe on random single lines (profiles/r04/line_rate_probe*.txt) shows the fabric
+        # serving ~57-61 G lines/s whatever share of the requests hits the L2, hits riding along for free until the L2's own
+        # ~250 G requests/s (an ADDITIVE model -- hits / L2 rate + misses / fabric rate -- overstates the time: a 64 MiB one-word
+        # table ran 18 % faster than it allows).  Both rates are measured now (a 4 MiB table = L2 resident; a scratch table of the
+        # kernel's table size, taking the L2's share of it as hits); hits and misses per read are replayed from the counter passes
+        # of profiles/traffic.json (TCC_HIT / TCC_MISS = TCC_EA0_RDREQ).
         tj_req = load_json("traffic.json").get("readme360" if (name == "readme" and read_len == 360) else name, {}) \
             if (read_len == default_len or (name == "readme" and read_len == 360)) else {}
         narrow = bool(plans) and all(pl.get("phased") or "merged" in pl.get("kernel", "") for pl in plans)
@@ -447,22 +450,30 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 scratch.fill_synth(7)
                 torch.cuda.synchronize()
                 l2_bytes = 4 << 20
-                r_hit = max(scratch.probe_read_peak(128, 0, 24, l2_bytes, 60.0)[0] for _ in range(2)) / 128.0
+                r_l2 = max(scratch.probe_read_peak(128, 0, 24, l2_bytes, 60.0)[0] for _ in range(2)) / 128.0
                 r_full = max(scratch.probe_read_peak(128, 0, 24, 0, 100.0)[0] for _ in range(2)) / 128.0
                 scratch.free()
                 share = min(1.0, l2_bytes / float(ktab))
-                r_miss = (1.0 - share) / max(1e-9, 1.0 / r_full - share / r_hit) if share < 1.0 else r_full
+                r_fabric = (1.0 - share) * r_full if share < 1.0 else r_full  # the probe's misses per second on a table of this size
                 miss_pr = tj_req["TCC_EA0_RDREQ"] / tj_req["reads_per_launch"]
                 hr = tj_req["l2_hit_rate"]
                 hit_pr = miss_pr * hr / max(1e-9, 1.0 - hr)
-                model_ms = n_reads * (hit_pr / r_hit + miss_pr / r_miss) / 1e6  # (rates in G lines/s)
+                fabric_ms = n_reads * miss_pr / r_fabric / 1e6  # (rates in G lines/s)
+                l2_ms = n_reads * (hit_pr + miss_pr) / r_l2 / 1e6
+                model_ms = max(fabric_ms, l2_ms)
                 roof["request_roofline"] = {
-                    "bound": "L2 requests + fabric line requests", "l2_resident_Glines_per_s": r_hit, "fabric_Glines_per_s": r_miss,
+                    "bound": "fabric line requests" if fabric_ms >= l2_ms else "L2 requests",
+                    "l2_Grequests_per_s": r_l2, "fabric_Glines_per_s": r_fabric,
                     "probe_table_bytes": ktab, "probe_full_table_Glines_per_s": r_full,
                     "l2_requests_per_read": hit_pr + miss_pr, "l2_hits_per_read": hit_pr, "fabric_lines_per_read": miss_pr,
-                    "model_ms_per_launch": model_ms, "frac": model_ms / (avg_kernel_s * 1e3),
+                    "fabric_ms_per_launch": fabric_ms, "l2_ms_per_launch": l2_ms, "model_ms_per_launch": model_ms,
+                    "frac": model_ms / (avg_kernel_s * 1e3),
+                    # where the clock-phased kernels really are: a window starts on a cold slice (fabric bound) and ends on a warm one
+                    # (L2 bound), and the two parts do not overlap -- the kernel time is close to the SUM of the two terms
+                    "frac_of_sum_of_terms": (fabric_ms + l2_ms) / (avg_kernel_s * 1e3),
+                    "achieved_fabric_Glines_per_s": n_reads * miss_pr / avg_kernel_s / 1e9,
                     "source": "rates: rb_dibf_probe_read_peak with 128-byte rows, this run (4 MiB table; a scratch table of the kernel's "
-                              "table size, corrected for the L2's share); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
+                              "table size, its misses = the share beyond the L2); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
             except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
                 roof["request_roofline"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
