@@ -469,8 +469,8 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                     "fabric_ms_per_launch": fabric_ms, "l2_ms_per_launch": l2_ms, "model_ms_per_launch": model_ms,
                     "frac": model_ms / (avg_kernel_s * 1e3),
                     # where the clock-phased kernels really are: a window starts on a cold slice (fabric bound) and ends on a warm one
-                    # (L2 bound), and the two parts do not overlap -- the kernel time is close to the SUM of the two terms
-                    "frac_of_sum_of_terms": (fabric_ms + l2_ms) / (avg_kernel_s * 1e3),
+                    # (L2 bound), and the two parts overlap little -- the kernel time is within 10 % of the SUM of the two terms
+                    "sum_of_terms_over_kernel_ms": (fabric_ms + l2_ms) / (avg_kernel_s * 1e3),
                     "achieved_fabric_Glines_per_s": n_reads * miss_pr / avg_kernel_s / 1e9,
                     "source": "rates: rb_dibf_probe_read_peak with 128-byte rows, this run (4 MiB table; a scratch table of the kernel's "
                               "table size, its misses = the share beyond the L2); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
