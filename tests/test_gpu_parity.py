@@ -1361,7 +1361,7 @@ def test_engines_of_one_device_share_the_merged_copy():
     import torch
     rng = np.random.default_rng(4242)
     ref = H.random_dna(rng, 40000)
-    n_blocks = 1_000_003  # 4 words x 8 B x 1 M blocks = 32 MB per merged copy
+    n_blocks = 4_000_037  # 4 words x 8 B x 4 M blocks = 128 MB per merged copy: far above what four engines allocate for themselves
     filters, views, keep = [], [], []
 
     def view_all():
@@ -1389,12 +1389,12 @@ def test_engines_of_one_device_share_the_merged_copy():
         assert e.merge_info() == (1, 4, copy_bytes)
         assert np.array_equal(e.classify(buf, offs, lens)[0], exp)
     used = free0 - torch.cuda.mem_get_info(0)[0]
-    assert copy_bytes <= used < 3 * copy_bytes, (used, copy_bytes)  # one copy (+ the engines' small staging buffers), not four
+    assert copy_bytes <= used < 2 * copy_bytes, (used, copy_bytes)  # one copy (+ the engines' small staging buffers), not four
     # the same filters merged in another order: another block layout, another copy
     other = capi.Engine(0, filters[1:2], [filters[0]] + filters[2:])
     assert np.array_equal(other.classify(buf, offs, lens)[0], exp[:, [1, 0, 2, 3]])
     used2 = free0 - torch.cuda.mem_get_info(0)[0]
-    assert used2 - used >= copy_bytes - (4 << 20), (used, used2)
+    assert used2 - used >= copy_bytes - (8 << 20), (used, used2)
     # an insert into a member while the engines classify on threads of their own: every engine ends on the new bits
     errors = []
 
