@@ -386,8 +386,8 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         # fabric-side traffic of one launch: NOT measured in this run -- rocprofv3 --pmc passes of an earlier run of the
         # same workload (profiles/collect_pmc.sh), kept in profiles/traffic.json and replayed here per read
         traffic, traffic_source = None, None
-        tj = load_json("traffic.json").get(name, {})
-        if tj.get("hbm_bytes_per_read") and not bin_sharded and read_len == default_len:
+        tj = load_json("traffic.json").get("readme360" if (name == "readme" and read_len == 360) else name, {})
+        if tj.get("hbm_bytes_per_read") and not bin_sharded and (read_len == default_len or (name == "readme" and read_len == 360)):
             traffic = tj["hbm_bytes_per_read"] * n_reads
             traffic_source = "replayed: profiles/traffic.json (%s), per read x reads per launch" % tj.get("source", "rocprofv3 --pmc, separate passes")
         decisions = t_dec.cpu().numpy()
