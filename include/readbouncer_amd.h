@@ -437,6 +437,9 @@ typedef struct rb_plan_info {
     char phase_shape_name[64];
     uint32_t phase_slice_log2, phase_slices, phase_window_ticks;  /* window length in effect, in 10 ns ticks */
     uint32_t phase_rule_ticks;   /* what the planner's table alone gives (differs after rb_engine_calibrate) */
+    uint32_t reserved0;
+    uint64_t phase_slice_bytes;  /* slice length in effect: 2^phase_slice_log2, or -- four-word one-lane builds -- the equal-length slices
+                                  * the table is cut into instead (fewer and up to 1.19 x longer; rb_phase_plan.h, phase_equal_slices) */
 } rb_plan_info;
 RB_API int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads, uint32_t max_len, rb_plan_info *out);
 /* Fits the window lengths of the clock-phased gathers to THIS device: the planner's table was measured on one box, and clocks,

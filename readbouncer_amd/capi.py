@@ -30,7 +30,7 @@ class PlanInfo(C.Structure):
                 ("column_slices", C.c_uint32), ("counter_planes", C.c_uint32), ("nontemporal", C.c_uint32), ("split_waves", C.c_uint32),
                 ("phased", C.c_uint32), ("phase_shape", C.c_uint32), ("phase_shape_name", C.c_char * 64),
                 ("phase_slice_log2", C.c_uint32), ("phase_slices", C.c_uint32), ("phase_window_ticks", C.c_uint32),
-                ("phase_rule_ticks", C.c_uint32)]
+                ("phase_rule_ticks", C.c_uint32), ("reserved0", C.c_uint32), ("phase_slice_bytes", C.c_uint64)]
 
 
 class IbfCompare(C.Structure):

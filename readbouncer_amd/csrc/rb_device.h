@@ -40,7 +40,7 @@ struct ReadSrc {
 // n_slices runs of 2^shift blocks, and window number (wall clock * inv_ticks) >> 32 tells the whole chip which slice to
 // gather from.  n_slices == 0: off.
 struct PhaseCfg {
-    uint32_t shift;      // log2 blocks per slice
+    uint32_t shift;      // log2 blocks per slice; with bit 31 set the low bits are blocks per slice, any number (stride-4 one-lane builds)
     uint32_t n_slices;   // ceil(n_blocks / 2^shift), <= 32 (the engine plans <= 8)
     uint32_t inv_ticks;  // floor(2^32 / window length in 10 ns ticks)
     uint32_t skew;       // added to the window number: 0, or this wave's XCD number when xcd_skew is set (experiment)
@@ -113,6 +113,7 @@ struct CountLaunch {
     int phase_shape;              // engine bookkeeping (rbplan::PhaseShape of the planner's row for this launch; the kernels do not read it)
     uint32_t phase_slice_log2, phase_ticks;  // ... the slice size and window length in effect (10 ns ticks), for rb_engine_plan
     uint32_t phase_rule_ticks;               // ... and what the planner's table alone would give (rb_engine_calibrate may have replaced it)
+    uint64_t phase_slice_bytes;              // ... and the slice length in effect (2^phase_slice_log2, or the equal-length slices of the four-word builds)
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)

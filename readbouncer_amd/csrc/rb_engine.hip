@@ -194,6 +194,7 @@ struct rb_engine {
     // rb_engine_set_phase_slices (RB_PHASE_MAX_SLICES, RB_PHASE_SLICE_LOG2 for whole processes): tests and experiments
     uint32_t phase_max_slices = 32;   // slices a table is cut into (<= 32: a wave keeps a bit per slice)
     uint32_t phase_slice_log2 = 0;    // slices of 2^n bytes instead of the rule of phase_slice_log2(); 1-5: as small as phase_max_slices allows
+    uint32_t phase_n_slices = 0;      // RB_PHASE_N_SLICES: that many equal-length slices for the four-word one-lane builds (0: phase_equal_slices())
     uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
     // rb_engine_calibrate: window lengths measured on this device that replace the planner's for a (table, kernel shape, slice size)
     struct PhaseOverride {
@@ -723,6 +724,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     if (const char *v = std::getenv("RB_PHASE_SLICE_LOG2")) {
         if (std::atoi(v) >= 1 && std::atoi(v) <= 26) { e->phase_slice_log2 = (uint32_t)std::atoi(v); note("RB_PHASE_SLICE_LOG2", v); }
     }
+    if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
     if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
     if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
     rb::set_warning(accepted.empty() ? std::string() : "rb_engine_create: environment overrides in effect: " + accepted);
@@ -1096,9 +1098,20 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint32_t sh = 0;
             while (slice_log2 >= 6 && (f->stride * 8) << (sh + 1) <= (1ull << slice_log2)) ++sh;  // (< 6: as small as max_slices allows)
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > e->phase_max_slices) ++sh;
-            const uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
+            uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
+            // the four-word one-lane builds: slices of equal length, fewer than the 4 MiB ones (rb_phase_plan.h, phase_equal_slices)
+            uint64_t blocks_per_slice = 0;
+            if (!e->phase_slice_log2 && f->stride == 4 && a.lg == 2) {
+                uint32_t want = phase_equal_slices(shape, slice_log2, table_bytes);
+                if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
+                if (want >= 1 && want <= e->phase_max_slices && want < n_sl) {
+                    blocks_per_slice = (f->geo.n_blocks + want - 1) / want;
+                    n_sl = (uint32_t)((f->geo.n_blocks + blocks_per_slice - 1) / blocks_per_slice);
+                }
+            }
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
-                                               : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
+                             : blocks_per_slice ? phase_equal_slices_ticks(shape, a.lg, n_sl, kmers)
+                                                : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
             a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             if (!e->phase_explicit)  // a window measured on this device for exactly this table, shape and slice size (rb_engine_calibrate)
                 for (const rb_engine::PhaseOverride &o : e->phase_overrides)
@@ -1107,10 +1120,11 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase_slice_log2 = slice_log2;
             a.phase_ticks = (uint32_t)ticks;
             ticks = std::max<uint64_t>(2, ticks * e->wall_clock_khz / 100000);  // 10 ns units -> ticks of this device's clock (>= 2: 2^32 / ticks must fit 32 bits)
-            a.phase.shift = sh;
+            a.phase.shift = blocks_per_slice ? (0x80000000u | (uint32_t)blocks_per_slice) : sh;  // bit 31: the low bits are blocks per slice, any number
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
             a.phase.xcd_skew = e->phase_xcd_skew;
+            a.phase_slice_bytes = blocks_per_slice ? blocks_per_slice * f->stride * 8 : (f->stride * 8) << sh;
         } else if ((a.lg == 0 || (shape != PhaseShape::General && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
                     ((shape == PhaseShape::WideFourTiles || shape == PhaseShape::Wide3FourTiles) && phase_fill(shape, kmers) >= 0.8 &&
                      table_bytes < phase_shape_min_bytes(shape, a.lg, 1.0))) && e->short_read_kernel) {
@@ -1709,6 +1723,7 @@ extern "C" int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads,
         if (a.phase.inv_ticks) {  // clock-phased (one slice and no clock: the both-strands round of that kernel without waiting)
             out->phased = 1;
             out->phase_slice_log2 = a.phase_slice_log2;
+            out->phase_slice_bytes = a.phase_slice_bytes;
             out->phase_window_ticks = a.phase_ticks;
             out->phase_rule_ticks = a.phase_rule_ticks;
         }

@@ -462,8 +462,10 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
         done |= 1u << cur;
-        const uint32_t start = cur << slice_shift;
-        const uint32_t span = 1u << slice_shift;
+        // (EXPERIMENT: bit 31 of slice_shift = the low bits are a slice length in bytes, any multiple of the block size)
+        const bool any_len = (slice_shift >> 31) != 0;
+        const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << slice_shift;
+        const uint32_t start = any_len ? cur * span : cur << slice_shift;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             const uint32_t k = f.k;
             const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
             const uint64_t valid2 = col_bits_mask(nm.col_bits[2]), valid3 = col_bits_mask(nm.col_bits[3]);
-            const uint32_t slice_shift = min(31u, ph.shift + 5u);
+            const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 32u)) : min(31u, ph.shift + 5u);
             uint32_t c01f = 0, c23f = 0, c01r = 0, c23r = 0;  // lane b: counts of bins b | 64 + b << 16, and 128 + b | 192 + b << 16
 #pragma unroll 1
             for (uint32_t base = 0; base < (SHORT == 1 ? 1u : n); base += 64u * T2) {

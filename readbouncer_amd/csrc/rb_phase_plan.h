@@ -22,6 +22,7 @@
 //    `min_bytes` the phased form has nothing to win; blocks of five and more words gain nothing from phases at any size.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 
@@ -188,6 +189,23 @@ inline uint32_t phase_slice_log2(PhaseShape shape, int lg, uint64_t table_bytes,
     return mib < r.four_mib_from_mib * fill ? 21 : 22;
 }
 
+// Slices of EQUAL length, not of 2^n bytes, for the four-word one-lane builds when their rule asks for 4 MiB slices AND cutting the
+// table at 4 MiB is wasteful (at least two slices more than slices of up to 4.75 MiB need): the TA spends 16 cycles on every predicated
+// wave-level load whatever share of its lanes lies in the slice of the moment, and every slice means one more pass over all of a
+// wave's loads -- 74 % of that kernel's cycles at ten slices (profiles/r04/pmc_units_readme.txt).  README shape (37.7 MiB), M reads/s at
+// the best window: 250 bp 10 slices of 4 MiB (the last one 1.7 MiB) 59.5, 9 slices 63.1, 8 slices of 4.7 MiB 66.5, 7 slices 66.0,
+// 6 slices 63.7; 360 bp 37.6 / 40.6 / 43.4 / 43.8 / 43.2 (profiles/r04/slice_count_sweep.txt).  Where 4 MiB slices fill the table
+// exactly (28, 32 MiB) one slice less buys nothing: the window has to grow with the lookups per slice (its cliff sits near 4 100 / n
+// ticks at 250 bp), profiles/r04/equal_slices_check*.txt.  Returns the number of slices (0: keep the slices of 2^slice_log2 bytes).
+constexpr double kWideEqualSliceMiB = 4.75;
+inline uint32_t phase_equal_slices(PhaseShape shape, uint32_t slice_log2, uint64_t table_bytes)
+{
+    if (slice_log2 != 22 || (shape != PhaseShape::WideFourTiles && shape != PhaseShape::WideRounds)) return 0;
+    const uint32_t pow2 = (uint32_t)((table_bytes + (4_MiB - 1)) / 4_MiB);
+    const uint32_t n = (uint32_t)std::ceil((double)table_bytes / (kWideEqualSliceMiB * 1048576.0));
+    return n >= 2 && n + 2 <= pow2 ? n : 0;
+}
+
 inline uint64_t phase_window_ticks(PhaseShape shape, int lg, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers)
 {
     const PhaseRule &r = phase_rule(shape, lg);
@@ -208,6 +226,15 @@ inline uint64_t phase_window_ticks(PhaseShape shape, int lg, uint32_t slice_log2
     if (w.full_floor_n && n_slices <= w.full_floor_n) return (uint64_t)std::max(t, std::max(w.floor, w.full_floor_small * fill));
     return (uint64_t)std::max(t, w.floor);
 }
+
+// the window for such slices: the shape's rule for that many slices, and for the rounds of three tiles not below 3 360 / n ticks (eight
+// slices of 4.7 MiB, 360 bp: 360 ticks 31.9 ms, 400 ticks 23.0, 440 ticks 24.5 -- the rule's 400 would sit right on the cliff)
+inline uint64_t phase_equal_slices_ticks(PhaseShape shape, int lg, uint32_t n_slices, uint32_t kmers)
+{
+    const uint64_t rule = phase_window_ticks(shape, lg, 22, n_slices, kmers);
+    return shape == PhaseShape::WideRounds ? std::max<uint64_t>(rule, 3360u / std::max(n_slices, 1u)) : rule;
+}
+
 
 // from which table size on the phased form pays ...
 inline uint64_t phase_shape_min_bytes(PhaseShape shape, int lg, double fill)
