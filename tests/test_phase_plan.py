@@ -19,6 +19,40 @@ def test_phase_rules_match_the_golden_table(tmp_path):
         assert g.split("  (")[0] == e.split("  (")[0], (g, e)  # (the row names in brackets are commentary)
 
 
+def test_equal_length_slices_of_the_four_word_builds(tmp_path):
+    """phase_equal_slices (rb_phase_plan.h): the four-word one-lane builds get fewer, equal-length slices only where cutting the table
+    at 4 MiB is wasteful -- at least two slices more than slices of up to 4.75 MiB need; the points are the measured ones of
+    profiles/r04/equal_slices_check.txt (README table 37.73 MiB: 10 -> 8)"""
+    src = tmp_path / "eq.cpp"
+    src.write_text('''
+#include <cstdint>
+#include <cstdio>
+#include "%s"
+using namespace rbplan;
+int main() {
+    const double mib[] = {24, 28, 32, 34, 37.73, 38.5, 41.5, 44, 46, 48, 60, 100};
+    for (double m : mib) {
+        const uint64_t b = (uint64_t)(m * 1048576.0);
+        std::printf("%%.2f %%u %%u %%u %%u %%llu %%llu\\n", m, phase_equal_slices(PhaseShape::WideFourTiles, 22, b), phase_equal_slices(PhaseShape::WideRounds, 22, b),
+                    phase_equal_slices(PhaseShape::WideFourTiles, 21, b), phase_equal_slices(PhaseShape::FourTiles, 22, b),
+                    (unsigned long long)phase_equal_slices_ticks(PhaseShape::WideFourTiles, 2, 8, 238), (unsigned long long)phase_equal_slices_ticks(PhaseShape::WideRounds, 2, 8, 348));
+    }
+}
+''' % os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h"))
+    exe = str(tmp_path / "eq")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", str(src), "-o", exe])
+    rows = [l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()]
+    got = {float(r[0]): int(r[1]) for r in rows}
+    assert got[24] == got[28] == got[32] == got[34] == got[38.5] == got[44] == 0 and got[37.73] == 8 and got[41.5] == 9 and got[46] == 10
+    for r in rows:
+        m, n4, nr, n21, nft = float(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4])
+        assert n4 == nr and n21 == 0 and nft == 0  # the same for both four-word shapes; only with 4 MiB slices; no other shape
+        if n4:
+            pow2 = -(-int(m * 1048576) // (4 << 20))
+            assert n4 + 2 <= pow2 and m / n4 <= 4.75 + 1e-9
+        assert int(r[5]) == 500 and int(r[6]) == 420  # eight slices: the four-tile rule's 500 ticks; rounds of three tiles not below 3 360 / 8
+
+
 def test_every_shape_has_a_named_row():
     hdr = open(os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h")).read()
     for name in ("General", "FourTiles", "Rounds", "SixTiles", "WideRounds", "WideFourTiles", "Wide3FourTiles", "Wide3Rounds"):
