@@ -1101,8 +1101,8 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             // the four-word one-lane builds: slices of equal length, fewer than the 4 MiB ones (rb_phase_plan.h, phase_equal_slices)
             uint64_t blocks_per_slice = 0;
-            if (!e->phase_slice_log2 && f->stride == 4 && a.lg == 2) {
-                uint32_t want = phase_equal_slices(shape, slice_log2, table_bytes);
+            if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || e->phase_n_slices)) {
+                uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes) : 0;
                 if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
                 if (want >= 1 && want <= e->phase_max_slices && want < n_sl) {
                     blocks_per_slice = (f->geo.n_blocks + want - 1) / want;

@@ -372,8 +372,9 @@ __device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
         done |= 1u << cur;
-        const uint32_t start = cur << slice_shift;  // slice_shift == 31 goes with a single slice (cur == 0)
-        const uint32_t span = 1u << slice_shift;
+        const bool any_len = (slice_shift >> 31) != 0 && slice_shift != 0x80000000u;  // bit 31 + a length in bytes: slices of any length
+        const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << min(slice_shift, 31u);  // (slice_shift == 31: a single slice, cur == 0)
+        const uint32_t start = any_len ? cur * span : cur << min(slice_shift, 31u);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
@@ -417,8 +418,9 @@ __device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
         done |= 1u << cur;
-        const uint32_t start = cur << slice_shift;
-        const uint32_t span = 1u << slice_shift;
+        const bool any_len = (slice_shift >> 31) != 0;  // bit 31 + a length in bytes: slices of any length
+        const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << slice_shift;
+        const uint32_t start = any_len ? cur * span : cur << slice_shift;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
@@ -580,7 +582,8 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
                 // numbers plus 64-bit addresses would not leave room for three waves per SIMD
                 uint32_t bn[8][H];
                 const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
-                const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(S)));  // S (words per block) is a power of two here
+                const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * (uint32_t)(S * 8)))
+                                                              : min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(S)));  // S (words per block) is a power of two here
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int s = blk * 8 + u;
@@ -927,7 +930,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
             const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
-            const uint32_t slice_shift = min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
+            const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * (f.stride * 8u)))
+                                                          : min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
             uint32_t cf = 0, cr = 0;  // lane b: count of bin b, forward / reverse complement
             // the counts of a round are summed across the wave at once, so no counter planes are carried
 #pragma unroll 1
@@ -984,7 +988,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
             const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
-            const uint32_t slice_shift = min(31u, ph.shift + 4u);
+            const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 16u)) : min(31u, ph.shift + 4u);
             uint32_t cf = 0, cr = 0;  // lane b: counts of bins b (low half) and 64 + b (high half), forward / reverse complement
 #pragma unroll 1
             for (uint32_t base = 0; base < (SHORT == 2 ? n : 1u); base += kRound) {
