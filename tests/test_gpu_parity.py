@@ -1424,3 +1424,34 @@ def test_engines_of_one_device_share_the_merged_copy():
     assert free0 - torch.cuda.mem_get_info(0)[0] < copy_bytes // 2
     for d in filters:
         d.free()
+
+
+def test_equal_length_slices_through_the_planner():
+    """A four-word table that 4 MiB slices cut wastefully (37.7 MiB: ten slices, the last one 1.7 MiB) is walked in eight equal slices of
+    4.7 MiB (rb_phase_plan.h, phase_equal_slices): the plan says so, and the maxima equal the oracle's and those of the 4 MiB
+    slices, for the four-tile build (250 bp) and the rounds of three tiles (360 bp), with blocks at both ends of every slice in play."""
+    rng = np.random.default_rng(8088)
+    ref = H.random_dna(rng, 60000)
+    n_blocks = 1_236_269  # x 32 B = 37.73 MiB, the README shape's merged table
+    d = capi.DeviceIBF.create(0, 250, 3, 13, 256 * n_blocks)
+    d.fill_synth(21)
+    d.add_sequence(ref, 250)
+    o, _keep = oracle_view(d)
+    eng = capi.Engine(0, [d], [])
+    for L, shape in ((250, "wide, four tiles"), (360, "wide, rounds of three tiles")):
+        reads = make_reads(np.random.default_rng(L), ref, 4200, lo=L - 60, hi=L + 1, err=0.05)  # (>= 4096: the phased form of a table this size)
+        buf, offs, lens = H.pack_reads(reads)
+        exp = po.batch_raw_max(o, buf, offs, lens, 8)
+        pl = eng.plan(0, len(reads), L)
+        assert pl["phased"] == 1 and pl["phase_shape_name"].startswith(shape), pl
+        assert pl["phase_slices"] == 8 and pl["phase_slice_log2"] == 22, pl
+        assert pl["phase_slice_bytes"] == -(-n_blocks // 8) * 32 and pl["phase_slice_bytes"] & (pl["phase_slice_bytes"] - 1), pl
+        got = eng.classify(buf, offs, lens)[0][:, 0]
+        assert np.array_equal(got, exp)
+        eng.set_phase_slices(22, 32)  # the slices of 2^22 bytes they replace
+        p2 = eng.plan(0, len(reads), L)
+        assert p2["phase_slices"] == 10 and p2["phase_slice_bytes"] == 1 << 22
+        assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], exp)
+        eng.set_phase_slices()
+    eng.destroy()
+    d.free()
