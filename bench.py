@@ -417,7 +417,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 try:
                     pl = eng.plan(fi, n_reads, read_len)
                     plans.append({k: pl[k] for k in ("kernel", "table_bytes", "merged_members", "phased", "phase_shape_name", "phase_slice_log2",
-                                                     "phase_slices", "phase_window_ticks", "column_slices", "nontemporal") if pl[k] not in (0, "")})
+                                                     "phase_slices", "phase_slice_bytes", "phase_window_ticks", "column_slices", "nontemporal") if pl[k] not in (0, "")})
                 except Exception as ex:  # noqa: BLE001
                     plans.append({"error": str(ex)[:120]})
         forms = {pl.get("kernel", "?") for pl in plans} or {"ibf_count_max_kernel"}
