@@ -22,6 +22,7 @@ from readbouncer_amd import capi, synth  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--points", default="24:250,28:250,32:250,37.73:250,44:250,28:360,32:360,37.73:360,44:360,37.73:200,37.73:430")
 ap.add_argument("--reads", type=int, default=500_000)
+ap.add_argument("--bins", type=int, default=256, help="bins of the filter (129-192: the three-word builds, 193-256: the four-word builds)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 FACTORS = (0.8, 0.9, 1.0, 1.1, 1.25)
@@ -51,7 +52,7 @@ for point in args.points.split(","):
     seqs, offs, lens = reads[L]
     mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
     n_blocks = int(mib * (1 << 20) / 32) - 3
-    d = capi.DeviceIBF.create(0, 256, 3, 13, 256 * n_blocks)
+    d = capi.DeviceIBF.create(0, args.bins, 3, 13, 64 * ((args.bins + 63) // 64) * n_blocks)
     d.fill_synth(3)
     eng = capi.Engine(0, [d], [])
     eng.set_timing(True)
