@@ -189,7 +189,7 @@ inline uint32_t phase_slice_log2(PhaseShape shape, int lg, uint64_t table_bytes,
     return mib < r.four_mib_from_mib * fill ? 21 : 22;
 }
 
-// Slices of EQUAL length, not of 2^n bytes, for the four-word one-lane builds when their rule asks for 4 MiB slices AND cutting the
+// Slices of EQUAL length, not of 2^n bytes, for the three- and four-word one-lane builds when their rule asks for 4 MiB slices AND cutting the
 // table at 4 MiB is wasteful (at least two slices more than slices of up to 4.75 MiB need): the TA spends 16 cycles on every predicated
 // wave-level load whatever share of its lanes lies in the slice of the moment, and every slice means one more pass over all of a
 // wave's loads -- 74 % of that kernel's cycles at ten slices (profiles/r04/pmc_units_readme.txt).  README shape (37.7 MiB), M reads/s at
@@ -200,7 +200,7 @@ inline uint32_t phase_slice_log2(PhaseShape shape, int lg, uint64_t table_bytes,
 constexpr double kWideEqualSliceMiB = 4.75;
 inline uint32_t phase_equal_slices(PhaseShape shape, uint32_t slice_log2, uint64_t table_bytes)
 {
-    if (slice_log2 != 22 || (shape != PhaseShape::WideFourTiles && shape != PhaseShape::WideRounds)) return 0;
+    if (slice_log2 != 22 || !phase_shape_is_wide(shape)) return 0;  // (the four- and the three-word one-lane builds)
     const uint32_t pow2 = (uint32_t)((table_bytes + (4_MiB - 1)) / 4_MiB);
     const uint32_t n = (uint32_t)std::ceil((double)table_bytes / (kWideEqualSliceMiB * 1048576.0));
     return n >= 2 && n + 2 <= pow2 ? n : 0;
@@ -232,7 +232,12 @@ inline uint64_t phase_window_ticks(PhaseShape shape, int lg, uint32_t slice_log2
 inline uint64_t phase_equal_slices_ticks(PhaseShape shape, int lg, uint32_t n_slices, uint32_t kmers)
 {
     const uint64_t rule = phase_window_ticks(shape, lg, 22, n_slices, kmers);
-    return shape == PhaseShape::WideRounds ? std::max<uint64_t>(rule, 3360u / std::max(n_slices, 1u)) : rule;
+    const uint32_t n = std::max(n_slices, 1u);
+    // the three-word builds (five waves per SIMD: longer passes): 250 bp, 41.5 MiB in nine slices: 500 ticks 19.8 ms, 550 ticks 15.2;
+    // 360 bp, 37.7 MiB in eight slices: 382 ticks 27.3 ms, 425 ticks 23.1, 467 ticks 22.4 (profiles/r04/equal_slices_three_word_builds.txt)
+    const uint32_t floor_ticks = shape == PhaseShape::WideRounds ? 3360u / n : shape == PhaseShape::Wide3FourTiles ? 5200u / n
+                               : shape == PhaseShape::Wide3Rounds ? 3600u / n : 0u;
+    return std::max<uint64_t>(rule, floor_ticks);
 }
 
 

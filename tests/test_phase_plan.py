@@ -33,6 +33,8 @@ int main() {
     const double mib[] = {24, 28, 32, 34, 37.73, 38.5, 41.5, 44, 46, 48, 60, 100};
     for (double m : mib) {
         const uint64_t b = (uint64_t)(m * 1048576.0);
+        if (phase_equal_slices(PhaseShape::Wide3FourTiles, 22, b) != phase_equal_slices(PhaseShape::WideFourTiles, 22, b) ||
+            phase_equal_slices(PhaseShape::Wide3Rounds, 22, b) != phase_equal_slices(PhaseShape::WideRounds, 22, b)) return 1;  // the three-word builds: the same cut
         std::printf("%%.2f %%u %%u %%u %%u %%llu %%llu\\n", m, phase_equal_slices(PhaseShape::WideFourTiles, 22, b), phase_equal_slices(PhaseShape::WideRounds, 22, b),
                     phase_equal_slices(PhaseShape::WideFourTiles, 21, b), phase_equal_slices(PhaseShape::FourTiles, 22, b),
                     (unsigned long long)phase_equal_slices_ticks(PhaseShape::WideFourTiles, 2, 8, 238), (unsigned long long)phase_equal_slices_ticks(PhaseShape::WideRounds, 2, 8, 348));
@@ -51,6 +53,8 @@ int main() {
             pow2 = -(-int(m * 1048576) // (4 << 20))
             assert n4 + 2 <= pow2 and m / n4 <= 4.75 + 1e-9
         assert int(r[5]) == 500 and int(r[6]) == 420  # eight slices: the four-tile rule's 500 ticks; rounds of three tiles not below 3 360 / 8
+    hdr = open(os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h")).read()
+    assert "5200u / n" in hdr and "3600u / n" in hdr  # the three-word builds' window floors (profiles/r04/equal_slices_three_word_builds.txt)
 
 
 def test_every_shape_has_a_named_row():
