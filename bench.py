@@ -17,7 +17,11 @@ data-path collective); time = max over ranks, value = all reads / that time.  `p
 itself (fresh child processes, started before this process touches the GPU); under torchrun (WORLD_SIZE set) it is one of
 the ranks.
 
-Prints ONE JSON line with the driver contract fields plus "roofline" and "cpu_baseline".
+Prints ONE JSON line on stdout -- the contract fields plus "roofline", "cpu_baseline", "parity" and a one-row summary of every
+`other_configs` leg -- bounded to COMPACT_LIMIT bytes (compact_line); everything else (plans, probes, request bounds, pool
+statistics, per-rank device records, latency tables) goes to the sidecar file `bench_detail.json` beside this script (and
+into gpurun_out/ when that directory exists), or wherever RB_BENCH_DETAIL points.  A run that fails still ends in one
+parseable line with an "error" field and a non-zero exit code.
 The CPU oracle is used here only as the checker / cpu_baseline leg, never in the timed path.
 """
 import argparse
@@ -61,6 +65,191 @@ def host_cores():
     if quota:
         n = max(1, min(n, int(quota + 0.5)))
     return n
+
+
+COMPACT_LIMIT = 4096  # bytes of the final stdout line: the driver keeps an 8 KB tail of stdout and stderr together
+
+
+def _sig(x, digits=6):
+    """floats to `digits` significant digits (the line is for reading and for a parser with a small window)"""
+    if isinstance(x, bool) or x is None:
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None  # strict JSON: no NaN / Infinity tokens
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.floating,)):
+        return _sig(float(x), digits)
+    return x
+
+
+def _cut(text, n):
+    return text if not isinstance(text, str) or len(text) <= n else text[: n - 3] + "..."
+
+
+def leg_summary(r):
+    """one row of `other_configs` in the final line: value, HBM fraction, p99, parity -- nothing else"""
+    if not isinstance(r, dict):
+        return {"error": "no result"}
+    out = {}
+    if r.get("error"):
+        out["error"] = _cut(str(r["error"]), 120)
+    if r.get("value") is not None:
+        out["value"] = r["value"]
+    if r.get("ms_per_step") is not None:
+        out["ms_per_step"] = r["ms_per_step"]
+    roof = r.get("roofline") or {}
+    if roof.get("frac") is not None:
+        out["frac"] = roof["frac"]
+    if roof.get("frac_of_measured_read_peak") is not None:
+        out["frac_of_read_peak"] = roof["frac_of_measured_read_peak"]
+    rb = (roof.get("request_bound") or {}).get("request_bound_frac")
+    if rb is not None:
+        out["request_bound_frac"] = rb
+    lat = r.get("latency") or {}
+    if lat.get("p99_ms") is not None:
+        out["p99_ms"] = lat["p99_ms"]
+    live = r.get("live_step") or {}
+    if live.get("p99_ms") is not None:
+        out["live_p99_ms"] = live["p99_ms"]
+    cb = r.get("cpu_baseline") or {}
+    if cb.get("value") is not None:
+        out["cpu_reads_per_s"] = cb["value"]
+    par = r.get("parity")
+    if isinstance(par, dict):
+        if "decision_mismatches" in par:
+            out["parity_ok"] = not (par.get("decision_mismatches") or par.get("raw_max_mismatches"))
+            out["checked_reads"] = par.get("checked_reads")
+        elif "pool_outputs_equal_single_engine" in par:
+            out["parity_ok"] = bool(par["pool_outputs_equal_single_engine"]) and par.get("oracle_mismatches", 0) == 0
+            out["checked_reads"] = par.get("checked_reads")
+        elif "replayed_decisions_equal_one_batch" in par:
+            out["parity_ok"] = bool(par["replayed_decisions_equal_one_batch"])
+            out["checked_reads"] = par.get("checked_reads")
+    else:
+        out["parity_ok"] = None
+    return out
+
+
+def compact_line(result, detail_path=None):
+    """The driver-facing line: contract fields, roofline, cpu_baseline, parity and one summary row per other leg, never more than
+    COMPACT_LIMIT bytes.  Everything the full result carries beyond that is in the sidecar file."""
+    roof = result.get("roofline") or None
+    c = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = result.get("config") or {}
+    c["config"] = {"workload": _cut(cfg.get("workload", ""), 200)}
+    for k in ("reads_per_gpu_per_step", "reads_per_call", "read_len", "parallelism", "decisions", "decisions_sha1"):
+        if cfg.get(k) is not None:
+            c["config"][k] = _cut(cfg[k], 120)
+    if isinstance(roof, dict):
+        c["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        for k in ("kernel", "avg_kernel_ms", "algorithmic_bytes_per_read", "algorithmic_bytes_per_launch", "frac_of_measured_read_peak", "basis"):
+            if roof.get(k) is not None:
+                c["roofline"][k] = _cut(roof[k], 120)
+        if (roof.get("read_peak_probe") or {}).get("GBps"):
+            c["roofline"]["read_peak_probe_GBps"] = roof["read_peak_probe"]["GBps"]
+        if roof.get("traffic_source"):
+            c["roofline"]["traffic_source"] = _cut(roof["traffic_source"], 100)
+        rb = roof.get("request_bound") or {}
+        if rb.get("request_bound_frac") is not None:
+            c["roofline"]["request_bound_frac"] = rb["request_bound_frac"]
+    else:
+        c["roofline"] = None
+    cb = result.get("cpu_baseline")
+    c["cpu_baseline"] = ({k: _cut(cb.get(k), 160) for k in ("value", "unit", "cores", "kind", "sample")} if isinstance(cb, dict) else None)
+    par = result.get("parity")
+    c["parity"] = ({k: v for k, v in par.items() if k != "against"} if isinstance(par, dict) else None)
+    if isinstance(c["parity"], dict) and "error" in c["parity"]:
+        c["parity"]["error"] = _cut(c["parity"]["error"], 100)
+    lat = result.get("latency") or {}
+    if lat.get("p99_ms") is not None:  # (c5 as the headline)
+        c["latency"] = {k: lat[k] for k in ("p50_ms", "p99_ms", "p99.9_ms", "max_ms", "slo_met") if k in lat}
+    elif lat.get("by_batch"):
+        c["latency"] = {"host_to_host_p99_ms_by_batch": {k: v.get("p99_ms") for k, v in lat["by_batch"].items()}}
+    ranks = result.get("ranks") or {}
+    if ranks:
+        c["ranks"] = {k: ranks.get(k) for k in ("backend", "rccl_ranks", "self_launched", "per_rank_reads_per_s") if k in ranks}
+        if ranks.get("devices"):
+            c["ranks"]["devices"] = [d.get("device") if isinstance(d, dict) else None for d in ranks["devices"]]
+    for k in ("engine", "bin_sharded_reduce_ok", "test_reads_divisor", "error", "bench_seconds"):
+        if result.get(k) is not None:
+            c[k] = _cut(result[k], 300)
+    others = result.get("other_configs")
+    if isinstance(others, dict):
+        c["other_configs"] = {k: leg_summary(v) for k, v in others.items()}
+    if detail_path:
+        c["detail"] = detail_path
+    c = _sig(c)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    # a hard bound, whatever a future leg adds: shed the optional parts in order of how little the record needs them
+    for shed in ("ranks.devices", "latency", "config.decisions", "other_configs.checked_reads", "other_configs.min", "cpu_baseline.sample",
+                 "other_configs", "ranks"):
+        if len(line) <= COMPACT_LIMIT:
+            break
+        if shed == "ranks.devices":
+            (c.get("ranks") or {}).pop("devices", None)
+        elif shed == "config.decisions":
+            c["config"].pop("decisions", None)
+        elif shed == "other_configs.checked_reads":
+            for v in (c.get("other_configs") or {}).values():
+                v.pop("checked_reads", None)
+                v.pop("ms_per_step", None)
+        elif shed == "other_configs.min":
+            c["other_configs"] = {k: {kk: v[kk] for kk in ("value", "frac", "p99_ms", "parity_ok", "error") if kk in v}
+                                  for k, v in (c.get("other_configs") or {}).items()}
+        elif shed == "cpu_baseline.sample":
+            if isinstance(c.get("cpu_baseline"), dict):
+                c["cpu_baseline"]["sample"] = _cut(c["cpu_baseline"].get("sample"), 40)
+        else:
+            c.pop(shed, None)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    return line
+
+
+def detail_paths():
+    """where the full result goes: RB_BENCH_DETAIL if set (tests), else bench_detail.json beside this script and a copy under
+    gpurun_out/ when that scratch directory exists (gpurun merges it back)"""
+    env = os.environ.get("RB_BENCH_DETAIL")
+    if env:
+        return [env]
+    out = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        out.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    return out
+
+
+def emit(result):
+    """rank 0, once: the sidecar file(s) with everything, then the one bounded line on stdout"""
+    written = None
+    for path in detail_paths():
+        try:
+            tmp = path + ".tmp%d" % os.getpid()
+            with open(tmp, "w") as f:
+                json.dump(_sig(result, 9), f, allow_nan=False)
+                f.write("\n")
+            os.replace(tmp, path)
+            if written is None:
+                written = os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+        except Exception as ex:  # noqa: BLE001  (a read-only tree must not cost the line)
+            print("bench.py: could not write %s: %s" % (path, ex), file=sys.stderr)
+    sys.stdout.write(compact_line(result, written) + "\n")
+    sys.stdout.flush()
+
+
+def error_line(msg, world=1, args=None):
+    """a run that cannot finish still ends in ONE parseable line (value 0, the reason) -- the caller exits non-zero"""
+    r = {"metric": METRIC, "value": 0.0, "unit": "reads/s", "n_gpus": world, "steps": getattr(args, "steps", 0),
+         "warmup": getattr(args, "warmup", 0), "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+         "dtype": "u64", "data": "synthetic", "config": {"workload": "failed before a measurement"}, "roofline": None,
+         "cpu_baseline": None, "parity": None, "error": _cut(str(msg), 300)}
+    emit(r)
 
 
 def _free_port():
@@ -131,12 +320,17 @@ def launch_ranks(n):
             deadline = float("inf")
         time.sleep(0.2)
     reader.join(10)
-    for line in "".join(out0).splitlines():  # the contract is ONE JSON line on stdout; library chatter goes to stderr
+    lines = "".join(out0).splitlines()
+    for line in lines:  # the contract is ONE JSON line on stdout; library chatter goes to stderr
         (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     rc = 0
     for p in procs:
         rc = rc or (p.returncode or 0)
+    if not any(l.startswith("{") for l in lines):
+        # rank 0 never got to its line (it died, or a dead rank left it in a collective until it was terminated)
+        error_line("no line from rank 0; exit codes of the ranks: %s" % [p.returncode for p in procs], n)
+        rc = rc or 1
     sys.exit(rc if rc >= 0 else 1)
 
 
@@ -205,6 +399,7 @@ class Ctx:
         self.dev = torch.device("cuda", dev_index)
         self.red_dev = self.dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the collectives live
         self.filters = {}  # workload key -> (DeviceIBF, planted reference)
+        self.views = {}    # workload key -> (host image, oracle view of it)
         self.filter_setup_s = 0.0
 
     SEEDS = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60), "grch38_f100k": (8, 80),
@@ -221,6 +416,25 @@ class Ctx:
             self.torch.cuda.synchronize()
             self.filter_setup_s += time.time() - t
         return self.filters[key]
+
+    def oracle_view(self, key):
+        """the checker's view of a resident filter (rank 0's parity / cpu_baseline legs only): downloaded from HBM once per run and
+        kept while the filter is -- config 3's table is 8 GiB and four legs check against it"""
+        from oracle import pyoracle as po
+        if key not in self.views:
+            h = self.filter(key)[0].download()
+            self.views[key] = (h, po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"], h.words()))
+        return self.views[key][1]
+
+    def release(self, keys):
+        for k in keys:
+            self.views.pop(k, None)
+            f = self.filters.pop(k, None)
+            if f is not None:
+                try:
+                    f[0].free()
+                except Exception:  # noqa: BLE001
+                    pass
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -461,13 +675,15 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 fabric_ms = n_reads * miss_pr / r_fabric / 1e6  # (rates in G lines/s)
                 l2_ms = n_reads * (hit_pr + miss_pr) / r_l2 / 1e6
                 model_ms = max(fabric_ms, l2_ms)
-                roof["request_roofline"] = {
+                roof["request_bound"] = {
+                    "what": "lower bound on the kernel time from REQUEST rates (L2 requests, fabric line requests), not a byte fraction: "
+                            "request_bound_frac = bound / kernel time",
                     "bound": "fabric line requests" if fabric_ms >= l2_ms else "L2 requests",
                     "l2_Grequests_per_s": r_l2, "fabric_Glines_per_s": r_fabric,
                     "probe_table_bytes": ktab, "probe_full_table_Glines_per_s": r_full,
                     "l2_requests_per_read": hit_pr + miss_pr, "l2_hits_per_read": hit_pr, "fabric_lines_per_read": miss_pr,
                     "fabric_ms_per_launch": fabric_ms, "l2_ms_per_launch": l2_ms, "model_ms_per_launch": model_ms,
-                    "frac": model_ms / (avg_kernel_s * 1e3),
+                    "request_bound_frac": model_ms / (avg_kernel_s * 1e3),
                     # where the clock-phased kernels really are: a window starts on a cold slice (fabric bound) and ends on a warm one
                     # (L2 bound), and the two parts overlap little -- the kernel time is within 10 % of the SUM of the two terms
                     "sum_of_terms_over_kernel_ms": (fabric_ms + l2_ms) / (avg_kernel_s * 1e3),
@@ -475,7 +691,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                     "source": "rates: rb_dibf_probe_read_peak with 128-byte rows, this run (4 MiB table; a scratch table of the kernel's "
                               "table size, its misses = the share beyond the L2); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
             except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
-                roof["request_roofline"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
+                roof["request_bound"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
         if table_bytes < (256 << 20) * 4:
             roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
@@ -508,13 +724,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
         buf = t_seq[: cap * read_len].cpu().numpy()
     if rank == 0 and not args.no_cpu_baseline and cpu_seconds > 0:
         from oracle import pyoracle as po
-        keep = []
-        views = []
-        for f in filters:
-            h = f.download()
-            keep.append(h)
-            views.append(po.OracleIBF.wrap(h.info["n_bins"], h.info["n_hash"], h.info["kmer_size"], h.info["n_bits"],
-                                           h.words()))
+        views = [ctx.oracle_view(k) for k in dep_keys + tgt_keys]
         od, ot = views[:len(deplete)], views[len(deplete):]
         cores = host_cores()
         cap = len(buf) // read_len
@@ -558,7 +768,7 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                                        "the timed batch"}
         if mism or max_mism:
             result["parity"]["error"] = "GPU decisions or raw maxima differ from the oracle"
-        del views, keep
+        del views
     elif rank == 0:
         result["cpu_baseline"] = None
 
@@ -637,11 +847,14 @@ def run_pool(ctx, name, steps=3):
                                blocks["dec"].ptr, blocks["st"].ptr)
         call()  # engines' staging buffers, threshold tables, code objects on every device
         pool.stats(reset=True)
+        pool.set_timing(True)  # hipEvent pairs around every engine's count kernels (rb_engine_set_timing per worker)
         t0 = time.perf_counter()
         for _ in range(steps):
             call()
         wall = time.perf_counter() - t0
         st = pool.stats()
+        ktimes = pool.kernel_time()
+        pool.set_timing(False)
         # parity: the pool's outputs for the first reads against ONE engine on this rank's device (same resident filters)
         m = min(n, 200_000)
         eng = capi.Engine(ctx.dev_index, deplete, target)
@@ -655,6 +868,37 @@ def run_pool(ctx, name, steps=3):
         mc2, _, dec2, _ = eng.classify(blocks["seq"].array[lo * L:], np.arange(n - lo, dtype=np.uint64) * np.uint64(L), blocks["len"].array[lo:].copy())
         eng.destroy()
         equal = equal and bool(np.array_equal(mc2.reshape(-1), blocks["max"].array[lo * nf:]) and np.array_equal(dec2, blocks["dec"].array[lo:]))
+        parity = {"checked_reads": int(m + n - lo), "pool_outputs_equal_single_engine": equal}
+        # ... and against the ORACLE: the head of the first device's slice and the tail of the last one's
+        if not ctx.args.no_cpu_baseline:
+            from oracle import pyoracle as po
+            views = [ctx.oracle_view(k) for k in dep_keys + tgt_keys]
+            od, ot = views[:len(deplete)], views[len(deplete):]
+            cores = host_cores()
+            q = min(n, 1024)
+            mism = 0
+            for a, b in ((0, q), (n - q, n)):
+                sub = np.ascontiguousarray(blocks["seq"].array[a * L: b * L])
+                so, sl = np.arange(b - a, dtype=np.uint64) * np.uint64(L), np.full(b - a, L, dtype=np.uint32)
+                cdec, _ = po.batch_check_unblock(od, ot, sub, so, sl, n_threads=cores)
+                cmax = np.stack([po.batch_raw_max(v, sub, so, sl, cores) for v in views], axis=1)
+                mism += int((cdec != blocks["dec"].array[a:b]).sum())
+                mism += int((cmax.reshape(-1) != blocks["max"].array[a * nf: b * nf]).sum())
+            parity.update(oracle_checked_reads=2 * q, oracle_mismatches=mism,
+                          against="a single engine on the same filters (all outputs) AND the oracle's decisions + raw maxima on the "
+                                  "first and the last reads of the call")
+        geo = [(f.info["n_bins"], f.info["kmer_size"], f.info["n_hash"]) for f in deplete + target]
+        bytes_per_read = synth.algorithmic_bytes_per_read(L, geo)
+        per_dev_gbs = [bytes_per_read * r / (ms / 1e3) / 1e9 if ms > 0 else None for (_, _, r, _), (ms, _) in zip(st, ktimes)]
+        have = [x for x in per_dev_gbs if x]
+        roof = None
+        if have:
+            achieved = float(np.mean(have))  # per GPU, like every other leg: the devices gather from their own replicas
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "ibf_count_max_kernel (per pool worker)", "algorithmic_bytes_per_read": bytes_per_read,
+                    "basis": "K1 hipEvent time of every worker's engine; mean over devices",
+                    "per_device_GBps": per_dev_gbs, "per_device_kernel_ms": [ms for ms, _ in ktimes],
+                    "per_device_launches": [int(c) for _, c in ktimes]}
         result = {"metric": METRIC, "value": n * steps / wall, "unit": "reads/s", "n_gpus": len(devices), "steps": steps, "warmup": 1,
                   "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                   "data": "synthetic",
@@ -664,8 +908,8 @@ def run_pool(ctx, name, steps=3):
                   "pool": {"create_seconds": create_s, "replication_seconds": pool.replication_seconds,
                            "replicated_bytes_per_device": int(sum(f.info["n_blocks"] * f.device_stride() * 8 for f in deplete + target)),
                            "per_device": [{"device": d, "busy_share": b / wall, "reads": int(r), "calls": int(c)} for d, b, r, c in st]},
-                  "parity": {"checked_reads": int(m + n - lo), "pool_outputs_equal_single_engine": equal},
-                  "roofline": None, "cpu_baseline": None}
+                  "parity": parity,
+                  "roofline": roof, "cpu_baseline": None}
         pool.destroy()
         for b in blocks.values():
             b.free()
@@ -720,13 +964,25 @@ def pool_child(ctx, steps, timeout_s=600):
         leg = {"error": why, "value": 0.0, "n_gpus": ctx.world, "config": {"workload": "one-process pool leg (child of rank 0)"},
                "parity": None, "roofline": None, "cpu_baseline": None}
         return {"pool_c3": dict(leg), "pool_c4": dict(leg), "xgmi_preflight": {"ran": False, "error": why}}
+    import tempfile
+    fd, side = tempfile.mkstemp(prefix="rb_pool_child_", suffix=".json")
+    os.close(fd)
+    os.unlink(side)
+    env["RB_BENCH_DETAIL"] = side  # the child's full result (its stdout line is the bounded summary)
     try:
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        if not lines:
+        head = None
+        if os.path.exists(side):
+            try:
+                head = json.load(open(side))
+            finally:
+                os.unlink(side)
+        if not lines or head is None:
             out = failed("child exit code %d, no line; stderr tail: %s" % (p.returncode, p.stderr.strip()[-300:]))
+        elif head.get("error") and not head.get("value"):
+            out = failed("child exit code %d: %s" % (p.returncode, head["error"]))
         else:
-            head = json.loads(lines[-1])
             c4 = (head.pop("other_configs", None) or {}).get("pool_c4")
             pre = head.pop("xgmi_preflight", {"ran": False, "why": "the child did not report one"})
             for leg in (head, c4):
@@ -933,6 +1189,19 @@ def xgmi_preflight(ctx):
         return {"ran": False, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
+FULL_LEGS = ("c3np2", "c4", "c5", "c2", "grch38_f100k", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4")
+# N > 1 (what a SCALE record carries, four runs back to back): the BASELINE configs that name several GPUs, config 3 at the
+# reference's own sizing, and the one-process pool legs; the narrow shapes and c2 are single-GPU parity / roofline legs
+MULTI_LEGS = ("c3np2", "c4", "c5", "pool_c3", "pool_c4")
+
+
+def default_leg_names(world):
+    if os.environ.get("RB_BENCH_LEGS"):  # e.g. RB_BENCH_LEGS=c4,c5 (any subset of FULL_LEGS, in that order)
+        want = [x.strip() for x in os.environ["RB_BENCH_LEGS"].split(",") if x.strip()]
+        return tuple(x for x in FULL_LEGS if x in want)
+    return FULL_LEGS if world == 1 else MULTI_LEGS
+
+
 def null_engine_run(args, torch, dist, world, rank, backend):
     """Control-flow test hook (RB_BENCH_ENGINE=none, set only by tests/): the rank flow of this script -- rendezvous,
     barriers, max-over-ranks timing, the per-rank gather, the all-gather + max of the bin-sharded layout, the headline +
@@ -999,7 +1268,7 @@ def null_engine_run(args, torch, dist, world, rank, backend):
     head = leg(args.workload or "c3", args.steps, args.bin_sharded)
     others = {}
     if not args.workload and not args.bin_sharded and not args.no_extras:
-        for name in ("c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4"):
+        for name in default_leg_names(world):
             others[name] = leg(name, 1, False)
     infos = [{"rank": rank, "device": None}]
     if dist is not None:
@@ -1011,7 +1280,7 @@ def null_engine_run(args, torch, dist, world, rank, backend):
                          "per_rank_reads_per_s": head["per_rank_reads_per_s"], "xgmi_preflight": {"ran": False, "why": "no engine"}}
         if others:
             head["other_configs"] = others
-        print(json.dumps(head))
+        emit(head)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -1088,32 +1357,45 @@ def main():
     if extras:
         # the other BASELINE configs, by all ranks, after the headline measurement; a failure is reported, never raised
         others = {}
-        legs = [# config 3 at the reference's own sizing (IBFBuild.cpp:404-413: BinSizeBits x 8256, a non-power-of-two block count --
-                # the Barrett modulus every reference-built filter takes): full steps, ONE launch of 10 M reads, like the headline
-                ("c3np2", lambda: run_throughput(ctx, "c3np2")),
-                ("c4", lambda: run_throughput(ctx, "c4", cpu_seconds=8.0)),
-                ("c5", lambda: replay(ctx)),
-                ("c2", lambda: run_throughput(ctx, "c2", cpu_seconds=5.0)),
-                ("readme", lambda: run_throughput(ctx, "readme", cpu_seconds=5.0)),
-                # the README filters at the north star's read length
-                ("readme_360bp", lambda: run_throughput(ctx, "readme", read_len=360, steps=min(args.steps, 5), warmup=1, cpu_seconds=0)),
-                # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
-                ("targets3", lambda: run_throughput(ctx, "targets3", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0)),
-                ("deplete_target", lambda: run_throughput(ctx, "deplete_target", steps=min(args.steps, 5), warmup=1, cpu_seconds=3.0)),
-                # one host process driving every GPU of the job through rb_pool (rank 0; the other ranks wait): what SCALE's per-rank
-                # numbers do not show
-                ("pool_c3", lambda: run_pool(ctx, "c3")),
-                ("pool_c4", lambda: run_pool(ctx, "c4"))]
-        for lname, fn in legs:
+        few = min(args.steps, 5)
+        table = {
+            # config 3 at the reference's own sizing (IBFBuild.cpp:404-413: BinSizeBits x 8256, a non-power-of-two block count --
+            # the Barrett modulus every reference-built filter takes): ONE launch of 10 M reads per step, like the headline
+            "c3np2": lambda: run_throughput(ctx, "c3np2", steps=few, warmup=1, cpu_seconds=6.0),
+            "c4": lambda: run_throughput(ctx, "c4", steps=min(args.steps, 10), warmup=2, cpu_seconds=8.0),
+            "c5": lambda: replay(ctx),
+            "c2": lambda: run_throughput(ctx, "c2", cpu_seconds=5.0),
+            # GRCh38 at the reference's DEFAULT fragment_size = 100 000 (configReader.cpp:238-243): ~31 000 bins, W = 485 words,
+            # 3.9 KB blocks, 4.8 GB -- the filter a ReadBouncer user builds without touching a setting
+            "grch38_f100k": lambda: run_throughput(ctx, "grch38_f100k", steps=min(args.steps, 3), warmup=1, cpu_seconds=5.0),
+            "readme": lambda: run_throughput(ctx, "readme", cpu_seconds=5.0),
+            # the README filters at the north star's read length
+            "readme_360bp": lambda: run_throughput(ctx, "readme", read_len=360, steps=few, warmup=1, cpu_seconds=3.0),
+            # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
+            "targets3": lambda: run_throughput(ctx, "targets3", steps=few, warmup=1, cpu_seconds=3.0),
+            "deplete_target": lambda: run_throughput(ctx, "deplete_target", steps=few, warmup=1, cpu_seconds=3.0),
+            # one host process driving every GPU of the job through rb_pool (rank 0; the other ranks wait): what SCALE's per-rank
+            # numbers do not show
+            "pool_c3": lambda: run_pool(ctx, "c3"),
+            "pool_c4": lambda: run_pool(ctx, "c4"),
+        }
+        # filters a later leg no longer needs are freed as the run goes (N ranks on one node hold N replicas of each)
+        last_use = {"c3np2": ["c3np2"], "c2": ["c2"], "grch38_f100k": ["grch38_f100k"],
+                    "deplete_target": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]}
+        names = default_leg_names(world)
+        for lname in names:
+            t_leg = time.time()
             try:
-                r = fn()
+                r = table[lname]()
             except Exception as ex:  # noqa: BLE001
                 if world > 1:
                     raise  # a rank that drops out of the collectives would hang the others: fail the whole job loudly
                 r = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            ctx.release(last_use.get(lname, []))
             if rank == 0:
                 if isinstance(r, dict):
                     r.pop("per_rank_reads_per_s", None)
+                    r["leg_seconds"] = round(time.time() - t_leg, 2)
                 others[lname] = r
         if rank == 0:
             result["other_configs"] = others
@@ -1125,10 +1407,18 @@ def main():
     if rank == 0:
         if TEST_DIVISOR > 1:
             result["test_reads_divisor"] = TEST_DIVISOR
-        print(json.dumps(result))
+        result["bench_seconds"] = round(time.time() - t_start, 1)
+        try:
+            result["hbm_peak_allocated_bytes"] = int(torch.cuda.max_memory_allocated(dev_index))  # torch's share only: reads, outputs
+            free_b, total_b = torch.cuda.mem_get_info(dev_index)
+            result["hbm_in_use_at_exit_bytes"] = int(total_b - free_b)
+        except Exception:  # noqa: BLE001
+            pass
+        emit(result)
+
         def differs(r):
             par = r.get("parity") if isinstance(r, dict) else None
-            return bool(par and (par.get("decision_mismatches") or par.get("raw_max_mismatches")))
+            return bool(par and (par.get("decision_mismatches") or par.get("raw_max_mismatches") or par.get("oracle_mismatches")))
         bad = differs(result)
         for r in (result.get("other_configs") or {}).values():
             bad |= differs(r)
@@ -1137,5 +1427,26 @@ def main():
             sys.exit(3)
 
 
+def guarded_main():
+    """main() with the promise of the header kept: whatever goes wrong, rank 0 (or the launcher) leaves ONE parseable line with
+    an "error" field on stdout and the exit code is non-zero -- never a hang, never a bare traceback as the last word"""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as ex:  # noqa: BLE001
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        if rank == 0:
+            try:
+                error_line("%s: %s" % (type(ex).__name__, ex), world)
+            except Exception:  # noqa: BLE001
+                pass
+        sys.stderr.flush()
+        os._exit(1)  # (not sys.exit: a rank stuck in a collective's teardown must not keep the job alive)
+
+
 if __name__ == "__main__":
-    main()
+    guarded_main()

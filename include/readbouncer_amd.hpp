@@ -337,6 +337,10 @@ public:
 };
 
 // ---- engines are cached per (deplete set, target set) -----------------------------------------
+// What the reverse strand holds for an N of the read, for every engine this process creates from now on (a recalled SeqAn fact,
+// readbouncer_amd.h: rb_engine_set_revcomp_of_n): 3 = T, the default; 4 = N.  Call it before the first classify.
+inline void set_revcomp_of_n(uint32_t ordinal) { throw_status(rb_set_default_revcomp_of_n(ordinal), "set_revcomp_of_n"); }
+
 namespace detail
 {
 // One engine per (calling thread, filter set).  Engines only borrow the filters (no copy in HBM) and own their streams

@@ -26,16 +26,16 @@ $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c4 -- pyth
 for w in c2 readme c1; do
   $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$w -- python3 $R/bench.py --workload $w --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_$w.log 2>&1
 done
-RB_MERGE=0 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_readme_phased -- python3 $R/bench.py --workload readme --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_readme_phased.log 2>&1
-RB_MERGE=0 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_readme360_phased -- python3 $R/bench.py --workload readme --read-len 360 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_readme360_phased.log 2>&1
+RB_TUNING_ENV=1 RB_MERGE=0 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_readme_phased -- python3 $R/bench.py --workload readme --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_readme_phased.log 2>&1
+RB_TUNING_ENV=1 RB_MERGE=0 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_readme360_phased -- python3 $R/bench.py --workload readme --read-len 360 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_readme360_phased.log 2>&1
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_readme360 -- python3 $R/bench.py --workload readme --read-len 360 --steps 5 --warmup 1 --no-cpu-baseline --no-latency > $OUT/stats_readme360.log 2>&1
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c5 -- python3 $R/bench.py --workload c5 --replay-seconds 1.0 > $OUT/stats_c5.log 2>&1
 # PMC passes (separate runs, counters only): c3 on the 10 M-read launch
 bash $R/profiles/collect_pmc.sh c3 10000000 $OUT/pmc_c3 > /dev/null 2>&1
 for w in c2 c4 readme c1; do bash $R/profiles/collect_pmc.sh $w 1000000 $OUT/pmc_$w > /dev/null 2>&1; done
 bash $R/profiles/collect_pmc.sh readme 1000000 $OUT/pmc_readme360 "--read-len 360" > /dev/null 2>&1
-RB_MERGE=0 bash $R/profiles/collect_pmc.sh readme 1000000 $OUT/pmc_readme_phased > /dev/null 2>&1
-RB_MERGE=0 bash $R/profiles/collect_pmc.sh readme 1000000 $OUT/pmc_readme360_phased "--read-len 360" > /dev/null 2>&1
+RB_TUNING_ENV=1 RB_MERGE=0 bash $R/profiles/collect_pmc.sh readme 1000000 $OUT/pmc_readme_phased > /dev/null 2>&1
+RB_TUNING_ENV=1 RB_MERGE=0 bash $R/profiles/collect_pmc.sh readme 1000000 $OUT/pmc_readme360_phased "--read-len 360" > /dev/null 2>&1
 for w in c2 c3 c4 c5 readme readme360 readme_phased readme360_phased c1; do f=$(find $OUT/stats_$w -name "*kernel_stats.csv" | head -1); echo "== $w"; python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):

@@ -107,6 +107,8 @@ SIGNATURES = {
     "rb_pool_size": (_sz, [_vp]),
     "rb_pool_set_min_split": (_int, [_vp, _sz]),
     "rb_pool_set_serialize": (_int, [_vp, _int]),
+    "rb_pool_set_timing": (_int, [_vp, _int]),
+    "rb_pool_kernel_time": (_int, [_vp, _sz, C.POINTER(_dbl), C.POINTER(_u64)]),
     "rb_pool_classify_batch": (_int, [_vp, _vp, _vp, _vp, _sz, _dbl, _dbl, _int, _vp, _vp, _vp, _vp]),
     "rb_live_create": (_int, [_vp, _dbl, _dbl, _u32, _pp]),
     "rb_live_destroy": (None, [_vp]),
@@ -119,6 +121,7 @@ SIGNATURES = {
                                        C.POINTER(_dbl)]),
     "rb_dibf_clone_to_ex": (_int, [_vp, _int, _pp, C.POINTER(_int), C.POINTER(_dbl)]),
     "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
+    "rb_set_default_revcomp_of_n": (_int, [_u32]),
     "rb_engine_set_merge": (_int, [_vp, _int]),
     "rb_engine_merge_info": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
@@ -559,6 +562,16 @@ class Pool:
         dev, busy, reads, calls = (C.c_int * n)(), (C.c_double * n)(), (C.c_uint64 * n)(), (C.c_uint64 * n)()
         _check(lib().rb_pool_get_stats(self.h, n, dev, busy, reads, calls, int(reset)), "rb_pool_get_stats")
         return [(dev[i], busy[i], reads[i], calls[i]) for i in range(n)]
+
+    def set_timing(self, on):
+        _check(lib().rb_pool_set_timing(self.h, int(on)), "rb_pool_set_timing")
+
+    def kernel_time(self):
+        """per worker: (summed K1 milliseconds since the last collection, bracketed launches) -- rb_engine_kernel_time of each engine"""
+        n = self.size()
+        ms, calls = (C.c_double * n)(), (C.c_uint64 * n)()
+        _check(lib().rb_pool_kernel_time(self.h, n, ms, calls), "rb_pool_kernel_time")
+        return [(ms[i], calls[i]) for i in range(n)]
 
     def classify_into(self, seqs_ptr, offsets_ptr, lens_ptr, n, maxcount_ptr, best_ptr, decision_ptr, status_ptr, error_rate=0.1,
                       significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):

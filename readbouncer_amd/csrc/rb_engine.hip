@@ -164,6 +164,9 @@ struct MergedGroup {
     MergeMap map{};                 // this engine's view: where each member's maximum goes
 };
 
+// What engines created from now on take for the reverse strand's image of N (rb_set_default_revcomp_of_n; ibf_spec.h for the rule)
+static std::atomic<uint32_t> g_default_revcomp_of_n{rbspec::kRevCompOfN};
+
 struct rb_engine {
     int device = 0;
     std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
@@ -705,28 +708,29 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) == hipSuccess && khz > 0) e->wall_clock_khz = (uint32_t)khz;
         else (void)hipGetLastError();
     }
-    // Process-wide switches read from the environment -- for the CLI and the C++ mirror, which create their engines themselves
-    // (RB_REVCOMP_OF_N=4: the other candidate of the recalled reverse-complement-of-N rule, ibf_spec.h; the others pick kernel forms
-    // for A/B measurements and never change a result).  Each has a setter in the API.  Every override that was ACCEPTED is named in
-    // rb_last_warning() of the creating thread, so that a stray variable cannot change behaviour without a trace.
+    e->revcomp_of_n = g_default_revcomp_of_n.load();  // rb_set_default_revcomp_of_n: the one switch that changes results, never an environment variable
+    // A/B switches for measurements, read from the environment ONLY when RB_TUNING_ENV=1 says the process is a measurement (profiles/,
+    // bench.py sweeps): they pick kernel forms and slice cuts and never change a result; each has a setter in
+    // include/readbouncer_amd_tuning.h.  Every override that was ACCEPTED is named in rb_last_warning() of the creating thread, so
+    // that a stray variable cannot change behaviour without a trace.  A production process has no environment surface at all.
     std::string accepted;
     auto note = [&](const char *name, const char *v) { accepted += std::string(accepted.empty() ? "" : ", ") + name + "=" + v; };
-    if (const char *v = std::getenv("RB_REVCOMP_OF_N")) {
-        if (std::atoi(v) == 3 || std::atoi(v) == 4) { e->revcomp_of_n = (uint32_t)std::atoi(v); note("RB_REVCOMP_OF_N", v); }
+    const char *tuning_env = std::getenv("RB_TUNING_ENV");
+    if (tuning_env && std::atoi(tuning_env) == 1) {
+        if (const char *v = std::getenv("RB_MERGE")) {  // rb_engine_set_merge is the API
+            if (std::atoi(v) >= 0 && std::atoi(v) <= 2) { e->merge_mode = std::atoi(v); note("RB_MERGE", v); }
+        }
+        if (const char *v = std::getenv("RB_MERGE_MAX_BYTES")) { e->merge_max_bytes = std::strtoull(v, nullptr, 10); note("RB_MERGE_MAX_BYTES", v); }
+        if (const char *v = std::getenv("RB_PHASE_MAX_SLICES")) {
+            if (std::atoi(v) >= 1 && std::atoi(v) <= 32) { e->phase_max_slices = (uint32_t)std::atoi(v); note("RB_PHASE_MAX_SLICES", v); }
+        }
+        if (const char *v = std::getenv("RB_PHASE_SLICE_LOG2")) {
+            if (std::atoi(v) >= 1 && std::atoi(v) <= 26) { e->phase_slice_log2 = (uint32_t)std::atoi(v); note("RB_PHASE_SLICE_LOG2", v); }
+        }
+        if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
+        if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
+        if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
     }
-    if (const char *v = std::getenv("RB_MERGE")) {  // A/B switch for measurements; rb_engine_set_merge is the API
-        if (std::atoi(v) >= 0 && std::atoi(v) <= 2) { e->merge_mode = std::atoi(v); note("RB_MERGE", v); }
-    }
-    if (const char *v = std::getenv("RB_MERGE_MAX_BYTES")) { e->merge_max_bytes = std::strtoull(v, nullptr, 10); note("RB_MERGE_MAX_BYTES", v); }
-    if (const char *v = std::getenv("RB_PHASE_MAX_SLICES")) {
-        if (std::atoi(v) >= 1 && std::atoi(v) <= 32) { e->phase_max_slices = (uint32_t)std::atoi(v); note("RB_PHASE_MAX_SLICES", v); }
-    }
-    if (const char *v = std::getenv("RB_PHASE_SLICE_LOG2")) {
-        if (std::atoi(v) >= 1 && std::atoi(v) <= 26) { e->phase_slice_log2 = (uint32_t)std::atoi(v); note("RB_PHASE_SLICE_LOG2", v); }
-    }
-    if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
-    if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
-    if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
     rb::set_warning(accepted.empty() ? std::string() : "rb_engine_create: environment overrides in effect: " + accepted);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     e->d_parts.resize(e->filters.size());
@@ -781,6 +785,13 @@ int rb_engine_set_column_shard(rb_engine *e, int rank, int world)
     if (world != e->shard_world) e->merged_planned = false;  // a bin-sharded rank never uses merged tables: planned again at the next call
     e->shard_rank = rank;
     e->shard_world = world;
+    return RB_OK;
+}
+
+int rb_set_default_revcomp_of_n(uint32_t ordinal)
+{
+    if (ordinal != 3 && ordinal != 4) return rb::fail(RB_ERR_INVALID_ARG, "the reverse strand's image of N is ordinal 3 (T) or 4 (N)");
+    g_default_revcomp_of_n.store(ordinal);
     return RB_OK;
 }
 
@@ -1105,8 +1116,14 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
                 uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes) : 0;
                 if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
                 if (want >= 1 && want <= e->phase_max_slices && want < n_sl) {
-                    blocks_per_slice = (f->geo.n_blocks + want - 1) / want;
-                    n_sl = (uint32_t)((f->geo.n_blocks + blocks_per_slice - 1) / blocks_per_slice);
+                    // the kernels carry blocks-per-slice in 31 bits and the slice's span in BYTES in 31 bits as well (bit 31 is the
+                    // flag of this form): a slice of 2 GiB or more keeps the power-of-two cut, whose span is a shift (ADVICE r4 --
+                    // a truncated span would read lookups beyond it as "no lookup" and the counts would be silently short)
+                    const uint64_t bps = (f->geo.n_blocks + want - 1) / want;
+                    if (bps < (1ull << 31) && bps * f->stride * 8 < (1ull << 31)) {
+                        blocks_per_slice = bps;
+                        n_sl = (uint32_t)((f->geo.n_blocks + blocks_per_slice - 1) / blocks_per_slice);
+                    }
                 }
             }
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/readbouncer_amd.h"
+#include "../../include/readbouncer_amd_tuning.h"
 #include "ibf_spec.h"
 
 struct rb_ibf {

@@ -229,6 +229,30 @@ int rb_pool_get_stats(rb_pool *p, size_t n, int *devices, double *busy_seconds, 
 
 size_t rb_pool_size(const rb_pool *p) { return p ? p->workers.size() : 0; }
 
+int rb_pool_set_timing(rb_pool *p, int enabled)
+{
+    if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    for (Device *w : p->workers) {
+        const int rc = rb_engine_set_timing(w->engine, enabled);
+        if (rc != RB_OK) return rc;
+    }
+    return RB_OK;
+}
+
+int rb_pool_kernel_time(rb_pool *p, size_t n, double *total_ms, uint64_t *n_launches)
+{
+    if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");
+    for (size_t i = 0; i < n && i < p->workers.size(); ++i) {
+        double ms = 0.0;
+        uint64_t calls = 0;
+        const int rc = rb_engine_kernel_time(p->workers[i]->engine, &ms, &calls);
+        if (rc != RB_OK) return rc;
+        if (total_ms) total_ms[i] = ms;
+        if (n_launches) n_launches[i] = calls;
+    }
+    return RB_OK;
+}
+
 int rb_pool_set_min_split(rb_pool *p, size_t reads_per_device)
 {
     if (!p) return rb::fail(RB_ERR_INVALID_ARG, "null pool");

@@ -83,11 +83,13 @@ extern "C" int rb_dibf_probe_read_peak(rb_dibf *f, uint64_t table_bytes, uint32_
                                        double target_ms, double *gbps_out, double *ms_out)
 {
     if (!f || !gbps_out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
-    if (table_bytes == 0) {  // the whole table as it lies in HBM
+    {
         rb_ibf_info g;
         int rc = rb_dibf_get_info(f, &g);
         if (rc != RB_OK) return rc;
-        table_bytes = g.n_blocks * rb_dibf_device_stride(f) * 8;
+        const uint64_t whole = g.n_blocks * rb_dibf_device_stride(f) * 8;  // the table as it lies in HBM
+        if (table_bytes == 0) table_bytes = whole;
+        if (table_bytes > whole) return rb::fail(RB_ERR_INVALID_ARG, "probe table_bytes beyond the filter's table");  // (would gather out of bounds)
     }
     if (row_bytes != 128 && row_bytes != 1024 && row_bytes != 4096) return rb::fail(RB_ERR_INVALID_ARG, "probe rows are 128, 1024 or 4096 bytes");
     if (table_bytes < row_bytes || table_bytes / row_bytes >= (1ull << 32)) return rb::fail(RB_ERR_INVALID_ARG, "probe table size");

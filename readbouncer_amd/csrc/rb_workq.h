@@ -117,12 +117,15 @@ class Dispatcher {
 public:
     explicit Dispatcher(std::vector<Worker *> workers) : workers_(std::move(workers)) {}
     size_t size() const { return workers_.size(); }
-    // part k of `parts` (parts <= size()) is make_task(k, worker index); returns after queueing, the caller then waits on job
+    // part k of `parts` is make_task(k, worker index); returns after queueing, the caller then waits on job.  EVERY part is queued:
+    // a call of more parts than workers wraps around the chosen workers (several parts behind each other on one worker) -- a
+    // caller's slices are computed from its own part count, so a dropped part would be reads that are never classified.
     void dispatch(size_t parts, Job &job, const std::function<std::function<int()>(size_t, size_t)> &make_task)
     {
         std::lock_guard<std::mutex> lock(mu_);
         const size_t nw = workers_.size();
-        if (parts > nw) parts = nw;
+        const size_t all_parts = parts;
+        if (parts > nw) parts = nw;  // workers to choose
         // workers in cursor order with their loads; a stable selection of the `parts` smallest keeps the round-robin among ties
         std::vector<size_t> order(nw), load(nw);
         for (size_t k = 0; k < nw; ++k) {
@@ -141,13 +144,13 @@ public:
         size_t last = 0;
         for (size_t k : pick) last = std::max(last, k);
         next_ = (order[last] + 1) % nw;
-        job.pending = parts;  // no worker sees `job` before the first submit
-        size_t part = 0;
-        for (size_t k = 0; k < nw; ++k) {  // parts in cursor order: part 0 on the first chosen worker after the cursor
-            if (!taken[k]) continue;
-            const size_t w = order[k];
+        job.pending = all_parts;  // no worker sees `job` before the first submit
+        std::vector<size_t> chosen;  // in cursor order: part 0 on the first chosen worker after the cursor
+        for (size_t k = 0; k < nw; ++k)
+            if (taken[k]) chosen.push_back(order[k]);
+        for (size_t part = 0; part < all_parts; ++part) {
+            const size_t w = chosen[part % chosen.size()];
             workers_[w]->submit(Task{make_task(part, w), &job});
-            ++part;
         }
     }
 

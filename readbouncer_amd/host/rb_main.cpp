@@ -20,6 +20,7 @@
 #include <iostream>
 
 #include "../../include/readbouncer_amd.hpp"
+#include "../../include/readbouncer_amd_tuning.h"  // --calibrate only
 #include "config_reader.hpp"
 #include "seqio.hpp"
 
@@ -433,15 +434,29 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         uint64_t next_seq = 0, write_seq = 0;
         std::string worker_error;
         std::mutex cal_mu;
+        std::condition_variable cal_cv;
+        unsigned cal_parties = 0, cal_arrived = 0;  // (cal_parties is set before the first classifier starts)
         auto classifier = [&] {
             try {
-                if (opt.calibrate && !multi) {  // one engine at a time: they would spoil each other's timings
-                    std::lock_guard<std::mutex> lock(cal_mu);
+                if (opt.calibrate && !multi) {
+                    // one engine at a time, and nobody classifies before the last engine is calibrated: an engine timed beside
+                    // another thread's classification picks its windows from noise
+                    std::unique_lock<std::mutex> lock(cal_mu);
                     uint32_t n_tables = 0, n_changed = 0;
-                    const int rc = rb_engine_calibrate(interleave::detail::engine_for(DepletionFilters, TargetFilters), opt.batch_reads, chunk_length, 40.0,
-                                                       &n_tables, &n_changed);
+                    int rc = RB_ERR_INVALID_ARG;
+                    try {
+                        rc = rb_engine_calibrate(interleave::detail::engine_for(DepletionFilters, TargetFilters), opt.batch_reads, chunk_length, 40.0,
+                                                 &n_tables, &n_changed);
+                    } catch (...) {
+                        ++cal_arrived;  // (the others must not wait for a thread that is on its way out)
+                        cal_cv.notify_all();
+                        throw;
+                    }
                     if (rc != RB_OK) log_line("warn", std::string("calibration skipped: ") + rb_last_error());
                     else log_line("info", "calibrated " + std::to_string(n_tables) + " phased table(s), " + std::to_string(n_changed) + " window(s) changed");
+                    ++cal_arrived;
+                    cal_cv.notify_all();
+                    cal_cv.wait(lock, [&] { return cal_arrived >= cal_parties; });
                 }
                 for (;;) {
                     std::unique_ptr<seqio::Segment> seg;
@@ -512,6 +527,7 @@ static void classify_reads(ConfigReader& config, std::vector<interleave::IBFMeta
         {
             // (a multi-device pool spreads every call over its devices itself; two callers keep it fed while one formats)
             if (multi) n_classifiers = std::min(n_classifiers, 2u);
+            cal_parties = n_classifiers;
             std::vector<std::thread> workers;
             for (unsigned i = 1; i < n_classifiers; ++i) workers.emplace_back(classifier);
             classifier();
@@ -709,6 +725,7 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--calibrate")) opt.calibrate = true;
+        else if (!std::strcmp(argv[i], "--revcomp-of-n") && i + 1 < argc) interleave::set_revcomp_of_n((uint32_t)std::stoul(argv[++i]));
         else if (!std::strcmp(argv[i], "--mmap-output")) opt.mmap_output = true;
         else if (!std::strcmp(argv[i], "--no-mmap-output")) opt.mmap_output = false;
         else if (!std::strcmp(argv[i], "--segment-mb") && i + 1 < argc) opt.segment_mb = std::max<size_t>(1, (size_t)std::stoull(argv[++i]));
@@ -738,7 +755,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] [--calibrate] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] [--calibrate] [--revcomp-of-n 3|4] "
                          "[--devices 0,1,...] [--parse-stats file]\n"
                          "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;

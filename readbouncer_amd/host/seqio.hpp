@@ -502,7 +502,7 @@ class OrderedOutput
 {
 public:
     static constexpr size_t kChunk = (size_t)2 << 20;  // positional writes: bytes formatted between two hand-overs
-    static constexpr size_t kPoolBuffers = 12;         // per file: formatting threads stall when all of them wait to be written
+    static constexpr size_t kPoolBuffers = 12;         // per file: formatting threads wait while that many are queued for the writer thread
 
 private:
     struct Job
@@ -526,6 +526,7 @@ private:
     std::deque<Job> queue_;
     std::vector<std::unique_ptr<std::vector<char>>> buffers_;
     std::vector<std::vector<char>*> free_;
+    size_t in_flight_ = 0;  // buffers queued for, or being written by, the writer thread: the only ones that come back by themselves
     bool stop_ = false;
 
     void fail(const std::string& what)
@@ -548,21 +549,31 @@ private:
             {
                 std::lock_guard<std::mutex> lock(qmu_);
                 free_.push_back(j.buf);
+                --in_flight_;
             }
             pool_cv_.notify_one();
         }
     }
+    // A caller waits only for buffers that are ON THEIR WAY BACK (queued for the writer thread).  Buffers that sit half-filled in
+    // other threads' Writers return when those threads get on -- and they may be waiting for a buffer of ANOTHER file that this
+    // caller holds: with two output files and more formatting threads than pool buffers, twelve threads held file A's buffers
+    // and waited for B while twelve held B's and waited for A.  So when nothing is in flight the pool grows instead:
+    // at most one buffer per formatting thread and file.
     std::vector<char>* acquire()
     {
         std::unique_lock<std::mutex> lock(qmu_);
-        if (free_.empty() && buffers_.size() < kPoolBuffers) {
-            buffers_.emplace_back(new std::vector<char>(kChunk));
-            return buffers_.back().get();
+        for (;;) {
+            if (!free_.empty()) {
+                std::vector<char>* b = free_.back();
+                free_.pop_back();
+                return b;
+            }
+            if (buffers_.size() < kPoolBuffers || in_flight_ == 0) {
+                buffers_.emplace_back(new std::vector<char>(kChunk));
+                return buffers_.back().get();
+            }
+            pool_cv_.wait(lock);
         }
-        pool_cv_.wait(lock, [&] { return !free_.empty(); });
-        std::vector<char>* b = free_.back();
-        free_.pop_back();
-        return b;
     }
     void release(std::vector<char>* b)
     {
@@ -578,6 +589,7 @@ private:
             std::lock_guard<std::mutex> lock(qmu_);
             if (!writer_.joinable()) writer_ = std::thread([this] { writer_loop(); });
             queue_.push_back(Job{b, n, off});
+            ++in_flight_;
         }
         qcv_.notify_one();
     }

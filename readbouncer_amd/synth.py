@@ -24,7 +24,7 @@ WORKLOADS = {
     # GRCh38 exactly as ReadBouncer itself would build it: fragment_size 100000 (its default) -> ~31 000 bins,
     # W = 485 words (odd: 8-byte lanes, 8 column slices), 4.8 GB, odd block count
     "grch38_f100k": dict(name="GRCh38 at ReadBouncer's default fragment_size=100000: 31000 bins (3.9 KB blocks), 4.8 GB",
-                         n_bins=31000, k=13, h=3, fragment=100000, n_bits=None, reads=500_000, read_len=360),
+                         n_bins=31000, k=13, h=3, fragment=100000, n_bits=None, reads=2_000_000, read_len=360),
     # config 1 geometry (64 bins, F=100000) for completeness
     "c1": dict(name="config1 geometry: 360bp prefixes vs 64-bin IBF (k=13, F=100000)",
                n_bins=64, k=13, h=3, fragment=100000, n_bits=None, reads=1_000_000, read_len=360),

@@ -44,8 +44,9 @@ static std::vector<RefSeq> read_fasta(const std::string& path)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::cerr << "usage: test_mirror <fixture dir> <tmp dir>\n"; return 2; }
+    if (argc < 3) { std::cerr << "usage: test_mirror <fixture dir> <tmp dir> [revcomp-of-n: 3 | 4]\n"; return 2; }
     const std::string fix = argv[1], tmp = argv[2];
+    if (argc > 3) set_revcomp_of_n((uint32_t)std::stoul(argv[3]));  // the other candidate of the N rule, for the whole process
     std::filesystem::create_directories(tmp);
 
     // ---- IBFTest.CreateFilterTest (createfilter.hpp:43-203): build test.ibf from test.fasta

@@ -2,6 +2,10 @@
 // a page-locked allocator that refuses falls back to the heap with the same records and prefixes; an allocator that
 // throws inside a worker thread ends the stream with an error segment instead of std::terminate.
 #include <atomic>
+#include <chrono>
+#include <thread>
+#include <vector>
+#include <cstring>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -119,6 +123,59 @@ int main()
         got << in.rdbuf();
         CHECK(got.str() == expect);
         std::remove(path.c_str());
+    }
+    {
+        // more formatting threads than a file has pool buffers, TWO output files, every thread holding a half-filled
+        // buffer of one file while it asks for a buffer of the other (what a classifier thread does: one Writer per output file for
+        // the whole format pass of its segment).  Half of the threads take file A first, half file B first.  Used to hang with
+        // 0 of 30 threads finishing; a watchdog turns a hang into a failure.
+        const int n_threads = 30;
+        static_assert(n_threads > 2 * (int)seqio::OrderedOutput::kPoolBuffers, "more threads than both pools hold");
+        const std::string pa = std::string("/tmp/rb_test_two_files_") + std::to_string((long)getpid()) + "_a";
+        const std::string pb = std::string("/tmp/rb_test_two_files_") + std::to_string((long)getpid()) + "_b";
+        seqio::OrderedOutput a, b;
+        CHECK(a.open(pa, false) && b.open(pb, false));
+        const size_t piece = 3000;
+        std::vector<uint64_t> at_a(n_threads), at_b(n_threads);
+        for (int t = 0; t < n_threads; ++t) { at_a[t] = a.reserve(piece); at_b[t] = b.reserve(piece); }
+        std::atomic<int> holding{0}, done{0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t] {
+                seqio::OrderedOutput::Writer wa = a.writer(at_a[t], piece), wb = b.writer(at_b[t], piece);
+                seqio::OrderedOutput::Writer& first = (t & 1) ? wb : wa;
+                seqio::OrderedOutput::Writer& second = (t & 1) ? wa : wb;
+                std::memset(first.take(piece / 2), 'a' + t % 26, piece / 2);  // holds a buffer of its first file from here on
+                ++holding;
+                while (holding.load() < n_threads && done.load() == 0) std::this_thread::yield();  // everybody holds one
+                std::memset(second.take(piece), 'A' + t % 26, piece);
+                std::memset(first.take(piece - piece / 2), 'a' + t % 26, piece - piece / 2);
+                if (wa.finish() && wb.finish()) ++done;
+            });
+        for (int ms = 0; ms < 20000 && done.load() < n_threads; ms += 10) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        CHECK(done.load() == n_threads);
+        if (done.load() < n_threads) {
+            std::cerr << "two output files, " << n_threads << " threads: " << done.load() << " finished -- deadlock" << std::endl;
+            std::_Exit(1);  // the stuck threads cannot be joined
+        }
+        for (auto& x : th) x.join();
+        a.close();
+        b.close();
+        CHECK(a.ok() && b.ok() && a.bytes() == (uint64_t)n_threads * piece && b.bytes() == (uint64_t)n_threads * piece);
+        for (const std::string* path : {&pa, &pb}) {
+            std::ifstream in(*path, std::ios::binary);
+            std::stringstream got;
+            got << in.rdbuf();
+            const std::string text = got.str();
+            bool good = text.size() == (size_t)n_threads * piece;
+            for (int t = 0; good && t < n_threads; ++t) {
+                const bool first_file = ((t & 1) != 0) == (path == &pb);
+                const char want = (char)((first_file ? 'a' : 'A') + t % 26);
+                for (size_t i = 0; i < piece; ++i) good = good && text[(size_t)t * piece + i] == want;
+            }
+            CHECK(good);
+            std::remove(path->c_str());
+        }
     }
     {
         seqio::OrderedOutput nothing;  // a file nobody wrote to ends up empty

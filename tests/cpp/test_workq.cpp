@@ -126,6 +126,23 @@ int main()
         for (auto &j : jobs) j->wait();
         extra.wait();
     }
+    // a call of MORE parts than there are workers: every part runs exactly once (a clamp to the worker count would have dropped the
+    // tail of the caller's slices without an error), wrapped around the workers
+    {
+        const size_t parts = 3 * W + 1;
+        std::vector<std::atomic<int>> ran(parts);
+        for (auto &x : ran) x = 0;
+        std::vector<int> per_worker(W, 0);
+        rbq::Job job;
+        disp.dispatch(parts, job, [&](size_t k, size_t w) -> std::function<int()> {
+            ++per_worker[w];
+            return [&ran, k] { ++ran[k]; return 0; };
+        });
+        job.wait();
+        CHECK(job.rc == 0);
+        for (size_t k = 0; k < parts; ++k) CHECK(ran[k] == 1);
+        for (size_t w = 0; w < W; ++w) CHECK(per_worker[w] == 3 || per_worker[w] == 4);
+    }
     // shutdown runs what is queued
     {
         std::atomic<int> done{0};

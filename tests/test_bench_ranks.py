@@ -14,19 +14,61 @@ import sys
 
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
+def _strict(text):
+    """strict JSON: NaN / Infinity tokens are refused like a non-Python parser would refuse them"""
+    def refuse(tok):
+        raise ValueError("non-standard JSON token %s" % tok)
+    return json.loads(text, parse_constant=refuse)
+
+
 def _run(argv, env_extra, timeout=240, launcher=None):
+    """-> (process, full result).  bench.py prints ONE bounded line (the driver's record) and writes everything else to the sidecar
+    file RB_BENCH_DETAIL names; the tests read the sidecar and find the line itself under "_line" / "_compact"."""
+    import tempfile
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
+    fd, side = tempfile.mkstemp(prefix="rb_bench_detail_", suffix=".json")
+    os.close(fd)
+    os.unlink(side)
+    env["RB_BENCH_DETAIL"] = side
     env.update(env_extra)
     cmd = (launcher or [sys.executable]) + [BENCH] + argv
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    return p, (json.loads(lines[-1]) if lines else None)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if not lines:
+            return p, None
+        compact = _strict(lines[-1])
+        d = _strict(open(side).read()) if os.path.exists(side) else dict(compact)
+        d["_line"], d["_compact"] = lines[-1], compact
+        return p, d
+    finally:
+        if os.path.exists(side):
+            os.unlink(side)
+
+
+def _check_line(d, n_gpus):
+    """the contract of the final line: bounded, strict JSON, the headline with its roofline, CPU baseline and
+    parity keys, one small row per other leg"""
+    line, c = d["_line"], d["_compact"]
+    assert len(line.encode()) <= 4096, len(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert key in c, key
+    assert c["n_gpus"] == n_gpus and c["value"] == pytest.approx(d["value"], rel=1e-4)
+    assert isinstance(c["config"]["workload"], str) and "model" not in c["config"]
+    for leg, row in (c.get("other_configs") or {}).items():
+        assert set(row) <= {"value", "ms_per_step", "frac", "frac_of_read_peak", "request_bound_frac", "p99_ms", "live_p99_ms", "cpu_reads_per_s",
+                            "parity_ok", "checked_reads", "error"}, (leg, row)
+        assert len(json.dumps(row)) < 300
+    return c
 
 
 CPU_HOOKS = {"RB_BENCH_ENGINE": "none", "RB_BENCH_BACKEND": "gloo"}
@@ -41,6 +83,7 @@ def test_gpus2_self_launch_read_sharded_cpu():
     assert "no classification ran" in d["engine"]  # the hook can never be mistaken for a measurement
     # exactly one JSON line on stdout
     assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1
+    _check_line(d, 2)
     # whole-job aggregate: both ranks' reads over the max time
     assert abs(d["value"] - 2 * 400 * 3 / (d["ms_per_step"] * 3 / 1e3)) / d["value"] < 1e-6
 
@@ -54,7 +97,10 @@ def test_gpus2_default_line_structure_cpu():
     for key in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data",
                 "roofline", "cpu_baseline", "parity", "ranks", "other_configs"):
         assert key in d, key
-    assert set(d["other_configs"]) == {"c3np2", "c2", "c4", "c5", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4"}
+    # N > 1 carries the multi-GPU configs and the pool legs only (four SCALE runs back to back); N = 1 carries every leg
+    assert set(d["other_configs"]) == {"c3np2", "c4", "c5", "pool_c3", "pool_c4"}
+    c = _check_line(d, 2)
+    assert set(c["other_configs"]) == set(d["other_configs"]) and len(c["ranks"]["per_rank_reads_per_s"]) == 2
     for sub in d["other_configs"].values():
         assert sub["n_gpus"] == 2 and sub["value"] > 0
     # the one-process pool legs: rank 0 measures alone, the other rank waits for it on the HOST (rendezvous store), not in a
@@ -97,9 +143,79 @@ def test_under_torchrun_cpu():
 
 
 def test_dead_rank_does_not_hang_the_launcher():
+    """a rank that dies: the launcher ends the others, exits non-zero and still leaves ONE parseable line with an `error` field"""
     p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200"],
                 dict(CPU_HOOKS, RB_BENCH_TEST_DIE_RANK="1"), timeout=120)
     assert p.returncode != 0
+    # (rank 0 notices the broken collective itself, or the launcher reports that rank 0 left no line: either way a reason)
+    assert d is not None and d["_compact"]["value"] == 0 and d["_compact"]["error"]
+    assert len(d["_line"]) <= 4096
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200"],
+                dict(CPU_HOOKS, RB_BENCH_TEST_DIE_RANK="0"), timeout=120)
+    assert p.returncode != 0 and d is not None and d["_compact"]["value"] == 0 and d["_compact"]["error"]
+
+
+@pytest.mark.parametrize("n", [1, 8])
+def test_default_line_is_bounded_cpu(n):
+    """the DEFAULT command at N = 1 and N = 8 on the null engine: one line, at most 4 KB, strict JSON, roofline / cpu_baseline /
+    parity keys present, every leg of the run summarised in a row; the sidecar holds the rest"""
+    p, d = _run(["--gpus", str(n), "--steps", "2", "--warmup", "1"], CPU_HOOKS, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1
+    c = _check_line(d, n)
+    import bench
+    assert tuple(c["other_configs"]) == (bench.FULL_LEGS if n == 1 else bench.MULTI_LEGS)
+    assert "grch38_f100k" in bench.FULL_LEGS  # the reference-default human filter rides in the default N = 1 run
+    if n > 1:
+        assert len(c["ranks"]["per_rank_reads_per_s"]) == n and len(d["ranks"]["devices"]) == n
+
+
+def test_compact_line_sheds_detail_but_keeps_the_contract():
+    """compact_line on a result as fat as round 4's (29.6 KB: plans, probes, request bounds, pool statistics, per-rank device records
+    of eight ranks): <= 4 KB, the headline's roofline.frac and cpu_baseline.value intact, request bounds never under a key `frac`"""
+    import bench
+    plan = [{"kernel": "ibf_count_max_phased_kernel", "table_bytes": 41943040, "merged_members": 4, "phased": 1,
+             "phase_shape_name": "four tiles, four-word one-lane" * 2, "phase_slices": 8, "phase_window_ticks": 575}] * 4
+    def leg(i):
+        return {"metric": bench.METRIC, "value": 1e6 * (i + 1) + 0.123456789, "unit": "reads/s", "n_gpus": 8, "steps": 5, "warmup": 1,
+                "ms_per_step": 12.3456789, "config": {"workload": "w" * 400, "filters": [{"n_bins": 8192}] * 4, "decisions": [1, 2, 3]},
+                "roofline": {"bound": "hbm", "achieved": 3700.123456, "peak": 8000.0, "unit": "GB/s", "frac": 0.4625154, "traffic": 1.0e13,
+                             "traffic_source": "s" * 300, "plan": plan, "read_peak_probe": {"GBps": 6900.5, "source": "x" * 300},
+                             "frac_of_measured_read_peak": 0.9981,
+                             "request_bound": {"request_bound_frac": 0.93, "source": "y" * 400, "l2_Grequests_per_s": 250.0}},
+                "cpu_baseline": {"value": 15400.7, "unit": "reads/s", "cores": 16, "kind": "port", "sample": "z" * 300},
+                "parity": {"checked_reads": 220000, "decision_mismatches": 0, "raw_max_mismatches": 0, "near_threshold_reads": 2800,
+                           "against": "a" * 200},
+                "latency": {"by_batch": {"64": {"p50_ms": 0.066, "p99_ms": 0.081}, "1024": {"p50_ms": 0.38, "p99_ms": 0.39}}},
+                "setup_s": 1.0}
+    head = leg(0)
+    head["ranks"] = {"backend": "nccl", "rccl_ranks": 8, "self_launched": False, "per_rank_reads_per_s": [3.2e6 + i for i in range(8)],
+                     "devices": [{"rank": i, "device": i, "name": "AMD Instinct MI355X", "uuid": "u" * 36, "peer_access_possible": [True] * 8}
+                                 for i in range(8)], "xgmi_preflight": {"ran": True, "GBps": 50.0}}
+    head["other_configs"] = {name: leg(i + 1) for i, name in enumerate(bench.FULL_LEGS)}
+    head["other_configs"]["pool_c3"]["parity"] = {"pool_outputs_equal_single_engine": True, "oracle_mismatches": 0, "checked_reads": 5}
+    head["other_configs"]["c5"]["latency"] = {"p99_ms": 0.16, "p50_ms": 0.06}
+    head["other_configs"]["c5"]["parity"] = {"replayed_decisions_equal_one_batch": True, "checked_reads": 300000}
+    assert len(json.dumps(head)) > 25000
+    line = bench.compact_line(head, "bench_detail.json")
+    assert len(line.encode()) <= bench.COMPACT_LIMIT == 4096
+    c = _strict(line)
+    assert c["roofline"]["frac"] == pytest.approx(0.4625154, rel=1e-5) and c["cpu_baseline"]["value"] == pytest.approx(15400.7)
+    assert c["roofline"]["request_bound_frac"] == 0.93 and c["parity"]["decision_mismatches"] == 0
+    assert set(c["other_configs"]) == set(bench.FULL_LEGS)
+    assert c["other_configs"]["c5"]["p99_ms"] == 0.16 and c["other_configs"]["pool_c3"]["parity_ok"] is True
+    assert all(r["parity_ok"] is True for r in c["other_configs"].values())
+    assert c["detail"] == "bench_detail.json" and "plan" not in line and "request_roofline" not in line
+    # NaN / Infinity never reach the line; a mismatch shows
+    head["value"] = float("nan")
+    head["other_configs"]["c4"]["parity"]["raw_max_mismatches"] = 3
+    c = _strict(bench.compact_line(head))
+    assert c["value"] is None and c["other_configs"]["c4"]["parity_ok"] is False
+    # and far beyond anything the run produces (64 ranks, 40 legs) the bound still holds
+    head["value"] = 1.0
+    head["ranks"]["per_rank_reads_per_s"] = [3.2e6] * 64
+    head["other_configs"] = {"leg%d" % i: leg(i) for i in range(40)}
+    assert len(bench.compact_line(head, "bench_detail.json")) <= 4096
 
 
 GPU_HOOKS = {"RB_BENCH_BACKEND": "gloo", "RB_BENCH_SAME_GPU": "1", "RB_BENCH_DUMP_DECISIONS": "1"}

@@ -14,9 +14,23 @@ from tests import helpers as H
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "readbouncer_amd.h")).read()
+HEADERS = ("readbouncer_amd.h", "readbouncer_amd_tuning.h")  # the reference-mapped calls; measurement aids and scheduling knobs
+
+
+def declared_symbols(headers=HEADERS):
+    text = "".join(open(os.path.join(ROOT, "include", h)).read() for h in headers)
     return sorted(set(re.findall(r"RB_API[^;(]*?\b(rb_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_boundary_header_holds_no_lab_equipment():
+    """include/readbouncer_amd.h is the drop-in boundary: calls a ReadBouncer integration binds.  Knobs that
+    pick kernel forms, planners, probes, replays and synthetic fillers live in readbouncer_amd_tuning.h -- same library -- and no
+    symbol is declared twice."""
+    main, tuning = declared_symbols(HEADERS[:1]), declared_symbols(HEADERS[1:])
+    assert not set(main) & set(tuning)
+    lab = re.compile(r"probe|replay|calibrate|fill_synth|set_phased|phase_slices|split_parts|set_timing|kernel_time|get_stats|_plan$|serialize")
+    assert [s for s in main if lab.search(s)] == []
+    assert len(main) >= 50 and len(tuning) >= 20
 
 
 def test_library_exports_every_declared_symbol():

@@ -1002,6 +1002,8 @@ def test_measurement_aids_answer():
     assert gbps > 0 and ms > 0
     with pytest.raises(capi.RBError):
         d.probe_read_peak(100, False)  # rows of 128, 1024 or 4096 bytes
+    with pytest.raises(capi.RBError):  # a table larger than the filter's own would gather out of bounds
+        d.probe_read_peak(1024, False, 12, table_bytes=d.info["n_blocks"] * d.device_stride() * 8 + 1024, target_ms=5.0)
     eng = capi.Engine(0, [d], [])
     pl = eng.plan(0, 100000, 360)
     assert pl["kernel"] == "ibf_count_max_kernel" and pl["lanes_per_block_log2"] == 6 and pl["words_per_lane"] == 2 and not pl["phased"]
@@ -1266,6 +1268,7 @@ def test_a_merged_copy_beyond_the_cap_is_not_made(monkeypatch):
     copy_bytes = (n_blocks * 4 + 8) * 8  # 100 + 30 + 30 + 30 bins side by side, bit to bit: three words, padded to four (whole words: five -> eight)
     small_copy = (n_blocks * 2 + 8) * 8  # the three 30-bin targets alone: 90 bins in two words
     for cap, expect in ((copy_bytes, (1, 4, copy_bytes)), (copy_bytes - 1, (1, 3, small_copy)), (1000, (0, 0, 0))):
+        monkeypatch.setenv("RB_TUNING_ENV", "1")  # environment switches are read by measurement processes only
         monkeypatch.setenv("RB_MERGE_MAX_BYTES", str(cap))
         eng = capi.Engine(0, filters[:1], filters[1:])
         assert eng.merge_info() == expect

@@ -293,11 +293,14 @@ def test_cpp_mirror_reads_like_the_reference_tests(tmp_path, refdata):
     p = subprocess.run([exe, refdata, str(tmp_path / "work")], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "failures: 0" in p.stdout
-    # the other candidate of the reverse-complement-of-N rule, for a whole process (RB_REVCOMP_OF_N): exactly the one
-    # expectation that tells the two rules apart fails (30 shared 13-mers on the reverse strand become 18 -> count 0)
-    env = dict(os.environ, RB_REVCOMP_OF_N="4")
-    q = subprocess.run([exe, refdata, str(tmp_path / "work4")], capture_output=True, text=True, env=env)
+    # the other candidate of the reverse-complement-of-N rule, for a whole process (interleave::set_revcomp_of_n ->
+    # rb_set_default_revcomp_of_n; a call, not an environment variable): exactly the one expectation that tells the two rules
+    # apart fails (30 shared 13-mers on the reverse strand become 18 -> count 0)
+    q = subprocess.run([exe, refdata, str(tmp_path / "work4"), "4"], capture_output=True, text=True)
     assert q.returncode != 0 and "failures: 1" in q.stdout and "pn.first" in q.stderr, q.stdout + q.stderr
+    # ... and the environment no longer reaches it: RB_REVCOMP_OF_N is not read by anything
+    r = subprocess.run([exe, refdata, str(tmp_path / "work5")], capture_output=True, text=True, env=dict(os.environ, RB_REVCOMP_OF_N="4"))
+    assert r.returncode == 0 and "failures: 0" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu

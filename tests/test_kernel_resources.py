@@ -5,7 +5,10 @@ The narrow-filter kernels live on the lookups a CU holds in registers: their bui
 noticed.  This pins waves per SIMD and "no scratch" for the builds the planner's window lengths were fitted with."""
 import os
 import re
+import shutil
 import subprocess
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "readbouncer_amd", "csrc")
@@ -35,6 +38,8 @@ def _demangle_args(mangled):
 
 def test_occupancy_classes_and_no_scratch(tmp_path):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this box: the occupancy classes are pinned where the library is built")
     p = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "--offload-arch=gfx950",
                         "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, "rb_kernels.hip"), "-o", str(tmp_path / "k.o")],
                        capture_output=True, text=True, timeout=900)
