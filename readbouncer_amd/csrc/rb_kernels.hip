@@ -292,13 +292,7 @@ struct BaseSrc {
     }
 };
 
-// Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
-// mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves) and of
-// each macro tile the eight-step blocks [blk_first, blk_end) (all STEPS / 8 of them, or a wave's share in the split kernel).
-// The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the
-// window of its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  With ph = {shift 0.., n_slices 1, inv_ticks 0} and
-// a slice_shift of 31 this is one batch of predicated gathers with no waiting (tables that need no phasing).
-// k-mers of a lane whose gathers go out together (B: one-word blocks, three 8-byte loads per k-mer; KB: two-word blocks,
+// Batch sizes of the phased window loop (phased_window_loop below): k-mers of a lane whose gathers go out together (B: one-word blocks, three 8-byte loads per k-mer; KB: two-word blocks,
 // three 16-byte loads per k-mer).  Every load in flight holds its destination registers, so the batch size sets the
 // occupancy: with ALL lookups of a window in flight (8 k-mers, 48 registers) the 250 bp one-word kernel has five waves per
 // SIMD, with two k-mers per batch six (73 VGPRs) -- four waits per window instead of one, and 7 % less time per read; the
@@ -352,160 +346,109 @@ __device__ __forceinline__ uint32_t phase_next_slice(uint32_t done, const PhaseC
     }
 }
 
-// The window loop of the phased form: x[u] &= the words at the byte offsets bn[u][*] of `words`, each gathered in the window of
-// its slice (offset >> slice_shift).  0xFFFFFFFF = no lookup.  The predication is done by the BOUNDS CHECK of a raw buffer
-// descriptor, not by exec masks: per window the wave points the descriptor at the slice of the moment (base = slice start,
-// num_records = slice bytes) and issues every lookup as buffer_load with the offset (lookup - slice start): a lane whose lookup
-// lies in another slice (or that has none) is out of range, makes no memory access and gets 0 back, which an OR with the
-// lane's out-of-range mask turns into the neutral all-ones.  No saveexec, no branch around a load, no scalar work per lookup
-// (the exec-masked loads of round 2: ~11 instructions per lookup and window, seven of them scalar or branches, every
-// destination register kept initialised across the window loop).  With ph = {n_slices 1, inv_ticks 0} and a slice_shift of 31
-// this is one batch of gathers with no waiting (tables that need no phasing).
-template <int N, int H, bool NT, int B = N>
-__device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (&bn)[N][H], const uint64_t *words,
-                                              uint32_t slice_shift, const PhaseCfg ph)
+// The window loop of the phased form -- ONE body for every block width a single lane holds (NW = 1 to 4 words; the three entry
+// points below only name the load widths): x*[u] &= the words of the block at byte offset bn[u][*] of `words`, each gathered in the
+// window of its slice.  0xFFFFFFFF = no lookup.  The predication is done by the BOUNDS CHECK of a raw buffer descriptor, not by
+// exec masks: per window the wave points the descriptor at the slice of the moment (base = slice start, num_records = slice
+// bytes) and issues every lookup as buffer_load with the offset (lookup - slice start): a lane whose lookup lies in another
+// slice (or that has none) is out of range, makes no memory access and gets 0 back, which an OR with the lane's out-of-range
+// mask turns into the neutral all-ones.  No saveexec, no branch around a load, no scalar work per lookup (the exec-masked loads
+// of round 2: ~11 instructions per lookup and window, seven of them scalar or branches, every destination register kept
+// initialised across the window loop).
+// How a table is cut is carried by slice_shift (rb_engine.hip, plan_geometry): a plain value = slices of 2^slice_shift bytes
+// (31: one slice that holds every offset -- with ph = {n_slices 1, inv_ticks 0} that is one batch of gathers with no waiting,
+// for tables that need no phasing); bit 31 set + a non-zero length in the low bits = slices of that many BYTES, any multiple of
+// the block size (equal-length slices, rb_phase_plan.h).  Blocks never straddle a slice.
+// Loads per lookup: NW 1 = one 8-byte, 2 = one 16-byte, 3 = 16 + 8 bytes, 4 = two 16-byte (blocks of 3 and 4 words lie at a
+// stride of 4 words, 32-byte aligned).  K k-mers of a lane go out together (KB): every load in flight holds its destination
+// registers, so the batch size sets the occupancy (see RB_GATHER_* above).
+template <int NW, int N, int H, int KB>
+__device__ __forceinline__ void phased_window_loop(uint64_t (&x0)[N], uint64_t (&x1)[N], uint64_t (&x2)[N], uint64_t (&x3)[N],
+                                                   const uint32_t (&bn)[N][H], const uint64_t *words, uint32_t slice_shift,
+                                                   const PhaseCfg ph)
 {
-    static_assert(N % B == 0, "the k-mers of a lane are gathered in batches of B");
+    static_assert(NW >= 1 && NW <= 4, "one lane holds blocks of one to four words");
+    static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
     const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;  // one bit per slice
     uint32_t done = 0;
 #pragma unroll 1
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
         done |= 1u << cur;
-        const bool any_len = (slice_shift >> 31) != 0 && slice_shift != 0x80000000u;  // bit 31 + a length in bytes: slices of any length
+        const bool any_len = (slice_shift >> 31) != 0 && slice_shift != 0x80000000u;
         const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << min(slice_shift, 31u);  // (slice_shift == 31: a single slice, cur == 0)
         const uint32_t start = any_len ? cur * span : cur << min(slice_shift, 31u);
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
 #pragma unroll
-        for (int part = 0; part < N / B; ++part) {
-            rb_u32x2 ld[B][H];
+        for (int part = 0; part < N / KB; ++part) {
+            rb_u32x2 lo2[KB][H], hi2[KB][H];  // NW 1: the block; NW 3: its third word
+            rb_u32x4 lo4[KB][H], hi4[KB][H];  // NW 2-4: words 0-1; NW 4: words 2-3
 #pragma unroll
-            for (int uu = 0; uu < B; ++uu) {
+            for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    // (the offsets are made opaque at both uses: otherwise `offset - start` of all 24 lookups is computed up
-                    // front and kept for the masks below -- 24 registers, a wave per SIMD on the 250 bp kernel)
-                    uint32_t off = bn[part * B + uu][h];
+                    // (the offsets are made opaque at both uses: otherwise `offset - start` of all lookups is computed up front
+                    // and kept for the masks below -- 24 registers, a wave per SIMD on the 250 bp one-word kernel)
+                    uint32_t off = bn[part * KB + uu][h];
                     asm volatile("" : "+v"(off));
-                    ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, off - start, 0, 0);
+                    if constexpr (NW == 1) lo2[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, off - start, 0, 0);
+                    else lo4[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
+                    // ("no lookup" stays out of range with bit 4 set)
+                    if constexpr (NW == 3) hi2[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, (off - start) | 16u, 0, 0);
+                    if constexpr (NW == 4) hi4[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (off - start) | 16u, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int uu = 0; uu < B; ++uu) {
+            for (int uu = 0; uu < KB; ++uu) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
-                    uint32_t off = bn[part * B + uu][h];
+                    uint32_t off = bn[part * KB + uu][h];
                     asm volatile("" : "+v"(off));
                     const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
-                    x[part * B + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
-                }
-            }
-        }
-    }
-}
-
-// The same for two-word blocks held by ONE lane (16-byte gathers): x0/x1 = the two word columns of the lane's N k-mers.
-template <int N, int H, int KB>
-__device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x1)[N], const uint32_t (&bn)[N][H],
-                                                 const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
-{
-    static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
-    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
-    uint32_t done = 0;
-#pragma unroll 1
-    while (done != all) {
-        const uint32_t cur = phase_next_slice(done, ph);
-        done |= 1u << cur;
-        const bool any_len = (slice_shift >> 31) != 0;  // bit 31 + a length in bytes: slices of any length
-        const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << slice_shift;
-        const uint32_t start = any_len ? cur * span : cur << slice_shift;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
-#pragma unroll
-        for (int part = 0; part < N / KB; ++part) {
-            rb_u32x4 ld[KB][H];
-#pragma unroll
-            for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    uint32_t off = bn[part * KB + uu][h];
-                    asm volatile("" : "+v"(off));
-                    ld[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    uint32_t off = bn[part * KB + uu][h];
-                    asm volatile("" : "+v"(off));
-                    const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
-                    x0[part * KB + uu] &= (((uint64_t)(ld[uu][h].y | out)) << 32) | (ld[uu][h].x | out);
-                    x1[part * KB + uu] &= (((uint64_t)(ld[uu][h].w | out)) << 32) | (ld[uu][h].z | out);
-                }
-            }
-        }
-    }
-}
-
-// The same for three- and four-word blocks (stride 4 words) held by ONE lane: two 16-byte gathers per lookup.
-template <int N, int H, int KB, int NW = 4>
-__device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x1)[N], uint64_t (&x2)[N], uint64_t (&x3)[N],
-                                                 const uint32_t (&bn)[N][H], const uint64_t *words, uint32_t slice_shift,
-                                                 const PhaseCfg ph)
-{
-    static_assert(N % KB == 0, "the k-mers of a lane are gathered in batches of KB");
-    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
-    uint32_t done = 0;
-#pragma unroll 1
-    while (done != all) {
-        const uint32_t cur = phase_next_slice(done, ph);
-        done |= 1u << cur;
-        // (EXPERIMENT: bit 31 of slice_shift = the low bits are a slice length in bytes, any multiple of the block size)
-        const bool any_len = (slice_shift >> 31) != 0;
-        const uint32_t span = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << slice_shift;
-        const uint32_t start = any_len ? cur * span : cur << slice_shift;
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(reinterpret_cast<const char *>(words)) + start, 0, (int)span, kBufRsrcWord3);
-#pragma unroll
-        for (int part = 0; part < N / KB; ++part) {
-            rb_u32x4 lo[KB][H], hi[KB][H];
-            rb_u32x2 hi2[KB][H];  // NW == 3: the third word alone (8 bytes)
-#pragma unroll
-            for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    uint32_t off = bn[part * KB + uu][h];
-                    asm volatile("" : "+v"(off));
-                    lo[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, off - start, 0, 0);
-                    // (blocks are 32-byte aligned and never straddle a slice; "no lookup" stays out of range)
-                    if constexpr (NW == 3) hi2[uu][h] = __builtin_amdgcn_raw_buffer_load_b64(rs, (off - start) | 16u, 0, 0);
-                    else hi[uu][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, (off - start) | 16u, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int uu = 0; uu < KB; ++uu) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    uint32_t off = bn[part * KB + uu][h];
-                    asm volatile("" : "+v"(off));
-                    const uint32_t out = (off - start) >= span ? 0xFFFFFFFFu : 0u;
-                    x0[part * KB + uu] &= (((uint64_t)(lo[uu][h].y | out)) << 32) | (lo[uu][h].x | out);
-                    x1[part * KB + uu] &= (((uint64_t)(lo[uu][h].w | out)) << 32) | (lo[uu][h].z | out);
-                    if constexpr (NW == 3) {
-                        x2[part * KB + uu] &= (((uint64_t)(hi2[uu][h].y | out)) << 32) | (hi2[uu][h].x | out);
+                    const int u = part * KB + uu;
+                    if constexpr (NW == 1) {
+                        x0[u] &= (((uint64_t)(lo2[uu][h].y | out)) << 32) | (lo2[uu][h].x | out);
                     } else {
-                        x2[part * KB + uu] &= (((uint64_t)(hi[uu][h].y | out)) << 32) | (hi[uu][h].x | out);
-                        x3[part * KB + uu] &= (((uint64_t)(hi[uu][h].w | out)) << 32) | (hi[uu][h].z | out);
+                        x0[u] &= (((uint64_t)(lo4[uu][h].y | out)) << 32) | (lo4[uu][h].x | out);
+                        x1[u] &= (((uint64_t)(lo4[uu][h].w | out)) << 32) | (lo4[uu][h].z | out);
+                    }
+                    if constexpr (NW == 3) x2[u] &= (((uint64_t)(hi2[uu][h].y | out)) << 32) | (hi2[uu][h].x | out);
+                    if constexpr (NW == 4) {
+                        x2[u] &= (((uint64_t)(hi4[uu][h].y | out)) << 32) | (hi4[uu][h].x | out);
+                        x3[u] &= (((uint64_t)(hi4[uu][h].w | out)) << 32) | (hi4[uu][h].z | out);
                     }
                 }
             }
         }
     }
+}
+
+// one-word blocks (8-byte gathers): x = the word of each of the lane's N k-mers
+template <int N, int H, bool NT, int B = N>
+__device__ __forceinline__ void phased_gather(uint64_t (&x)[N], const uint32_t (&bn)[N][H], const uint64_t *words,
+                                              uint32_t slice_shift, const PhaseCfg ph)
+{
+    phased_window_loop<1, N, H, B>(x, x, x, x, bn, words, slice_shift, ph);
+}
+
+// two-word blocks held by ONE lane (16-byte gathers): x0 / x1 = the two word columns of the lane's N k-mers
+template <int N, int H, int KB>
+__device__ __forceinline__ void phased_gather_x2(uint64_t (&x0)[N], uint64_t (&x1)[N], const uint32_t (&bn)[N][H],
+                                                 const uint64_t *words, uint32_t slice_shift, const PhaseCfg ph)
+{
+    phased_window_loop<2, N, H, KB>(x0, x1, x1, x1, bn, words, slice_shift, ph);
+}
+
+// three- and four-word blocks (stride 4 words) held by ONE lane: two gathers per lookup
+template <int N, int H, int KB, int NW = 4>
+__device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x1)[N], uint64_t (&x2)[N], uint64_t (&x3)[N],
+                                                 const uint32_t (&bn)[N][H], const uint64_t *words, uint32_t slice_shift,
+                                                 const PhaseCfg ph)
+{
+    static_assert(NW == 3 || NW == 4, "narrower blocks have entry points of their own");
+    phased_window_loop<NW, N, H, KB>(x0, x1, x2, x3, bn, words, slice_shift, ph);
 }
 
 // PH = clock-phased gathers (PhaseCfg): for a table of a few L2 sizes -- one- and two-word blocks, 10-20 MB -- every
@@ -517,6 +460,9 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
 // keeps in registers; after n_slices windows every lookup has been served once, in whatever window its slice came up.
 // Nothing depends on the timing but the speed: a wave that is ahead of the clock sleeps until its next window opens, one
 // that is behind never waits, and the result is the same AND of the same words.
+// Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
+// mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves) and of
+// each macro tile the eight-step blocks [blk_first, blk_end) (all STEPS / 8 of them, or a wave's share in the split kernel).
 template <int LG, int WPL, int NP, int H, bool NT, bool PH = false>
 __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
                                              const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
