@@ -1074,10 +1074,16 @@ def replay(ctx, live_leg=True):
         n_live = len(arr)
         lbuf = np.ascontiguousarray(buf.reshape(n, read_len)[rows].reshape(-1))
         lv = capi.Live(eng)
-        warm = capi.Live(eng)
-        warm.process([b"w%d" % i for i in range(64)], [bytes(buf[i * read_len:(i + 1) * read_len]) for i in range(64)])
-        warm.process([b"w%d" % i for i in range(64)], [bytes(buf[i * read_len:(i + 1) * read_len]) for i in range(64)])  # concatenations
-        warm.destroy()
+        # warm-up of everything the timed replay will meet: undecided chunks concatenated to 720 / 1080 / 1440 bp (kernel builds with more
+        # counter planes: their code objects load at first launch, tens of milliseconds), in micro-batches and in a batch large
+        # enough to grow the staging buffers a backlog would need
+        und = idx_und if len(idx_und) >= 64 else np.arange(n)
+        for wn in (64, min(1024, len(und))):
+            warm = capi.Live(eng)
+            rows_w = und[:wn]
+            for _ in range(n_chunks):
+                warm.process([b"w%d" % i for i in range(wn)], [bytes(buf[r * read_len:(r + 1) * read_len]) for r in rows_w])
+            warm.destroy()
         ctx.barrier()
         act, llat, clen, lcalls, lservice, lelapsed = lv.replay_arrivals(ids, lbuf, read_len, arr, max_batch=16384)
         lelapsed = ctx.max_over_ranks([lelapsed])[0]

@@ -270,13 +270,26 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
     for d in (d1, d2):
         assert d["parity"]["decision_mismatches"] == 0 and d["parity"]["raw_max_mismatches"] == 0 and d["parity"]["checked_reads"] > 0
         assert d["parity"]["near_threshold_reads"] > 0  # the sample holds reads on which a count off by a few would flip the decision
-        assert set(d["other_configs"]) >= {"c3np2", "c2", "c4", "c5", "readme", "targets3", "deplete_target"}
-        for leg in ("c3np2", "c2", "c4", "readme", "targets3", "deplete_target"):
+        import bench
+        legs = bench.FULL_LEGS if d is d1 else bench.MULTI_LEGS  # N > 1 carries the multi-GPU configs and the pool legs only
+        assert tuple(d["other_configs"]) == legs
+        for leg in legs:
+            assert "error" not in d["other_configs"][leg], (leg, d["other_configs"][leg].get("error"))
+            if leg.startswith("pool_") or leg == "c5":
+                continue
             par = d["other_configs"][leg]["parity"]
             assert par["decision_mismatches"] == 0 and par["raw_max_mismatches"] == 0 and par["checked_reads"] > 0, leg
-        for leg in ("pool_c3", "pool_c4"):  # one process through rb_pool: outputs equal to a single engine's
-            assert d["other_configs"][leg]["parity"]["pool_outputs_equal_single_engine"] is True, leg
+            if d is d1:
+                assert d["other_configs"][leg]["cpu_baseline"]["value"] > 0, leg  # every throughput leg has its CPU figure at N = 1
+        for leg in ("pool_c3", "pool_c4"):  # one process through rb_pool: outputs equal to a single engine's AND to the oracle's
+            par = d["other_configs"][leg]["parity"]
+            assert par["pool_outputs_equal_single_engine"] is True and par["oracle_mismatches"] == 0 and par["oracle_checked_reads"] > 0, leg
             assert d["other_configs"][leg]["pool"]["per_device"][0]["reads"] > 0
+            assert d["other_configs"][leg]["roofline"]["frac"] > 0 and d["_compact"]["other_configs"][leg]["frac"] > 0
+        _check_line(d, d["n_gpus"])
+        if d is d1:
+            g = d["other_configs"]["grch38_f100k"]  # the reference-default human filter: W = 485, non-power-of-two block count
+            assert g["config"]["filters"][0]["n_bins"] == 31000 and g["parity"]["near_threshold_reads"] > 0
         assert "generic modulus" in d["other_configs"]["c3np2"]["config"]["workload"]
         assert d["other_configs"]["c3np2"]["config"]["filters"][0]["bytes"] % (1 << 20) != 0  # BinSizeBits x 8256: not a power of two
         # (latency SLO and keep-up of the c5 leg: wall-clock figures, asserted by test_c5_leg_meets_its_slo under -m gpuperf)
