@@ -109,6 +109,8 @@ def leg_summary(r):
         out["frac"] = roof["frac"]
     if roof.get("frac_of_measured_read_peak") is not None:
         out["frac_of_read_peak"] = roof["frac_of_measured_read_peak"]
+    if roof.get("fabric_Glines_per_s") is not None:
+        out["Glines_per_s"] = roof["fabric_Glines_per_s"]
     rb = (roof.get("request_bound") or {}).get("request_bound_frac")
     if rb is not None:
         out["request_bound_frac"] = rb
@@ -150,7 +152,8 @@ def compact_line(result, detail_path=None):
             c["config"][k] = _cut(cfg[k], 120)
     if isinstance(roof, dict):
         c["roofline"] = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-        for k in ("kernel", "avg_kernel_ms", "algorithmic_bytes_per_read", "algorithmic_bytes_per_launch", "frac_of_measured_read_peak", "basis"):
+        for k in ("kernel", "avg_kernel_ms", "algorithmic_bytes_per_read", "algorithmic_bytes_per_launch", "frac_of_measured_read_peak",
+                  "traffic_frac_of_measured_read_peak", "fabric_Glines_per_s", "basis"):
             if roof.get(k) is not None:
                 c["roofline"][k] = _cut(roof[k], 120)
         if (roof.get("read_peak_probe") or {}).get("GBps"):
@@ -281,6 +284,94 @@ def visible_gpu_count():
         return None
 
 
+def finish_without_line(why, world, partial_path):
+    """rank 0 ended without its line (a fault inside a leg, a kill, a dead peer): what it had checkpointed -- the headline, measured first,
+    and every leg finished since -- still goes out as the ONE line, with the reason under "error"; with no checkpoint, the error line."""
+    part = None
+    try:
+        if partial_path and os.path.exists(partial_path):
+            part = json.load(open(partial_path))
+    except Exception:  # noqa: BLE001
+        part = None
+    if isinstance(part, dict) and part.get("value"):
+        part["error"] = _cut(str(why), 300) + " -- the line carries what was complete at that point"
+        emit(part)
+    else:
+        error_line(why, world)
+
+
+def supervise(argv):
+    """Rank 0 of every run is a CHILD of this supervisor (started before anything touches the GPU; the supervisor never imports torch
+    and never execs).  The child checkpoints its result after the headline and after every further leg (RB_BENCH_PARTIAL); if it dies --
+    a GPU fault in a leg, a signal, a launcher tearing the job down because a peer rank died -- the supervisor still leaves ONE parseable
+    line on stdout (the checkpoint with an "error", or the bare error line) and exits non-zero.  A clean child is passed through."""
+    import signal
+    import subprocess
+    import tempfile
+    fd, partial = tempfile.mkstemp(prefix="rb_bench_partial_", suffix=".json")
+    os.close(fd)
+    os.unlink(partial)
+    env = dict(os.environ, RB_BENCH_SUPERVISED="1", RB_BENCH_PARTIAL=partial)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE, text=True)
+    killed = []
+
+    def on_term(signum, _frame):  # (the supervisor sits in Python waiting for the child: handlers run at once)
+        killed.append(signum)
+        try:
+            child.terminate()
+        except Exception:  # noqa: BLE001
+            pass
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sg, on_term)
+        except Exception:  # noqa: BLE001
+            pass
+    out = []
+    try:
+        for line in child.stdout:  # (read() would sit in C; iterating returns to the interpreter per line)
+            out.append(line.rstrip("\n"))
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        rc = child.wait(timeout=30)
+    except Exception:  # noqa: BLE001
+        child.kill()
+        rc = child.wait()
+    lines = [l for l in out if l.startswith("{")]
+    for l in out:
+        if not l.startswith("{"):
+            sys.stderr.write(l + "\n")
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    else:
+        why = ("terminated by signal %d (the launcher took the job down: a peer rank died?)" % killed[0]) if killed else \
+              ("rank 0 died with signal %d" % -rc if rc < 0 else "rank 0 exited with code %d and no line" % rc)
+        finish_without_line(why, world, partial)
+        rc = rc or 1
+    try:
+        if os.path.exists(partial):
+            os.unlink(partial)
+    except Exception:  # noqa: BLE001
+        pass
+    sys.exit(rc if rc > 0 else (1 if rc < 0 else 0))
+
+
+def checkpoint(result):
+    """rank 0, supervised: the result so far, where the supervisor finds it if this process does not live to print it"""
+    path = os.environ.get("RB_BENCH_PARTIAL")
+    if not path:
+        return
+    try:
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(_sig(result, 9), f, allow_nan=False)
+        os.replace(tmp, path)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (rank i -> GPU i, RCCL
     rendezvous on 127.0.0.1) and pass rank 0's JSON line through.  This process never initialises the GPU (no HIP call, no
@@ -294,11 +385,17 @@ def launch_ranks(n):
             print("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n, have), file=sys.stderr)
             sys.exit(2)
     port = _free_port()
+    import tempfile
+    fd, partial = tempfile.mkstemp(prefix="rb_bench_partial_", suffix=".json")
+    os.close(fd)
+    os.unlink(partial)
     procs = []
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   RB_BENCH_SELF_LAUNCHED="1")
+                   RB_BENCH_SELF_LAUNCHED="1", RB_BENCH_SUPERVISED="1")  # (this launcher is the supervisor of its ranks)
+        if r == 0:
+            env["RB_BENCH_PARTIAL"] = partial
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
@@ -329,8 +426,13 @@ def launch_ranks(n):
         rc = rc or (p.returncode or 0)
     if not any(l.startswith("{") for l in lines):
         # rank 0 never got to its line (it died, or a dead rank left it in a collective until it was terminated)
-        error_line("no line from rank 0; exit codes of the ranks: %s" % [p.returncode for p in procs], n)
+        finish_without_line("no line from rank 0; exit codes of the ranks: %s" % [p.returncode for p in procs], n, partial)
         rc = rc or 1
+    try:
+        if os.path.exists(partial):
+            os.unlink(partial)
+    except Exception:  # noqa: BLE001
+        pass
     sys.exit(rc if rc >= 0 else 1)
 
 
@@ -640,10 +742,18 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                 "kernel": " + ".join(sorted(forms)), "plan": plans, "avg_kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_read": bytes_per_read,
                 "algorithmic_bytes_per_launch": bytes_per_read * n_reads}
+        if traffic:
+            # the fabric serves LINES: what every wide shape runs into is the chip's rate of 128-byte line requests (c3, c3np2, c4, c2 and the
+            # reference-default GRCh38 filter all sit at 54-55.5 G lines/s, profiles/r05/line_rate_invariant.md), so a shape whose blocks
+            # do not fill their lines (c4's 600-bin target: 80 of 128 bytes; W = 485: 3 880 of 3 968) shows a lower ALGORITHMIC fraction at
+            # the same line rate
+            roof["fabric_Glines_per_s"] = traffic / 128.0 / avg_kernel_s / 1e9
         if probe:
             roof["read_peak_probe"] = probe
             if probe.get("GBps"):
                 roof["frac_of_measured_read_peak"] = achieved / probe["GBps"]
+                if traffic:
+                    roof["traffic_frac_of_measured_read_peak"] = traffic / avg_kernel_s / 1e9 / probe["GBps"]
         # Narrow filters (blocks of less than a cache line, tables of a few L2 sizes) are bound by REQUESTS, not bytes: every lookup is
         # one request to an XCD's L2, and every miss one 128-byte line request to the fabric.  Their roofline is
         #   t >= max( misses / (fabric line rate),  (hits + misses) / (L2 request rate) ),
@@ -1272,6 +1382,11 @@ def null_engine_run(args, torch, dist, world, rank, backend):
     if os.environ.get("RB_BENCH_TEST_DIE_RANK") == str(rank):  # tests: the launcher must not hang on a dead rank
         os._exit(7)
     head = leg(args.workload or "c3", args.steps, args.bin_sharded)
+    if rank == 0:
+        checkpoint(head)
+    if os.environ.get("RB_BENCH_TEST_DIE_LATE") == str(rank):  # tests: a process that dies AFTER the headline (a fault in a later leg)
+        time.sleep(0.3)
+        os.kill(os.getpid(), 11)  # SIGSEGV, like a GPU fault would end it
     others = {}
     if not args.workload and not args.bin_sharded and not args.no_extras:
         for name in default_leg_names(world):
@@ -1296,6 +1411,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)  # before anything touches the GPU
+    if int(os.environ.get("RANK", "0")) == 0 and os.environ.get("RB_BENCH_SUPERVISED") != "1" and os.environ.get("RB_BENCH_NO_SUPERVISOR") != "1":
+        return supervise(sys.argv[1:])  # N = 1, or rank 0 under torchrun: the measuring process is a child of this one
     import torch
 
     t_start = time.time()
@@ -1360,6 +1477,9 @@ def main():
                                "self_launched": os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1",
                                "same_gpu_test_hook": same_gpu, "devices": infos,
                                "per_rank_reads_per_s": result.pop("per_rank_reads_per_s"), "xgmi_preflight": pre}
+            checkpoint(result)  # the headline is safe from here on, whatever a later leg does to this process
+        if os.environ.get("RB_BENCH_TEST_DIE_RANK") == str(rank) and not no_engine:  # tests: a rank that dies after the headline
+            os._exit(7)
     if extras:
         # the other BASELINE configs, by all ranks, after the headline measurement; a failure is reported, never raised
         others = {}
@@ -1402,7 +1522,14 @@ def main():
                 if isinstance(r, dict):
                     r.pop("per_rank_reads_per_s", None)
                     r["leg_seconds"] = round(time.time() - t_leg, 2)
+                    try:  # HBM in use on this rank's device once the leg is over (every process on it: with the same-GPU test hook, all ranks)
+                        free_b, total_b = torch.cuda.mem_get_info(dev_index)
+                        r["hbm_in_use_after_leg_bytes"] = int(total_b - free_b)
+                    except Exception:  # noqa: BLE001
+                        pass
                 others[lname] = r
+                result["other_configs"] = others
+                checkpoint(result)
         if rank == 0:
             result["other_configs"] = others
             if getattr(ctx, "_pool_child", None) is not None and "ranks" in result:
@@ -1447,7 +1574,7 @@ def guarded_main():
         traceback.print_exc(file=sys.stderr)
         if rank == 0:
             try:
-                error_line("%s: %s" % (type(ex).__name__, ex), world)
+                finish_without_line("%s: %s" % (type(ex).__name__, ex), world, os.environ.get("RB_BENCH_PARTIAL"))
             except Exception:  # noqa: BLE001
                 pass
         sys.stderr.flush()

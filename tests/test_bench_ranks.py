@@ -65,7 +65,7 @@ def _check_line(d, n_gpus):
     assert c["n_gpus"] == n_gpus and c["value"] == pytest.approx(d["value"], rel=1e-4)
     assert isinstance(c["config"]["workload"], str) and "model" not in c["config"]
     for leg, row in (c.get("other_configs") or {}).items():
-        assert set(row) <= {"value", "ms_per_step", "frac", "frac_of_read_peak", "request_bound_frac", "p99_ms", "live_p99_ms", "cpu_reads_per_s",
+        assert set(row) <= {"value", "ms_per_step", "frac", "frac_of_read_peak", "Glines_per_s", "request_bound_frac", "p99_ms", "live_p99_ms", "cpu_reads_per_s",
                             "parity_ok", "checked_reads", "error"}, (leg, row)
         assert len(json.dumps(row)) < 300
     return c
@@ -153,6 +153,32 @@ def test_dead_rank_does_not_hang_the_launcher():
     p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "200"],
                 dict(CPU_HOOKS, RB_BENCH_TEST_DIE_RANK="0"), timeout=120)
     assert p.returncode != 0 and d is not None and d["_compact"]["value"] == 0 and d["_compact"]["error"]
+
+
+def test_headline_survives_a_process_that_dies_later_cpu():
+    """Rank 0 measures as a child of a supervisor and checkpoints its result after the headline and after every leg: a process that
+    dies later (SIGSEGV here, as a GPU fault in a sub-leg would end it) still leaves ONE parseable line -- the headline with an
+    `error` -- and a non-zero exit code.  N = 1 (the driver's own command), N = 2 self-launched (rank 0 dies; then rank 1 dies and
+    takes the job down), and under torchrun, which answers a dead rank by sending SIGTERM to the others."""
+    p, d = _run(["--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "300"], dict(CPU_HOOKS, RB_BENCH_TEST_DIE_LATE="0"), timeout=120)
+    assert p.returncode != 0 and d is not None
+    c = d["_compact"]
+    assert c["value"] > 0 and c["steps"] == 2 and "signal 11" in c["error"] and len(d["_line"]) <= 4096
+    assert len([l for l in p.stdout.splitlines() if l.startswith("{")]) == 1
+    for die in ("0", "1"):
+        p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300"], dict(CPU_HOOKS, RB_BENCH_TEST_DIE_LATE=die), timeout=120)
+        assert p.returncode != 0 and d is not None, die
+        assert d["_compact"]["value"] > 0 and d["_compact"]["n_gpus"] == 2 and d["_compact"]["error"], die
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)]
+    p, d = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--reads", "300"], dict(CPU_HOOKS, RB_BENCH_TEST_DIE_LATE="1"), timeout=180,
+                launcher=launcher)
+    assert p.returncode != 0 and d is not None, p.stderr[-1500:]
+    assert d["_compact"]["value"] > 0 and d["_compact"]["error"]
 
 
 @pytest.mark.parametrize("n", [1, 8])
