@@ -40,5 +40,5 @@ for name, nt, overlap in (("default: deplete NT, target temporal, side by side",
     per = ms / 6
     byts = synth.algorithmic_bytes_per_read(L, [(8192, 13, 3), (600, 13, 3)]) * N
     lines = N * 2 * 348 * 3 * (8 + 1)
-    print("%-52s K1 %7.2f ms per 2 M reads  %.4f of 8 TB/s  %.2f G lines/s  sha %s" % (name, per, byts / per / 1e6 / 8000.0 / 1e3 * 1e3 / 1e3, lines / per / 1e6, sha), flush=True)
+    print("%-52s K1 %7.2f ms per 2 M reads  %.4f of 8 TB/s  %.2f G lines/s  sha %s" % (name, per, byts / (per / 1e3) / 8e12, lines / per / 1e6, sha), flush=True)
     eng.destroy()

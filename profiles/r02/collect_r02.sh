@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 evidence in one go (on the GPU box): bash profiles/collect_r02.sh <tag>
+# Round-2 evidence in one go (on the GPU box): bash profiles/r02/collect_r02.sh <tag>
 TAG=${1:-r02e}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 evidence in one go (on the GPU box): bash profiles/collect_r03.sh <tag> ; then here:
+# Round-3 evidence in one go (on the GPU box): bash profiles/r03/collect_r03.sh <tag> ; then here:
 #   RB_EVIDENCE_DATE=<date> python3 profiles/summarize.py gpurun_out/<tag> profiles/r03
 TAG=${1:-r03e}
 R=${GRAFT_REPO_ROOT:-/root/repo}

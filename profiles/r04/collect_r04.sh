@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 evidence in one go (on the GPU box): bash profiles/collect_r04.sh <tag> ; then here:
+# Round-4 evidence in one go (on the GPU box): bash profiles/r04/collect_r04.sh <tag> ; then here:
 #   RB_EVIDENCE_DATE=<date> python3 profiles/summarize.py gpurun_out/<tag> profiles/r04
 # (the round's working sessions used profiles/collect_r04_s<N>.sh; this is their union on the final tree)
 TAG=${1:-r04f}
