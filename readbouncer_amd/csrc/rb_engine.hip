@@ -1112,8 +1112,10 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
             // the four-word one-lane builds: slices of equal length, fewer than the 4 MiB ones (rb_phase_plan.h, phase_equal_slices)
             uint64_t blocks_per_slice = 0;
-            if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || e->phase_n_slices)) {
-                uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes) : 0;
+            const bool one_word_rule = f->stride == 1 && a.lg == 0 && phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) != 0;
+            if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || one_word_rule || e->phase_n_slices)) {
+                uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes)
+                                : one_word_rule ? phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) : 0;  // (one-word tables from 50 MiB on)
                 if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
                 if (want >= 1 && want <= e->phase_max_slices && want < n_sl) {
                     // the kernels carry blocks-per-slice in 31 bits and the slice's span in BYTES in 31 bits as well (bit 31 is the
@@ -1127,6 +1129,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
                 }
             }
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
+                             : (blocks_per_slice && one_word_rule && !e->phase_n_slices) ? phase_equal_slices_one_word_ticks(shape, n_sl, table_bytes, kmers)
                              : blocks_per_slice ? phase_equal_slices_ticks(shape, a.lg, n_sl, kmers)
                                                 : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
             a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);

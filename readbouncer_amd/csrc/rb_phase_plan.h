@@ -241,6 +241,34 @@ inline uint64_t phase_equal_slices_ticks(PhaseShape shape, int lg, uint32_t n_sl
 }
 
 
+// One-word tables of 50 MiB and more (a 64-bin filter of a 35-80 Mbp genome): equal-length slices LONGER than an L2, fewer of them, a
+// longer cycle.  Every slice is one more pass of a wave over all its predicated loads; from ~50 MiB on that costs more than the L2 hits a
+// 4 MiB slice buys (profiles/r05/one_word_equal_slices*.txt, 250 bp, K1 ms per 1 M reads, rule of 4 MiB slices -> best equal slices):
+// 56 MiB 13.6 -> 12.2 (11 slices), 64: 14.0 -> 13.1 (13), 80: 16.0 -> 14.1 (13), 96: 17.7 -> 15.1 (15), 112: 19.5 -> 15.9 (14),
+// 127: 21.4 -> 16.8 (16); 360 bp: 64 MiB 21.4 -> 19.6, 96: 26.1 -> 23.1, 127: 32.1 -> 25.6; up to 48 MiB within 2 %.  The best slice
+// length grows with the table (4.9 MiB at 56, 6.2 at 80, 8 at 112-127): n = round(MiB / (2.5 + 0.044 MiB)); the best cycle (window x
+// slices) is 8 000-9 000 ticks at 56-64 MiB and 12 000 at 112-127: 5 600 + 54 per MiB, x 1.24 for the six-tile build, and -- like every
+// curve of this file -- shorter for reads that leave the shape partly empty.  The optima are narrow (a window 10 % short falls off the
+// cliff: 80 MiB, 13 slices: 692 ticks 15.8 ms, 769 ticks 14.1); rb_engine_calibrate refines them per device.
+constexpr uint64_t kOneWordEqualFrom = 50_MiB;  // (48 MiB: within 2 % either way; 52 MiB: 13.4 -> 11.6-12.1 ms)
+inline uint32_t phase_equal_slices_one_word(PhaseShape shape, int lg, uint32_t slice_log2, uint64_t table_bytes)
+{
+    if (lg != 0 || slice_log2 != 22 || table_bytes < kOneWordEqualFrom) return 0;
+    if (shape != PhaseShape::FourTiles && shape != PhaseShape::SixTiles) return 0;
+    const double mib = (double)table_bytes / 1048576.0;
+    const uint32_t n = (uint32_t)std::lround(mib / (2.5 + 0.044 * mib));
+    const uint32_t pow2 = (uint32_t)((table_bytes + (4_MiB - 1)) / 4_MiB);
+    return n >= 2 && n < pow2 ? n : 0;
+}
+
+inline uint64_t phase_equal_slices_one_word_ticks(PhaseShape shape, uint32_t n_slices, uint64_t table_bytes, uint32_t kmers)
+{
+    const double mib = (double)table_bytes / 1048576.0;
+    const double fill = phase_fill(shape, kmers);
+    const double cycle = (5600.0 + 54.0 * mib) * (shape == PhaseShape::SixTiles ? 1.24 : 1.0) * (0.5 + 0.5 * (fill < 1.0 ? fill : 1.0));
+    return (uint64_t)(cycle / (double)std::max(n_slices, 1u));
+}
+
 // from which table size on the phased form pays ...
 inline uint64_t phase_shape_min_bytes(PhaseShape shape, int lg, double fill)
 {

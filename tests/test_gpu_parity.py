@@ -1458,3 +1458,38 @@ def test_equal_length_slices_through_the_planner():
         eng.set_phase_slices()
     eng.destroy()
     d.free()
+
+
+def test_equal_length_slices_of_large_one_word_tables():
+    """One-word tables from 50 MiB on are walked in fewer, equal-length slices that are LONGER than an L2 (rb_phase_plan.h,
+    phase_equal_slices_one_word: 56 MiB -> 11 slices of 5.1 MiB instead of 14 of 4 MiB): the plan says so, the maxima equal the
+    oracle's and those of the 4 MiB slices, for the four-tile build (250 bp) and the six-tile build (360 bp); 48 MiB keeps 4 MiB slices."""
+    rng = np.random.default_rng(8090)
+    ref = H.random_dna(rng, 60000)
+    n_blocks = 56 * (1 << 20) // 8 - 5  # one-word blocks: 56 MiB
+    d = capi.DeviceIBF.create(0, 64, 3, 13, 64 * n_blocks)
+    d.fill_synth(23)
+    d.add_sequence(ref, 1000)
+    o, _keep = oracle_view(d)
+    eng = capi.Engine(0, [d], [])
+    for L, shape in ((250, "four tiles"), (360, "six tiles")):
+        reads = make_reads(np.random.default_rng(L + 1), ref, 4200, lo=L - 60, hi=L + 1, err=0.05)
+        buf, offs, lens = H.pack_reads(reads)
+        exp = po.batch_raw_max(o, buf, offs, lens, 8)
+        pl = eng.plan(0, len(reads), L)
+        assert pl["phased"] == 1 and pl["phase_shape_name"].startswith(shape), pl
+        assert pl["phase_slices"] == 11 and pl["phase_slice_bytes"] == -(-n_blocks // 11) * 8 and pl["phase_slice_bytes"] > (4 << 20), pl
+        assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], exp)
+        eng.set_phase_slices(22, 32)  # the slices of 2^22 bytes they replace
+        p2 = eng.plan(0, len(reads), L)
+        assert p2["phase_slices"] == 14 and p2["phase_slice_bytes"] == 1 << 22
+        assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], exp)
+        eng.set_phase_slices()
+    eng.destroy()
+    d.free()
+    small = capi.DeviceIBF.create(0, 64, 3, 13, 64 * (48 * (1 << 20) // 8 - 5))
+    e2 = capi.Engine(0, [small], [])
+    p3 = e2.plan(0, 5000, 250)
+    assert p3["phased"] == 1 and p3["phase_slices"] == 12 and p3["phase_slice_bytes"] == 1 << 22, p3
+    e2.destroy()
+    small.free()

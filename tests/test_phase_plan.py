@@ -57,6 +57,41 @@ int main() {
     assert "5200u / n" in hdr and "3600u / n" in hdr  # the three-word builds' window floors (profiles/r04/equal_slices_three_word_builds.txt)
 
 
+def test_equal_length_slices_of_large_one_word_tables(tmp_path):
+    """phase_equal_slices_one_word (rb_phase_plan.h): one-word tables from 50 MiB on, four- and six-tile builds only -- slice counts and
+    windows at the sizes of profiles/r05/one_word_equal_slices*.txt"""
+    src = tmp_path / "ow.cpp"
+    src.write_text('''
+#include <cstdint>
+#include <cstdio>
+#include "%s"
+using namespace rbplan;
+int main() {
+    const double mib[] = {40, 48, 49.9, 50, 56, 64, 80, 96, 112, 127};
+    for (double m : mib) {
+        const uint64_t b = (uint64_t)(m * 1048576.0);
+        const uint32_t n4 = phase_equal_slices_one_word(PhaseShape::FourTiles, 0, 22, b), n6 = phase_equal_slices_one_word(PhaseShape::SixTiles, 0, 22, b);
+        std::printf("%%.1f %%u %%u %%u %%u %%u %%llu %%llu %%llu\\n", m, n4, n6, phase_equal_slices_one_word(PhaseShape::FourTiles, 1, 22, b),
+                    phase_equal_slices_one_word(PhaseShape::FourTiles, 0, 21, b), phase_equal_slices_one_word(PhaseShape::Rounds, 0, 22, b),
+                    (unsigned long long)phase_equal_slices_one_word_ticks(PhaseShape::FourTiles, n4 ? n4 : 1, b, 238),
+                    (unsigned long long)phase_equal_slices_one_word_ticks(PhaseShape::SixTiles, n6 ? n6 : 1, b, 348),
+                    (unsigned long long)phase_equal_slices_one_word_ticks(PhaseShape::FourTiles, n4 ? n4 : 1, b, 188));
+    }
+}
+''' % os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h"))
+    exe = str(tmp_path / "ow")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", str(src), "-o", exe])
+    rows = {float(r[0]): [int(x) for x in r[1:]] for r in (l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())}
+    assert [rows[m][0] for m in (40, 48, 49.9, 50, 56, 64, 80, 96, 112, 127)] == [0, 0, 0, 11, 11, 12, 13, 14, 15, 16]
+    for m, r in rows.items():
+        assert r[0] == r[1] and r[2] == r[3] == r[4] == 0  # both one-word builds alike; not two-word blocks, not 2 MiB slices, not the rounds
+        if r[0]:
+            assert m / r[0] > 4.0  # slices longer than an L2 ...
+            assert 0.9 * (5600 + 54 * m) / r[0] <= r[5] <= (5600 + 54 * m) / r[0] + 1  # ... a cycle of 5 600 + 54 per MiB ticks
+            assert 1.2 < r[6] / r[5] < 1.28 and 0.85 < r[7] / r[5] < 0.95  # six tiles x 1.24; 200 bp reads leave the shape partly empty
+    assert 660 <= rows[80][5] <= 800 and 700 <= rows[127][5] <= 800  # (the measured optima: 769-807 ticks at 80 MiB / 13 slices, 750 at 127 MiB / 16)
+
+
 def test_every_shape_has_a_named_row():
     hdr = open(os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h")).read()
     for name in ("General", "FourTiles", "Rounds", "SixTiles", "WideRounds", "WideFourTiles", "Wide3FourTiles", "Wide3Rounds"):
