@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p "$OUT"
 echo "$N" > "$OUT/reads.txt"
 cd /tmp && export TMPDIR=/tmp
+export RB_BENCH_NO_SUPERVISOR=1  # the profiled process is the one that measures (bench.py would otherwise run rank 0 as a child of a supervisor)
 ARGS="--workload $W --reads $N --steps 2 --warmup 1 --no-cpu-baseline --no-latency $EXTRA"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$R/bench.py" $ARGS > "$OUT/fetch.log" 2>&1
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$OUT/l2" -- python3 "$R/bench.py" $ARGS > "$OUT/l2.log" 2>&1

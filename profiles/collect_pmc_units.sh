@@ -6,6 +6,7 @@ W=$1; N=$2; OUT=$3; EXTRA=${4:-}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+export RB_BENCH_NO_SUPERVISOR=1  # the profiled process is the one that measures (bench.py would otherwise run rank 0 as a child of a supervisor)
 ARGS="--workload $W --reads $N --steps 2 --warmup 1 --no-cpu-baseline --no-latency $EXTRA"
 pass() { # tag counters...
   local tag=$1; shift

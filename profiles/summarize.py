@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(src, "bench_*.json")) + glob.glob(os.path.join(s
     shutil.copy(f, dst)
 if os.path.exists(os.path.join(src, "hbm_peak.txt")):
     shutil.copy(os.path.join(src, "hbm_peak.txt"), os.path.join(dst, "hbm_peak_raw.txt"))
-for w in ("c2", "c3", "c3np2", "grch38_f100k", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
+for w in ("c2", "c3", "c3np2", "grch38_f100k", "c4", "c5", "readme", "readme360", "readme_phased", "readme360_phased", "c1", "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart", "default"):
     hits = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if hits:
         shutil.copy(hits[0], os.path.join(dst, w + "_kernel_stats.csv"))
