@@ -33,6 +33,15 @@ def test_boundary_header_holds_no_lab_equipment():
     assert len(main) >= 50 and len(tuning) >= 20
 
 
+def test_integration_recipe_names_every_call():
+    """INTEGRATION.md section 1 maps every call of the boundary header to the reference interface it replaces, section 1b lists the
+    tuning header's: no export without a line there"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    one, one_b = text.split("### 1b.")[0], text.split("### 1b.")[1].split("Error conventions")[0]
+    assert [s for s in declared_symbols(HEADERS[:1]) if s not in one] == []
+    assert [s for s in declared_symbols(HEADERS[1:]) if s not in one_b] == []
+
+
 def test_library_exports_every_declared_symbol():
     decl = declared_symbols()
     assert len(decl) >= 30
