@@ -802,6 +802,10 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                               "table size, its misses = the share beyond the L2); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
             except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
                 roof["request_bound"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
+        try:  # tables of >= 1 GiB are placed by trial (rb_set_placement_tries): allocations probed, GB/s of the kept and of the slowest one
+            roof["placement"] = [dict(zip(("tries", "kept_GBps", "slowest_GBps"), f.placement())) for f in filters]
+        except Exception:  # noqa: BLE001
+            pass
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
         if table_bytes < (256 << 20) * 4:
             roof["note"] = ("table of %.2f GB against a 256 MiB Infinity Cache: part of the gathers are served on-die; "
@@ -1446,6 +1450,10 @@ def main():
     if no_engine:
         return null_engine_run(args, torch, dist, world, rank, backend)
     torch.cuda.set_device(dev_index)
+    if same_gpu and world > 2:
+        # (test hook: many ranks on ONE device -- every rank's placement trial would hold up to five copies of an 8 GiB table at once)
+        from readbouncer_amd import capi as _capi
+        _capi.set_placement_tries(1)
     ctx = Ctx(args, torch, dist, world, rank, dev_index, backend, same_gpu, force_group)
     bin_sharded = args.bin_sharded and (world > 1 or force_group)
 

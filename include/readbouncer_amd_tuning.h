@@ -59,6 +59,17 @@ RB_API int rb_live_replay_arrivals(rb_live *lv, const uint32_t *read_ids, const 
                                    uint32_t *out_classified_len, uint32_t *out_call_reads, double *out_call_service_s,
                                    size_t call_cap, size_t *out_calls, double *out_elapsed_s);
 
+/* ---- where a large table lies in HBM ---------------------------------------------------------------
+ * Filters of 1 GiB and more are placed by trial: the same table gathers 1.7-2.9 % slower or faster from one allocation of a process to
+ * the next (where the driver finds the pages -- an 8 GiB power-of-two table always gets the fast kind, a reference-sized 4.7 GB one does
+ * or does not), so rb_dibf_create / _upload / _open / _clone_to / _resize_bins allocate up to `tries` candidates (default 5), probe each
+ * with random whole-block gathers (~0.1 s), stop early only when one is 3 % faster than the slowest seen, keep the best and free the others.
+ * Transient cost: up to (tries - 1) x the table of HBM at load time (never more than half of what is free).  tries = 0 or 1: off.
+ * Process-wide; results never depend on it.  rb_dibf_placement: how many allocations were probed for this filter (0: not placed by
+ * trial), what the kept one and the slowest one delivered in GB/s. */
+RB_API int rb_set_placement_tries(int tries);
+RB_API int rb_dibf_placement(const rb_dibf *f, uint32_t *tries, double *kept_gbps, double *worst_gbps);
+
 /* ---- engine: kernel forms, planner, timing, probe ------------------------------------------------ */
 /* Filters of one hash geometry in one table.  Every filter the reference builds with one fragment_size has noOfBits =
  * BinSizeBits x 64 x binWidth (src/IBF/IBFBuild.cpp:404-413), i.e. the same noOfBlocks whatever its bin count; with equal k and

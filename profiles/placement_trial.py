@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Does K1 follow the probe from one allocation of a table to another within ONE process?  (profiles/placement_probe.py: the first
+allocations of a 4.7 GB table probe 1.5-2.5 % slower than later ones.)  Allocates the table N times, probes each, then times K1 (2 M reads,
+one launch) on the slowest- and the fastest-probing copy."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from readbouncer_amd import capi, synth  # noqa: E402
+
+key = sys.argv[1] if len(sys.argv) > 1 else "c3np2"
+n_alloc = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+w = synth.WORKLOADS[key]
+dev = torch.device("cuda:0")
+row = 4096 if key == "grch38_f100k" else 1024
+cands = []
+for i in range(n_alloc):
+    d, ref = synth.build_device_filter(0, w, fill_seed=4, plant_seed=40)
+    torch.cuda.synchronize()
+    g = max(d.probe_read_peak(row, True, 24, target_ms=60.0)[0] for _ in range(2))
+    cands.append((g, i, d))
+    print("allocation %d at 0x%x: probe %.0f GB/s" % (i, d.device_words(), g), flush=True)
+N, L = 2_000_000, 360
+seqs, offs, lens = synth.make_reads_device(1234, N, L, ref, dev)
+mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
+cands.sort(key=lambda c: c[0])
+byts = synth.algorithmic_bytes_per_read(L, [(w["n_bins"], w["k"], w["h"])]) * N
+shas = []
+for label, (g, i, d) in (("slowest probe", cands[0]), ("fastest probe", cands[-1]), ("slowest probe", cands[0]), ("fastest probe", cands[-1])):
+    eng = capi.Engine(0, [d], [])
+    eng.set_timing(True)
+    for it in range(5):
+        if it == 2:
+            eng.kernel_time()
+        eng.classify_device(seqs.data_ptr(), offs.data_ptr(), lens.data_ptr(), N, L, d_maxcount=mc.data_ptr())
+    torch.cuda.synchronize()
+    ms, calls = eng.kernel_time()
+    shas.append(int(mc.to(torch.int64).sum()))
+    print("%s (allocation %d, %.0f GB/s): K1 %.2f ms per 2 M reads = %.4f of 8 TB/s" % (label, i, g, ms / calls, byts / (ms / calls / 1e3) / 8e12), flush=True)
+    eng.destroy()
+assert len(set(shas)) == 1

@@ -47,7 +47,11 @@ for r in csv.DictReader(open(sys.argv[1])):
         print("  ", r["Name"].split("(")[0][-70:], r["Calls"], "avg ms %.4f" % (float(r["AverageNs"])/1e6))
 PY
 done
-find $OUT -name "*.db" -delete; find $OUT -path "*pmc_*" -name "*.csv" -size +2000k -delete
+# gpurun brings back at most 64 MiB: the per-dispatch traces are not evidence (the stats tables are), and the default run's c5 leg alone
+# launches 150 k kernels
+find $OUT -name "*.db" -delete; find $OUT -path "*stats_*" -name "*kernel_trace.csv" -delete; find $OUT -path "*stats_*" -name "*agent_info.csv" -delete
+find $OUT -path "*pmc_*" -name "*.csv" -size +2000k -delete; find $OUT -path "*pmc_*" -name "*kernel_trace.csv" -delete
+du -sm $OUT | cut -f1 | xargs echo "MiB under $OUT:"
 cd $R
 for f in $OUT/bench_*.json; do case $f in *_line.json) continue;; esac; python3 - "$f" <<'PY'
 import json,sys

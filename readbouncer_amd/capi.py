@@ -122,6 +122,8 @@ SIGNATURES = {
     "rb_dibf_clone_to_ex": (_int, [_vp, _int, _pp, C.POINTER(_int), C.POINTER(_dbl)]),
     "rb_engine_set_revcomp_of_n": (_int, [_vp, _u32]),
     "rb_set_default_revcomp_of_n": (_int, [_u32]),
+    "rb_set_placement_tries": (_int, [_int]),
+    "rb_dibf_placement": (_int, [_vp, C.POINTER(_u32), C.POINTER(_dbl), C.POINTER(_dbl)]),
     "rb_engine_set_merge": (_int, [_vp, _int]),
     "rb_engine_merge_info": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
@@ -299,6 +301,12 @@ class DeviceIBF:
         _check(lib().rb_dibf_probe_read_peak(self.h, table_bytes, row_bytes, int(bool(nontemporal)), loads_in_flight, target_ms,
                                              C.byref(g), C.byref(ms)), "rb_dibf_probe_read_peak")
         return g.value, ms.value
+
+    def placement(self):
+        """-> (allocations probed for this table: 0 = not placed by trial, GB/s of the kept one, GB/s of the slowest one)"""
+        t, g, w = _u32(0), _dbl(0.0), _dbl(0.0)
+        _check(lib().rb_dibf_placement(self.h, C.byref(t), C.byref(g), C.byref(w)), "rb_dibf_placement")
+        return t.value, g.value, w.value
 
     def resize_bins(self, new_bins):
         h = C.c_void_p()
@@ -700,6 +708,11 @@ class HostBlock:
             self.array = None
             lib().rb_host_free(self.ptr)
             self.ptr = None
+
+
+def set_placement_tries(tries):
+    """process-wide: candidates a table of >= 1 GiB is allocated and probed as (default 5; 0 / 1 = off)"""
+    _check(lib().rb_set_placement_tries(int(tries)), "rb_set_placement_tries")
 
 
 def pack_reads(seqs, offsets, lens):

@@ -26,6 +26,9 @@ void write_metadata(uint64_t *tail, unsigned shift, const uint64_t meta[4]);
 bool metadata_plausible(const uint64_t meta[4], uint64_t n_bits);
 bool calculate_ci(double r, uint8_t k, uint32_t readlen, double confidence, uint16_t *low, uint16_t *high);
 uint16_t threshold_u16(uint64_t readlen, uint64_t kmer_size, double r, double confidence);
+// rb_probe.hip: the read-peak probe on a bare block of device memory of the current device
+int probe_read_peak_raw(const void *table, uint64_t table_bytes, uint32_t row_bytes, int nontemporal, uint32_t loads_in_flight,
+                        double target_ms, double *gbps_out, double *ms_out);
 
 }  // namespace rb
 

@@ -79,23 +79,16 @@ hipError_t probe_dispatch(bool nt, int b, const uint8_t *base, uint32_t n_rows, 
 
 }  // namespace
 
-extern "C" int rb_dibf_probe_read_peak(rb_dibf *f, uint64_t table_bytes, uint32_t row_bytes, int nontemporal, uint32_t loads_in_flight,
-                                       double target_ms, double *gbps_out, double *ms_out)
+// the probe on a bare block of device memory (the current device): rb_dibf_probe_read_peak below, and the placement trials of
+// rb_engine.hip (dibf_alloc), which probe a table before it belongs to a filter
+int rb::probe_read_peak_raw(const void *table, uint64_t table_bytes, uint32_t row_bytes, int nontemporal, uint32_t loads_in_flight,
+                            double target_ms, double *gbps_out, double *ms_out)
 {
-    if (!f || !gbps_out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
-    {
-        rb_ibf_info g;
-        int rc = rb_dibf_get_info(f, &g);
-        if (rc != RB_OK) return rc;
-        const uint64_t whole = g.n_blocks * rb_dibf_device_stride(f) * 8;  // the table as it lies in HBM
-        if (table_bytes == 0) table_bytes = whole;
-        if (table_bytes > whole) return rb::fail(RB_ERR_INVALID_ARG, "probe table_bytes beyond the filter's table");  // (would gather out of bounds)
-    }
+    if (!table || !gbps_out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
     if (row_bytes != 128 && row_bytes != 1024 && row_bytes != 4096) return rb::fail(RB_ERR_INVALID_ARG, "probe rows are 128, 1024 or 4096 bytes");
     if (table_bytes < row_bytes || table_bytes / row_bytes >= (1ull << 32)) return rb::fail(RB_ERR_INVALID_ARG, "probe table size");
-    hipError_t e = hipSetDevice(rb_dibf_device(f));
-    if (e != hipSuccess) return rb::fail(e == hipErrorNoDevice ? RB_ERR_NO_DEVICE : RB_ERR_HIP, hipGetErrorString(e));
-    const uint8_t *base = (const uint8_t *)rb_dibf_device_words(f);
+    hipError_t e = hipSuccess;
+    const uint8_t *base = (const uint8_t *)table;
     const uint32_t n_rows = (uint32_t)(table_bytes / row_bytes);
     const int b = loads_in_flight >= 24 ? 24 : 12;
     const uint32_t blocks = 256u * 32u;  // 32 768 waves: 32 per SIMD, several rounds of residency
@@ -144,4 +137,19 @@ extern "C" int rb_dibf_probe_read_peak(rb_dibf *f, uint64_t table_bytes, uint32_
     *gbps_out = best_gbps;
     if (ms_out) *ms_out = best_ms;
     return RB_OK;
+}
+
+extern "C" int rb_dibf_probe_read_peak(rb_dibf *f, uint64_t table_bytes, uint32_t row_bytes, int nontemporal, uint32_t loads_in_flight,
+                                       double target_ms, double *gbps_out, double *ms_out)
+{
+    if (!f || !gbps_out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
+    rb_ibf_info g;
+    int rc = rb_dibf_get_info(f, &g);
+    if (rc != RB_OK) return rc;
+    const uint64_t whole = g.n_blocks * rb_dibf_device_stride(f) * 8;  // the table as it lies in HBM
+    if (table_bytes == 0) table_bytes = whole;
+    if (table_bytes > whole) return rb::fail(RB_ERR_INVALID_ARG, "probe table_bytes beyond the filter's table");  // (would gather out of bounds)
+    hipError_t e = hipSetDevice(rb_dibf_device(f));
+    if (e != hipSuccess) return rb::fail(e == hipErrorNoDevice ? RB_ERR_NO_DEVICE : RB_ERR_HIP, hipGetErrorString(e));
+    return rb::probe_read_peak_raw(rb_dibf_device_words(f), table_bytes, row_bytes, nontemporal, loads_in_flight, target_ms, gbps_out, ms_out);
 }

@@ -235,7 +235,8 @@ ZERO_SWEEP = r"""
 import ctypes as C, sys
 from readbouncer_amd import capi
 L = capi.lib()
-ok_allowed = {"rb_device_count", "rb_is_ibf_file", "rb_calculate_ci", "rb_pack_reads"}   # fine with zeros (an empty batch packs to nothing)
+ok_allowed = {"rb_device_count", "rb_is_ibf_file", "rb_calculate_ci", "rb_pack_reads",   # fine with zeros (an empty batch packs to nothing)
+              "rb_set_placement_tries"}                                                   # (0 tries = placement by trial off: a valid setting)
 report = []
 for name, (restype, argtypes) in sorted(capi.SIGNATURES.items()):
     args = []

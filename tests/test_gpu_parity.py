@@ -1493,3 +1493,41 @@ def test_equal_length_slices_of_large_one_word_tables():
     assert p3["phased"] == 1 and p3["phase_slices"] == 12 and p3["phase_slice_bytes"] == 1 << 22, p3
     e2.destroy()
     small.free()
+
+
+def test_large_tables_are_placed_by_trial():
+    """A table of 1 GiB and more is allocated two to five times, every candidate probed with random whole-block gathers, the best kept
+    (rb_set_placement_tries; profiles/r05/placement_*.txt: the same table gathers 1.7-2.9 % slower or faster from one allocation to the
+    next).  Nothing but the address depends on it: the filter round-trips and classifies like its oracle view; tries = 1 switches it off;
+    small tables are never tried."""
+    rng = np.random.default_rng(99)
+    ref = H.random_dna(rng, 30000)
+    n_blocks = (1200 << 20) // 1024  # 8192 bins: 1 KiB blocks, 1.17 GiB
+    d = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * n_blocks)
+    tries, kept, worst = d.placement()
+    assert 2 <= tries <= 5 and kept >= worst > 1000.0, (tries, kept, worst)  # (GB/s of an MI355X, not a stopwatch assertion)
+    d.add_sequence(ref, 100)
+    o, _keep = oracle_view(d)
+    reads = make_reads(rng, ref, 300, lo=100, hi=400)
+    buf, offs, lens = H.pack_reads(reads)
+    eng = capi.Engine(0, [d], [])
+    assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], po.batch_raw_max(o, buf, offs, lens, 8))
+    clone, _, _ = d.clone_to_ex(0)
+    assert clone.placement()[0] >= 1
+    cmp_ = d.compare(clone)
+    assert cmp_["new_bits"] == 0 and cmp_["file_bits"] == cmp_["rebuilt_bits"]
+    clone.free()
+    eng.destroy()
+    capi.set_placement_tries(1)
+    try:
+        off = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * n_blocks)
+        assert off.placement() == (0, 0.0, 0.0)
+        off.free()
+    finally:
+        capi.set_placement_tries(5)
+    small = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * 4099)
+    assert small.placement()[0] == 0
+    small.free()
+    with pytest.raises(capi.RBError):
+        capi.set_placement_tries(9)
+    d.free()
