@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from readbouncer_amd import capi, synth  # noqa: E402
 
+if os.environ.get("RB_PLACEMENT_TRIES_OFF"):
+    capi.set_placement_tries(1)  # this script's copies are plain allocations (it does the trial itself)
 key = sys.argv[1] if len(sys.argv) > 1 else "c3np2"
 n_alloc = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 w = synth.WORKLOADS[key]

@@ -78,6 +78,9 @@ static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uin
             break;
         }
         double g = 0.0;
+        // (the first probe of a trial may find the device in an idle clock state -- a filter is often created after seconds of host work --
+        // and read 3-6 % low, which would make the SECOND candidate look like the fast kind: one discarded run of ~60 ms first)
+        if (t == 0) (void)rb::probe_read_peak_raw(p, bytes - 64, row, bytes > (512ull << 20), 24, 60.0, &g, nullptr);
         if (rb::probe_read_peak_raw(p, bytes - 64, row, bytes > (512ull << 20), 24, 30.0, &g, nullptr) != RB_OK) g = 0.0;  // (a probe that fails only ends the trial)
         cand.emplace_back(g, p);
         worst = cand.size() == 1 ? g : std::min(worst, g);
