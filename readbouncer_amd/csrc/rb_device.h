@@ -158,6 +158,8 @@ hipError_t launch_reduce_slices(const uint16_t *part, uint32_t n_slices, uint32_
 hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens, const uint8_t *pre_status,
                          uint32_t n_reads, int mode, int32_t *best_target, uint8_t *decision, uint8_t *status,
                          hipStream_t st);
+// micro-batches: pinned host block -> device staging by a kernel of the call's own stream (16-byte units; both blocks hold whole units)
+hipError_t launch_copy_from_host(const void *h_src, void *d_dst, size_t bytes, hipStream_t st);
 hipError_t launch_chunk_prep(const uint32_t *lens, const uint32_t *ids, uint32_t n_items, uint32_t chunk_start,
                              uint32_t chunk_len, uint32_t *eff_lens, uint8_t *pre_status, hipStream_t st);
 hipError_t launch_insert(const IbfDev &f, uint64_t *words, const uint8_t *seq, const uint64_t *starts,

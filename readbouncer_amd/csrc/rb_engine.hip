@@ -152,7 +152,8 @@ struct PinnedBuf {
         cap = 0;
         size_t want = std::max(bytes, (size_t)65536);
         want = want + want / 2;
-        RB_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        // (coherent, whatever HIP_HOST_COHERENT says: kernels read micro-batches from here and write results here)
+        RB_HIP(hipHostMalloc(&p, want, hipHostMallocCoherent));
         cap = want;
         return RB_OK;
     }
@@ -323,6 +324,7 @@ struct rb_engine {
     hipStream_t copy_stream = nullptr;
     std::vector<hipEvent_t> copy_ev;
     uint64_t host_slice_bytes = (uint64_t)32 << 20;
+    uint64_t micro_copy_kernel_bytes = 1 << 20;  // micro-batches up to this size enter HBM by launch_copy_from_host (0: always the runtime's copy)
     std::mutex mu;
 };
 
@@ -805,6 +807,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
         if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
         if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
+        if (const char *v = std::getenv("RB_MICRO_COPY_KERNEL_BYTES")) { e->micro_copy_kernel_bytes = std::strtoull(v, nullptr, 10); note("RB_MICRO_COPY_KERNEL_BYTES", v); }
     }
     rb::set_warning(accepted.empty() ? std::string() : "rb_engine_create: environment overrides in effect: " + accepted);
     hipError_t he = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
@@ -2033,9 +2036,9 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         const size_t out_bytes = 4 * n + 2 * nf * n + 2 * n;
         {
             std::lock_guard<std::mutex> lock(e->mu);
-            if ((rc = e->h_in.ensure(in_bytes)) != RB_OK) return rc;
+            if ((rc = e->h_in.ensure(in_bytes + 16)) != RB_OK) return rc;  // (+16: the copy kernel moves whole 16-byte units)
             if ((rc = e->h_out.ensure(out_bytes)) != RB_OK) return rc;
-            if ((rc = e->d_seqs.ensure(in_bytes)) != RB_OK) return rc;
+            if ((rc = e->d_seqs.ensure(in_bytes + 16)) != RB_OK) return rc;
             if ((rc = e->d_maxcount.ensure(out_bytes)) != RB_OK) return rc;
         }
         uint64_t *ho = (uint64_t *)e->h_in.p;
@@ -2051,7 +2054,11 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         char *din = (char *)e->d_seqs.p;
         char *dout = (char *)e->d_maxcount.p;
         char *hout = (char *)e->h_out.p;
-        RB_HIP(hipMemcpyAsync(din, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
+        // up to 1 MiB the batch is fetched by a kernel of this stream: the runtime's copy is a blit kernel of its own that costs about 5 us
+        // more from 64 reads on (64 reads 69.8 -> 64.8 us host to host, 256: 138.4 -> 133.6, 512: 240.6 -> 235.7; equal at one read and
+        // from 1 024 reads on: profiles/r05/micro_copy_ab.txt)
+        if (in_bytes <= e->micro_copy_kernel_bytes) RB_HIP(launch_copy_from_host(e->h_in.p, din, in_bytes, st));
+        else RB_HIP(hipMemcpyAsync(din, e->h_in.p, in_bytes, hipMemcpyHostToDevice, st));
         rb_batch_desc desc;
         std::memset(&desc, 0, sizeof desc);
         desc.d_seqs = din + 12 * n;

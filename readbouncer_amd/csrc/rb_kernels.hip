@@ -1845,6 +1845,24 @@ hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const 
     return hipGetLastError();
 }
 
+// A micro-batch's way into HBM: the runtime's copy of a few KB is a blit kernel of its own that takes 11 us per call (the driver's
+// command under rocprofv3, profiles/r05/default_kernel_stats.csv: __amd_rocclr_copyBuffer, 75 k calls) -- a quarter of a micro-batch's
+// service time.  This one reads the pinned (coherent) host block with 16 bytes per lane -- a GPU read of host memory crosses PCIe one
+// request per lane -- and is queued like any other kernel of the call.  `units` 16-byte units.
+__global__ __launch_bounds__(256) void copy_from_host_kernel(const rb_u32x4 *__restrict__ src, rb_u32x4 *__restrict__ dst, uint32_t units)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < units) dst[i] = __builtin_nontemporal_load(src + i);
+}
+
+hipError_t launch_copy_from_host(const void *h_src, void *d_dst, size_t bytes, hipStream_t st)
+{
+    const uint32_t units = (uint32_t)((bytes + 15) >> 4);
+    if (units == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_from_host_kernel, dim3((units + 255) / 256), dim3(256), 0, st, (const rb_u32x4 *)h_src, (rb_u32x4 *)d_dst, units);
+    return hipGetLastError();
+}
+
 hipError_t launch_chunk_prep(const uint32_t *lens, const uint32_t *ids, uint32_t n_items, uint32_t chunk_start,
                              uint32_t chunk_len, uint32_t *eff_lens, uint8_t *pre_status, hipStream_t st)
 {

@@ -1531,3 +1531,37 @@ def test_large_tables_are_placed_by_trial():
     with pytest.raises(capi.RBError):
         capi.set_placement_tries(9)
     d.free()
+
+
+def test_micro_batches_enter_hbm_by_the_engines_own_copy_kernel(monkeypatch):
+    """Micro-batches of up to 1 MiB are copied from the pinned host block by a kernel of the call's stream instead of the runtime's copy
+    (profiles/r05/micro_copy_ab.txt: about 5 us less from 64 reads on).  Same bytes either way: every output of ragged batches around the
+    16-byte units of the copy equals what the runtime's copy gives (an engine created with the measurement switch set to 0) and the oracle."""
+    rng = np.random.default_rng(4242)
+    ref = H.random_dna(rng, 30000)
+    d = capi.DeviceIBF.create(0, 600, 3, 13, 640 * 40009)
+    d.add_sequence(ref, 500)
+    t = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 100003)
+    t.add_sequence(ref[10000:], 800)
+    od, _k1 = oracle_view(d)
+    ot, _k2 = oracle_view(t)
+    reads = make_reads(rng, ref, 1500, lo=1, hi=420, err=0.08, n_frac=0.2)
+    kernel_copy = capi.Engine(0, [d], [t])
+    monkeypatch.setenv("RB_TUNING_ENV", "1")
+    monkeypatch.setenv("RB_MICRO_COPY_KERNEL_BYTES", "0")
+    runtime_copy = capi.Engine(0, [d], [t])
+    monkeypatch.delenv("RB_MICRO_COPY_KERNEL_BYTES")
+    for n in (1, 2, 3, 5, 17, 64, 333, 1500):
+        buf, offs, lens = H.pack_reads(reads[:n])
+        a = kernel_copy.classify(buf, offs, lens)
+        b = runtime_copy.classify(buf, offs, lens)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)), n
+    buf, offs, lens = H.pack_reads(reads[:300])
+    got = kernel_copy.classify(buf, offs, lens)
+    exp_dec, exp_st = po.batch_check_unblock([od], [ot], buf, offs, lens, n_threads=8)
+    assert np.array_equal(got[2], exp_dec) and np.array_equal(got[3], exp_st)
+    assert np.array_equal(got[0][:, 0], po.batch_raw_max(od, buf, offs, lens, 8)) and np.array_equal(got[0][:, 1], po.batch_raw_max(ot, buf, offs, lens, 8))
+    kernel_copy.destroy()
+    runtime_copy.destroy()
+    d.free()
+    t.free()
