@@ -70,6 +70,10 @@ int rb_live_create(rb_engine *e, double error_rate, double significance, uint32_
     lv->error_rate = error_rate;
     lv->significance = significance;
     lv->max_undecided_len = max_undecided_len;
+    // once_seen holds the reads that wait for more data: at most one per sequencing channel (48 PromethION flow cells: 144 k).  Room for
+    // that many from the start, so that the map never rehashes in the middle of a run -- a rehash at 600 k pending reads stalled one call
+    // of a 20 s synthetic replay for 38 ms (profiles/r05/c5_replay_20s.txt; pending reads only pile up like that when no read ever ends)
+    lv->once_seen.reserve((size_t)1 << 18);
     *out = lv;
     return RB_OK;
 }
