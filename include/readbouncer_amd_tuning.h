@@ -106,6 +106,12 @@ RB_API int rb_engine_set_overlap(rb_engine *e, int enabled);
  * counters are added by the last workgroup to finish.  Results are identical. */
 RB_API int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t max_shares);
 
+/* Engines with one filter, micro-batches of up to 512 reads in the latency form: the count kernel makes the decisions too -- the
+ * workgroup that writes a read's raw maximum runs check_unblock's decision for it (src/main/adaptive_sampling.hpp:35-113) -- instead
+ * of a decision kernel launched behind it: one dependent launch less per call (1-2 us).  0 keeps the two launches.  Default on.
+ * Results are identical. */
+RB_API int rb_engine_set_fold_decide(rb_engine *e, int enabled);
+
 /* Filters larger than table_bytes are gathered with non-temporal loads (default 512 MiB = 2x the Infinity
  * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);

@@ -127,6 +127,7 @@ struct CountLaunch {
     IbfDev fused_f[kMaxFused];
     uint32_t fused_col_begin[kMaxFused], fused_col_end[kMaxFused], fused_out_offset[kMaxFused];
     uint8_t fused_geom[kMaxFused], fused_parts[kMaxFused], fused_sub[kMaxFused];  // latency form, see FilterSet
+    const struct FoldJob *fold;   // latency form: the launch also makes the decisions (nullptr: it only counts)
 };
 
 inline uint8_t geom_code(int lg, int wpl, int nt) { return (uint8_t)(lg | (wpl == 2 ? 8 : 0) | (nt ? 16 : 0)); }
@@ -142,6 +143,22 @@ struct DecideParams {
     // the raw maximum of a (read, filter) is the max over them.  1 = a plain table.
     uint32_t n_parts;
     uint64_t part_stride;
+};
+
+// The decision of a micro-batch made by the latency kernel itself, for engines with ONE filter: the workgroup that writes a read's raw
+// maximum runs the decision for that read, and the dependent launch of the decision kernel goes away (1.1-1.8 us of a 40-120 us call
+// up to 256 reads; with several filters the reads would need arrival counters of their own, and one more agent-scope release per
+// (read, filter) costs more than the launch did: profiles/r05/negative_results.md, entry 10).  By-value kernel argument.
+struct FoldJob {
+    uint32_t on;  // 0: the kernel only counts
+    int mode;
+    const uint16_t *maxcount;  // the table [n_reads][1] the launch writes into
+    const uint32_t *lens;
+    const uint8_t *pre_status;
+    int32_t *best_target;
+    uint8_t *decision;
+    uint8_t *status;
+    DecideParams P;
 };
 
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);

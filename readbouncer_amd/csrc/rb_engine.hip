@@ -289,6 +289,11 @@ struct rb_engine {
     DevBuf d_split_ws, d_split_tickets;
     bool tickets_dirty = false;  // a call that launched the multi-workgroup latency kernel did not come back clean: the arrival
                                  // counters may be non-zero (the kernel zeroes them itself only when it runs to its end)
+    // one-filter engines, micro-batches up to fold_max_reads in the latency form: the count kernel makes the decisions too (FoldJob,
+    // rb_device.h) -- one dependent launch less per call (deplete only: 1 read 41.5 -> 40.3 us, 64: 64.1 -> 62.8, 256: 119.2 -> 117.4;
+    // nothing from 1 024 reads on: profiles/r05/fold_decide_ab.txt)
+    bool fold_decide = true;
+    uint32_t fold_max_reads = 512;
     // threshold tables u16[len][filter][{r, r-0.02}], one per (error rate, significance) pair; the two most recently used
     // pairs stay resident so that a caller alternating two error rates never rebuilds (or waits for) a table.  A table
     // that is replaced or outgrown may still be read by queued kernels: its device block is parked in thr_retired.
@@ -960,6 +965,14 @@ int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t max_sha
     return RB_OK;
 }
 
+int rb_engine_set_fold_decide(rb_engine *e, int enabled)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->fold_decide = enabled != 0;
+    return RB_OK;
+}
+
 int rb_engine_set_overlap(rb_engine *e, int enabled)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -1345,10 +1358,9 @@ static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipSt
     return RB_OK;
 }
 
-static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
-                      size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
-                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr,
-                      uint32_t n_parts = 1, uint64_t part_stride = 0)
+// what the decision needs besides the raw maxima (the threshold table is made on `st` when this (max_len, r, conf) is new)
+static int decide_params(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st, uint16_t *maxcount_copy,
+                         uint32_t n_parts, uint64_t part_stride, DecideParams *out)
 {
     DecideParams P{};
     int rc = ensure_thresholds(e, max_len, r, conf, st, &P.thr, &P.thr_len);
@@ -1360,6 +1372,18 @@ static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *
     P.maxcount_copy = maxcount_copy;
     P.n_parts = n_parts ? n_parts : 1;
     P.part_stride = part_stride;
+    *out = P;
+    return RB_OK;
+}
+
+static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
+                      size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
+                      uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr,
+                      uint32_t n_parts = 1, uint64_t part_stride = 0)
+{
+    DecideParams P{};
+    int rc = decide_params(e, max_len, r, conf, st, maxcount_copy, n_parts, part_stride, &P);
+    if (rc != RB_OK) return rc;
     RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
 }
@@ -1712,6 +1736,11 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     }
     std::vector<CountLaunch> pending;
     std::vector<uint32_t> pending_fi;
+    // may the count kernel of this call decide as well?  (one filter, in the latency form with one column slice: settled below)
+    bool fold_ok = e->fold_decide && nf == 1 && e->shard_world == 1 && (d_best_target || d_decision || d_status) && !fan_out && !use_merged &&
+                   n_reads <= e->split_threshold && n_reads <= e->fold_max_reads;
+    bool folded = false;
+    FoldJob job{};
     // Which filters may run side by side?  A table of a few tens of MB lives partly in the 4 MiB L2 of each XCD (hit rate
     // about 4 MiB / table); two such tables gathered at once halve each other's share, so narrow filters take turns on the
     // call's stream (measured on the README shape, four filters of 10-20 MB: 13.3 -> 16.5 M reads/s).  Tables far beyond
@@ -1743,9 +1772,11 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         a.n_reads = (uint32_t)n_reads;
         if (!plan_geometry(e, f, n_reads, max_len, a)) {
             // this rank holds no column of this filter: its partial maxima are 0
+            fold_ok = false;
             RB_HIP(hipMemset2DAsync(maxcount + fi, nf * 2, 0, 2, n_reads, fs));
             continue;
         }
+        if (a.n_slices != 1 || a.split_waves < 2) fold_ok = false;
         if (a.n_slices == 1) {
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;
@@ -1754,6 +1785,19 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
                 pending.push_back(a);  // micro-batch: fused below with the filters of equal kernel geometry
                 pending_fi.push_back((uint32_t)fi);
             } else {
+                if (fold_ok) {  // the engine's only filter in the latency form: this launch decides
+                    if ((rc = decide_params(e, max_len, error_rate, significance, fs, host_maxcount, 1, 0, &job.P)) != RB_OK) return rc;
+                    job.on = 1;
+                    job.mode = mode;
+                    job.maxcount = maxcount;
+                    job.lens = (const uint32_t *)d_lens;
+                    job.pre_status = d_pre_status;
+                    job.best_target = (int32_t *)d_best_target;
+                    job.decision = (uint8_t *)d_decision;
+                    job.status = (uint8_t *)d_status;
+                    a.fold = &job;
+                    folded = true;
+                }
                 if ((rc = ensure_split_ws(e, a, 1, fs)) != RB_OK) return rc;
                 RB_HIP(launch_ibf_count_max(a, fs));
             }
@@ -1776,7 +1820,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
         }
     }
     if (evp) RB_HIP(hipEventRecord(evp->second, st));
-    if (e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
+    if (!folded && e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
         rc = run_decide(e, maxcount, (const uint32_t *)d_lens, d_pre_status, n_reads, max_len, error_rate, significance,
                         mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st, host_maxcount);
         if (rc != RB_OK) return rc;

@@ -1064,236 +1064,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     }
 }
 
-// latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
-// slot = p * (waves/2) + (w>>1) of the per-strand work: share slot % sub of the eight-step blocks of every
-// (slots/sub)-th macro tile starting at slot / sub.  Partial counters meet in LDS (bit-sliced adds); with parts > 1 the
-// workgroups leave their sums in a workspace and the last one to finish (ticket counter) adds them and takes the max.
-// A wide filter is latency bound per read -- 2088 dependent-free gathers, but only 12-24 of them in flight per wave --
-// so the way to a short kernel is more waves per read than one workgroup holds.
-// blockIdx.y selects one filter of the set; all filters of a micro-batch share ONE launch whatever their geometry (a
-// micro-batch against deplete + several targets would otherwise queue one short kernel per filter, 10-25 us each, and
-// the short kernel of a narrow target would wait for the long one of the wide deplete filter instead of hiding in it).
-// The launch has grid_parts workgroups per (read, slice); a filter that wants fewer leaves the others idle.
-template <int LG, int WPL, int NP, int H, bool NT>
-__device__ __forceinline__ void split_body(const IbfDev &f, uint32_t col_begin, uint32_t col_end, uint32_t parts,
-                                           uint32_t sub, const ReadSrc &src, uint32_t n_reads, uint32_t n_slices,
-                                           uint16_t *__restrict__ out, uint32_t out_read_stride,
-                                           uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
-                                           uint32_t *__restrict__ tickets, uint8_t *s_dyn)
-{
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int n_waves = blockDim.x >> 6;
-    const int wps = n_waves >> 1;  // waves per strand in this workgroup
-    const int strand = wave & 1, lslot = wave >> 1;
-    const uint32_t item = blockIdx.x / grid_parts;
-    const uint32_t part = blockIdx.x - item * grid_parts;
-    if (part >= parts) return;  // workgroup-uniform: this filter uses fewer workgroups per read than the launch has
-    const uint32_t read = item / n_slices;
-    const uint32_t slice = item - read * n_slices;
-    const uint32_t slots = (uint32_t)wps * parts;  // per strand, over all parts
-    const uint32_t slot = part * (uint32_t)wps + (uint32_t)lslot;
-
-    uint64_t *s_planes = reinterpret_cast<uint64_t *>(s_dyn);  // [wave][WPL][NP][64]
-    uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);  // [0..1] maxima, [2] ticket
-    uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
-
-    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
-    uint32_t len;
-    const BaseSrc seq = make_base_src(src, read, &len);
-    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
-    constexpr uint32_t ITEMS = TileShape<LG>::ITEMS;
-    constexpr int BPT = TileShape<LG>::STEPS / 8;  // eight-step blocks per macro tile
-    const int bps = BPT / (int)sub;                // ... per share (sub divides BPT and slots)
-    const int sb = (int)(slot % sub);
-
-    Planes<NP> pl[WPL];
-#pragma unroll
-    for (int w = 0; w < WPL; ++w) pl[w].clear();
-    count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, (slot / sub) * ITEMS, (slots / sub) * ITEMS, sb * bps,
-                                     (sb + 1) * bps, stage, lane);
-
-    if (lslot != 0) {
-#pragma unroll
-        for (int w = 0; w < WPL; ++w)
-#pragma unroll
-            for (int i = 0; i < NP; ++i) s_planes[(((size_t)wave * WPL + w) * NP + i) * 64 + lane] = pl[w].p[i];
-    }
-    __syncthreads();
-    const size_t gitem = (size_t)blockIdx.y * ((size_t)n_reads * n_slices) + item;
-    if (lslot == 0) {
-        for (int o = 1; o < wps; ++o) {
-            const int ow = (o << 1) | strand;
-#pragma unroll
-            for (int w = 0; w < WPL; ++w) {
-                uint64_t carry = 0;
-#pragma unroll
-                for (int i = 0; i < NP; ++i) {
-                    const uint64_t other = s_planes[(((size_t)ow * WPL + w) * NP + i) * 64 + lane];
-                    uint64_t h, l;
-                    RB_CSA(h, l, pl[w].p[i], other, carry);
-                    pl[w].p[i] = l;
-                    carry = h;
-                }
-            }
-        }
-        if (parts == 1) {
-            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
-            if (lane == 0) s_max[strand] = m;
-        } else {
-            uint64_t *dst = ws + ((gitem * grid_parts + part) * 2 + (size_t)strand) * (2 * NP * 64);
-#pragma unroll
-            for (int w = 0; w < WPL; ++w)
-#pragma unroll
-                for (int i = 0; i < NP; ++i) dst[(w * NP + i) * 64 + lane] = pl[w].p[i];
-        }
-    }
-    __syncthreads();
-    if (parts > 1) {
-        // The last workgroup of this (read, slice, filter) to arrive owns the result.  One agent-scope release per
-        // workgroup (the barrier above orders the other waves' stores before it) and one acquire in the last one (the
-        // barrier below orders it before the other waves' loads): on gfx950 a release writes the XCD's L2 back, which
-        // costs about a microsecond and serialises per XCD -- fences per wave made 64-read batches 2.4x slower.
-        if (threadIdx.x == 0) {
-            const uint32_t t = __hip_atomic_fetch_add(&tickets[gitem], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            if (t == parts - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            s_max[2] = t;
-        }
-        __syncthreads();
-        if (s_max[2] != parts - 1) return;  // workgroup-uniform
-        if (lslot == 0) {
-#pragma unroll
-            for (int w = 0; w < WPL; ++w) pl[w].clear();
-            for (uint32_t q = 0; q < parts; ++q) {
-                const uint64_t *srcp = ws + ((gitem * grid_parts + q) * 2 + (size_t)strand) * (2 * NP * 64);
-#pragma unroll
-                for (int w = 0; w < WPL; ++w) {
-                    uint64_t carry = 0;
-#pragma unroll
-                    for (int i = 0; i < NP; ++i) {
-                        const uint64_t other = srcp[(w * NP + i) * 64 + lane];
-                        uint64_t h, l;
-                        RB_CSA(h, l, pl[w].p[i], other, carry);
-                        pl[w].p[i] = l;
-                        carry = h;
-                    }
-                }
-            }
-            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
-            if (lane == 0) s_max[strand] = m;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) tickets[gitem] = 0;  // ready for the next launch on this stream
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t a = s_max[0], b = s_max[1];
-        out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)(a > b ? a : b);
-    }
-}
-
-
-// filters of ONE kernel geometry (single-filter engines, several targets of equal width): the body alone, with the
-// workgroup size its register budget allows
-template <int LG, int WPL, int NP, int H, bool NT>
-__global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : (LG == 0 ? 512 : 1024)) void ibf_count_max_split_kernel(
-    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
-    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
-    uint32_t *__restrict__ tickets)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    split_body<LG, WPL, NP, H, NT>(set.f[blockIdx.y], set.col_begin[blockIdx.y], set.col_end[blockIdx.y], set.parts[blockIdx.y],
-                                   set.sub[blockIdx.y], src, n_reads, n_slices, out_base + set.out_offset[blockIdx.y],
-                                   out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);
-}
-
-// filters of DIFFERENT geometries in one launch (deplete = human genome, targets = a few small genomes): the geometry
-// of the filter picked by blockIdx.y selects the body (workgroup-uniform branch).  Built for 512 threads: with all
-// bodies in one function the scalar state of sixteen specialisations spills into vector registers, and at 768+
-// threads that pushes the widest bodies over the budget.
-template <int NP, bool WIDE>
-__global__ __launch_bounds__(512) void ibf_count_max_split_any_kernel(
-    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
-    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
-    uint32_t *__restrict__ tickets)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
-    const IbfDev &f = set.f[blockIdx.y];
-    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
-    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
-    const uint32_t parts = set.parts[blockIdx.y], sub = set.sub[blockIdx.y];
-#define RB_SPLIT_CASE(LG_, WPL_)                                                                                          \
-    case (LG_) | ((WPL_) == 2 ? 8 : 0):                                                                                    \
-        split_body<LG_, WPL_, NP, 3, false>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,                \
-                                            out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);            \
-        break;                                                                                                             \
-    case (LG_) | ((WPL_) == 2 ? 8 : 0) | 16:                                                                               \
-        split_body<LG_, WPL_, NP, 3, true>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,                 \
-                                           out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);             \
-        break;
-    switch (set.geom[blockIdx.y]) {
-        RB_SPLIT_CASE(0, 1)
-        RB_SPLIT_CASE(1, 1)
-        RB_SPLIT_CASE(2, 1)
-        RB_SPLIT_CASE(3, 1)
-        RB_SPLIT_CASE(4, 1)
-        RB_SPLIT_CASE(5, 1)
-        RB_SPLIT_CASE(6, 1)
-    default:
-        if constexpr (WIDE) {
-            switch (set.geom[blockIdx.y]) {
-                RB_SPLIT_CASE(6, 2)
-            default: break;
-            }
-        }
-        break;
-    }
-#undef RB_SPLIT_CASE
-}
-
-// combine the per-slice partial maxima of one filter: part[slice][read] -> maxcount[read*nf + f]
-__global__ void reduce_slices_kernel(const uint16_t *__restrict__ part, uint32_t n_slices, uint32_t n_reads,
-                                     uint16_t *__restrict__ maxcount, uint32_t nf, uint32_t fidx)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
-    uint16_t m = 0;
-    for (uint32_t s = 0; s < n_slices; ++s) {
-        const uint16_t v = part[(size_t)s * n_reads + i];
-        m = v > m ? v : m;
-    }
-    maxcount[(size_t)i * nf + fidx] = m;
-}
-
 // ---------------------------------------------------------------------------------------------
-// on-GPU chunking (classify.hpp:264-271): work item i looks at bases [chunk_start, min(chunk_start+chunk_len, len)) of
-// its read; a chunk that starts beyond the read's end is the reference's undefined infix -> RB_ERR_BAD_CHUNK
-__global__ void chunk_prep_kernel(const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ids, uint32_t n_items,
-                                  uint32_t chunk_start, uint32_t chunk_len, uint32_t *__restrict__ eff_lens,
-                                  uint8_t *__restrict__ pre_status)
+// The decision for read i from the raw maxima of all filters: the body of K2, also run by the latency kernel for the reads of a
+// micro-batch of a one-filter engine (FoldJob).  The maxima are read past this thread's caches.
+__device__ __forceinline__ uint16_t load_count(const uint16_t *p)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const uint32_t len = lens[ids ? ids[i] : i];
-    const bool bad = chunk_start > len;
-    const uint32_t rest = bad ? 0u : len - chunk_start;
-    eff_lens[i] = (chunk_len && chunk_len < rest) ? chunk_len : rest;
-    pre_status[i] = bad ? (uint8_t)RB_ERR_BAD_CHUNK : (uint8_t)RB_OK;
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// K2: one thread per read.
-__global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxcount, const uint32_t *__restrict__ lens,
-                              const uint8_t *__restrict__ pre_status, uint32_t n_reads, int mode,
-                              int32_t *__restrict__ out_best_target, uint8_t *__restrict__ out_decision,
-                              uint8_t *__restrict__ out_status)
+__device__ __forceinline__ void decide_one(const DecideParams &P, const uint16_t *maxcount, const uint32_t *lens,
+                                           const uint8_t *pre_status, uint32_t i, int mode, int32_t *out_best_target,
+                                           uint8_t *out_decision, uint8_t *out_status)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
     const uint32_t nf = P.nd + P.nt;
     // raw maximum of (this read, filter fi): the max over the partial tables of the ranks (bin-sharded), or the one table
     auto raw_max = [&](uint32_t fi) -> uint32_t {
-        uint16_t m = maxcount[(size_t)i * nf + fi];
+        uint16_t m = load_count(maxcount + (size_t)i * nf + fi);
         for (uint32_t q = 1; q < P.n_parts; ++q) {
-            const uint16_t v = maxcount[(size_t)q * P.part_stride + (size_t)i * nf + fi];
+            const uint16_t v = load_count(maxcount + (size_t)q * P.part_stride + (size_t)i * nf + fi);
             m = v > m ? v : m;
         }
         return m;
@@ -1396,6 +1184,246 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
     if (out_best_target) out_best_target[i] = (P.nt && !short_t) ? best_t : -1;
     if (out_decision) out_decision[i] = decision;
     if (out_status) out_status[i] = status;
+}
+
+// latency kernel of a one-filter engine, after its body: `fin` = the read whose raw maximum this workgroup has just written, or ~0u
+__device__ __forceinline__ void fold_decide(const FoldJob &job, uint32_t fin)
+{
+    if (!job.on || fin == ~0u || threadIdx.x != 0) return;  // thread 0 wrote the maximum
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own store before own load of the same element
+    decide_one(job.P, job.maxcount, job.lens, job.pre_status, fin, job.mode, job.best_target, job.decision, job.status);
+}
+
+// latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
+// slot = p * (waves/2) + (w>>1) of the per-strand work: share slot % sub of the eight-step blocks of every
+// (slots/sub)-th macro tile starting at slot / sub.  Partial counters meet in LDS (bit-sliced adds); with parts > 1 the
+// workgroups leave their sums in a workspace and the last one to finish (ticket counter) adds them and takes the max.
+// A wide filter is latency bound per read -- 2088 dependent-free gathers, but only 12-24 of them in flight per wave --
+// so the way to a short kernel is more waves per read than one workgroup holds.
+// blockIdx.y selects one filter of the set; all filters of a micro-batch share ONE launch whatever their geometry (a
+// micro-batch against deplete + several targets would otherwise queue one short kernel per filter, 10-25 us each, and
+// the short kernel of a narrow target would wait for the long one of the wide deplete filter instead of hiding in it).
+// The launch has grid_parts workgroups per (read, slice); a filter that wants fewer leaves the others idle.
+template <int LG, int WPL, int NP, int H, bool NT>
+__device__ __forceinline__ uint32_t split_body(const IbfDev &f, uint32_t col_begin, uint32_t col_end, uint32_t parts,
+                                           uint32_t sub, const ReadSrc &src, uint32_t n_reads, uint32_t n_slices,
+                                           uint16_t *__restrict__ out, uint32_t out_read_stride,
+                                           uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+                                           uint32_t *__restrict__ tickets, uint8_t *s_dyn)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = blockDim.x >> 6;
+    const int wps = n_waves >> 1;  // waves per strand in this workgroup
+    const int strand = wave & 1, lslot = wave >> 1;
+    const uint32_t item = blockIdx.x / grid_parts;
+    const uint32_t part = blockIdx.x - item * grid_parts;
+    if (part >= parts) return ~0u;  // workgroup-uniform: this filter uses fewer workgroups per read than the launch has
+    const uint32_t read = item / n_slices;
+    const uint32_t slice = item - read * n_slices;
+    const uint32_t slots = (uint32_t)wps * parts;  // per strand, over all parts
+    const uint32_t slot = part * (uint32_t)wps + (uint32_t)lslot;
+
+    uint64_t *s_planes = reinterpret_cast<uint64_t *>(s_dyn);  // [wave][WPL][NP][64]
+    uint32_t *s_max = reinterpret_cast<uint32_t *>(s_dyn + (size_t)n_waves * WPL * NP * 64 * 8);  // [0..1] maxima, [2] ticket
+    uint8_t *stage = s_dyn + (size_t)n_waves * WPL * NP * 64 * 8 + 16 + (size_t)wave * kStageBytes;
+
+    const LaneCols<WPL> lc = make_lane_cols<LG, WPL>(f, lane, col_begin, col_end, slice);
+    uint32_t len;
+    const BaseSrc seq = make_base_src(src, read, &len);
+    const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
+    constexpr uint32_t ITEMS = TileShape<LG>::ITEMS;
+    constexpr int BPT = TileShape<LG>::STEPS / 8;  // eight-step blocks per macro tile
+    const int bps = BPT / (int)sub;                // ... per share (sub divides BPT and slots)
+    const int sb = (int)(slot % sub);
+
+    Planes<NP> pl[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) pl[w].clear();
+    count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, (slot / sub) * ITEMS, (slots / sub) * ITEMS, sb * bps,
+                                     (sb + 1) * bps, stage, lane);
+
+    if (lslot != 0) {
+#pragma unroll
+        for (int w = 0; w < WPL; ++w)
+#pragma unroll
+            for (int i = 0; i < NP; ++i) s_planes[(((size_t)wave * WPL + w) * NP + i) * 64 + lane] = pl[w].p[i];
+    }
+    __syncthreads();
+    const size_t gitem = (size_t)blockIdx.y * ((size_t)n_reads * n_slices) + item;
+    if (lslot == 0) {
+        for (int o = 1; o < wps; ++o) {
+            const int ow = (o << 1) | strand;
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                uint64_t carry = 0;
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    const uint64_t other = s_planes[(((size_t)ow * WPL + w) * NP + i) * 64 + lane];
+                    uint64_t h, l;
+                    RB_CSA(h, l, pl[w].p[i], other, carry);
+                    pl[w].p[i] = l;
+                    carry = h;
+                }
+            }
+        }
+        if (parts == 1) {
+            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
+            if (lane == 0) s_max[strand] = m;
+        } else {
+            uint64_t *dst = ws + ((gitem * grid_parts + part) * 2 + (size_t)strand) * (2 * NP * 64);
+#pragma unroll
+            for (int w = 0; w < WPL; ++w)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) dst[(w * NP + i) * 64 + lane] = pl[w].p[i];
+        }
+    }
+    __syncthreads();
+    if (parts > 1) {
+        // The last workgroup of this (read, slice, filter) to arrive owns the result.  One agent-scope release per
+        // workgroup (the barrier above orders the other waves' stores before it) and one acquire in the last one (the
+        // barrier below orders it before the other waves' loads): on gfx950 a release writes the XCD's L2 back, which
+        // costs about a microsecond and serialises per XCD -- fences per wave made 64-read batches 2.4x slower.
+        if (threadIdx.x == 0) {
+            const uint32_t t = __hip_atomic_fetch_add(&tickets[gitem], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == parts - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            s_max[2] = t;
+        }
+        __syncthreads();
+        if (s_max[2] != parts - 1) return ~0u;  // workgroup-uniform
+        if (lslot == 0) {
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) pl[w].clear();
+            for (uint32_t q = 0; q < parts; ++q) {
+                const uint64_t *srcp = ws + ((gitem * grid_parts + q) * 2 + (size_t)strand) * (2 * NP * 64);
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    uint64_t carry = 0;
+#pragma unroll
+                    for (int i = 0; i < NP; ++i) {
+                        const uint64_t other = srcp[(w * NP + i) * 64 + lane];
+                        uint64_t h, l;
+                        RB_CSA(h, l, pl[w].p[i], other, carry);
+                        pl[w].p[i] = l;
+                        carry = h;
+                    }
+                }
+            }
+            const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
+            if (lane == 0) s_max[strand] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) tickets[gitem] = 0;  // ready for the next launch on this stream
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t a = s_max[0], b = s_max[1];
+        out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)(a > b ? a : b);
+    }
+    return item;  // the (read, slice) this workgroup has written (a FoldJob implies one slice: item = read)
+}
+
+
+// filters of ONE kernel geometry (single-filter engines, several targets of equal width): the body alone, with the
+// workgroup size its register budget allows
+template <int LG, int WPL, int NP, int H, bool NT>
+__global__ __launch_bounds__(WPL == 2 ? (NP > 10 ? 512 : 768) : (LG == 0 ? 512 : 1024)) void ibf_count_max_split_kernel(
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+    uint32_t *__restrict__ tickets, FoldJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    const uint32_t fin = split_body<LG, WPL, NP, H, NT>(set.f[blockIdx.y], set.col_begin[blockIdx.y], set.col_end[blockIdx.y],
+                                                        set.parts[blockIdx.y], set.sub[blockIdx.y], src, n_reads, n_slices,
+                                                        out_base + set.out_offset[blockIdx.y], out_read_stride, out_slice_stride,
+                                                        grid_parts, ws, tickets, s_dyn);
+    fold_decide(job, fin);
+}
+
+// filters of DIFFERENT geometries in one launch (deplete = human genome, targets = a few small genomes): the geometry
+// of the filter picked by blockIdx.y selects the body (workgroup-uniform branch).  Built for 512 threads: with all
+// bodies in one function the scalar state of sixteen specialisations spills into vector registers, and at 768+
+// threads that pushes the widest bodies over the budget.
+template <int NP, bool WIDE>
+__global__ __launch_bounds__(512) void ibf_count_max_split_any_kernel(
+    FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
+    uint32_t out_read_stride, uint32_t out_slice_stride, uint32_t grid_parts, uint64_t *__restrict__ ws,
+    uint32_t *__restrict__ tickets, FoldJob job)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_dyn[];
+    uint32_t fin = ~0u;
+    const IbfDev &f = set.f[blockIdx.y];
+    const uint32_t col_begin = set.col_begin[blockIdx.y], col_end = set.col_end[blockIdx.y];
+    uint16_t *__restrict__ out = out_base + set.out_offset[blockIdx.y];
+    const uint32_t parts = set.parts[blockIdx.y], sub = set.sub[blockIdx.y];
+#define RB_SPLIT_CASE(LG_, WPL_)                                                                                          \
+    case (LG_) | ((WPL_) == 2 ? 8 : 0):                                                                                    \
+        fin = split_body<LG_, WPL_, NP, 3, false>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,          \
+                                                  out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);      \
+        break;                                                                                                             \
+    case (LG_) | ((WPL_) == 2 ? 8 : 0) | 16:                                                                               \
+        fin = split_body<LG_, WPL_, NP, 3, true>(f, col_begin, col_end, parts, sub, src, n_reads, n_slices, out,           \
+                                                 out_read_stride, out_slice_stride, grid_parts, ws, tickets, s_dyn);       \
+        break;
+    switch (set.geom[blockIdx.y]) {
+        RB_SPLIT_CASE(0, 1)
+        RB_SPLIT_CASE(1, 1)
+        RB_SPLIT_CASE(2, 1)
+        RB_SPLIT_CASE(3, 1)
+        RB_SPLIT_CASE(4, 1)
+        RB_SPLIT_CASE(5, 1)
+        RB_SPLIT_CASE(6, 1)
+    default:
+        if constexpr (WIDE) {
+            switch (set.geom[blockIdx.y]) {
+                RB_SPLIT_CASE(6, 2)
+            default: break;
+            }
+        }
+        break;
+    }
+#undef RB_SPLIT_CASE
+    fold_decide(job, fin);
+}
+
+// combine the per-slice partial maxima of one filter: part[slice][read] -> maxcount[read*nf + f]
+__global__ void reduce_slices_kernel(const uint16_t *__restrict__ part, uint32_t n_slices, uint32_t n_reads,
+                                     uint16_t *__restrict__ maxcount, uint32_t nf, uint32_t fidx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    uint16_t m = 0;
+    for (uint32_t s = 0; s < n_slices; ++s) {
+        const uint16_t v = part[(size_t)s * n_reads + i];
+        m = v > m ? v : m;
+    }
+    maxcount[(size_t)i * nf + fidx] = m;
+}
+
+// ---------------------------------------------------------------------------------------------
+// on-GPU chunking (classify.hpp:264-271): work item i looks at bases [chunk_start, min(chunk_start+chunk_len, len)) of
+// its read; a chunk that starts beyond the read's end is the reference's undefined infix -> RB_ERR_BAD_CHUNK
+__global__ void chunk_prep_kernel(const uint32_t *__restrict__ lens, const uint32_t *__restrict__ ids, uint32_t n_items,
+                                  uint32_t chunk_start, uint32_t chunk_len, uint32_t *__restrict__ eff_lens,
+                                  uint8_t *__restrict__ pre_status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const uint32_t len = lens[ids ? ids[i] : i];
+    const bool bad = chunk_start > len;
+    const uint32_t rest = bad ? 0u : len - chunk_start;
+    eff_lens[i] = (chunk_len && chunk_len < rest) ? chunk_len : rest;
+    pre_status[i] = bad ? (uint8_t)RB_ERR_BAD_CHUNK : (uint8_t)RB_OK;
+}
+
+// K2: one thread per read.
+__global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxcount, const uint32_t *__restrict__ lens,
+                              const uint8_t *__restrict__ pre_status, uint32_t n_reads, int mode,
+                              int32_t *__restrict__ out_best_target, uint8_t *__restrict__ out_decision,
+                              uint8_t *__restrict__ out_status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_reads) return;
+    decide_one(P, maxcount, lens, pre_status, i, mode, out_best_target, out_decision, out_status);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1545,8 +1573,13 @@ static hipError_t launch_split_kernel(K kern, std::atomic<uint64_t> &done, const
         done.fetch_or(bit, std::memory_order_release);
     }
     dim3 grid(a.n_reads * a.n_slices * grid_parts, set.n);
+    FoldJob job{};
+    if (a.fold) {
+        if (a.n_slices != 1 || set.n != 1 || !a.fold->maxcount || !a.fold->lens) return hipErrorInvalidValue;
+        job = *a.fold;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, st, set, a.src, a.n_reads, a.n_slices, a.out, a.out_read_stride,
-                       a.out_slice_stride, grid_parts, a.split_ws, a.split_tickets);
+                       a.out_slice_stride, grid_parts, a.split_ws, a.split_tickets, job);
     return hipGetLastError();
 }
 

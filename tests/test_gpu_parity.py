@@ -1565,3 +1565,61 @@ def test_micro_batches_enter_hbm_by_the_engines_own_copy_kernel(monkeypatch):
     runtime_copy.destroy()
     d.free()
     t.free()
+
+
+@pytest.mark.parametrize("setup", ["one_narrow", "one_wide", "wide_plus_narrow", "deplete_plus_three_targets", "targets_only"])
+def test_latency_kernel_makes_the_decisions_itself(setup):
+    """Micro-batches of a one-filter engine in the latency form: the workgroup that writes a read's raw maximum runs the decision for
+    it (FoldJob, rb_engine_set_fold_decide) -- same maxima, best targets, decisions and statuses as with the decision kernel behind K1
+    and as the oracle's check_unblock, in all three modes, with one and with several workgroups per read; engines with several filters
+    keep the two launches whatever the switch says (the same calls, the same answers)."""
+    rng = np.random.default_rng(len(setup) * 31)
+    ref = H.random_dna(rng, 50000)
+
+    def filt(n_bins, n_blocks, seq, frag):
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * n_blocks)
+        d.fill_synth(n_bins)
+        d.add_sequence(seq, frag)
+        o, h = oracle_view(d)
+        return d, o, h
+
+    narrow = lambda i: filt(40 + 11 * i, 30011 + 2 * i, ref[10000 * i:10000 * (i + 1)], 10000 // (40 + 11 * i) + 1)
+    wide = lambda i: filt(8192 - 64 * i, 211 + i, ref[10000 * i:10000 * (i + 2)], 20)
+    if setup == "one_narrow":
+        dep, tgt = [narrow(0)], []
+    elif setup == "one_wide":
+        dep, tgt = [wide(0)], []
+    elif setup == "wide_plus_narrow":
+        dep, tgt = [wide(0)], [narrow(2)]
+    elif setup == "deplete_plus_three_targets":
+        dep, tgt = [wide(1)], [narrow(0), filt(600, 997, ref[20000:30000], 20), narrow(3)]
+    else:
+        dep, tgt = [], [narrow(1), wide(3)]
+    eng = capi.Engine(0, [x[0] for x in dep], [x[0] for x in tgt])
+    od, ot = [x[1] for x in dep], [x[1] for x in tgt]
+    reads = make_reads(rng, ref, 150, lo=5, hi=600) + ["", "ACGT", "N" * 40, ref[100:460], ref[25000:25360]]
+    buf, offs, lens = H.pack_reads(reads)
+    exp_mc = np.stack([po.batch_raw_max(o, buf, offs, lens, 4) for o in od + ot], axis=1)
+    exp_dec, exp_st = po.batch_check_unblock(od, ot, buf, offs, lens, n_threads=4)
+    assert len(set(exp_dec.tolist())) >= 2
+    for mode in (capi.RB_MODE_CHECK_UNBLOCK, capi.RB_MODE_CLASSIFY_CHUNK, capi.RB_MODE_CLASSIFY_ANY):
+        for parts in ((8, 4), (1, 1)):
+            eng.set_split_parts(*parts)
+            for n_sub in (len(reads), 1, 7, len(reads)):
+                eng.set_fold_decide(False)
+                two = eng.classify(buf, offs[:n_sub], lens[:n_sub], mode=mode)
+                eng.set_fold_decide(True)
+                for _ in range(2):
+                    one = eng.classify(buf, offs[:n_sub], lens[:n_sub], mode=mode)
+                    for a, b in zip(one, two):
+                        assert np.array_equal(a, b), (setup, mode, parts, n_sub)
+                assert np.array_equal(one[0], exp_mc[:n_sub])
+                if mode == capi.RB_MODE_CHECK_UNBLOCK:
+                    assert np.array_equal(one[2], exp_dec[:n_sub]) and np.array_equal(one[3], exp_st[:n_sub])
+    # an error rate of its own per call (another threshold table) and reads longer than the first call announced
+    long_reads = reads[:20] + [ref[:1500], ref[30000:32500]]
+    b2, o2, l2 = H.pack_reads(long_reads)
+    for r in (0.05, 0.15, 0.1):
+        e_dec, e_st = po.batch_check_unblock(od, ot, b2, o2, l2, r=r, n_threads=4)
+        got = eng.classify(b2, o2, l2, error_rate=r)
+        assert np.array_equal(got[2], e_dec) and np.array_equal(got[3], e_st), r
