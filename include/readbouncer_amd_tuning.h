@@ -112,6 +112,15 @@ RB_API int rb_engine_set_split_parts(rb_engine *e, uint32_t max_parts, uint32_t 
  * Results are identical. */
 RB_API int rb_engine_set_fold_decide(rb_engine *e, int enabled);
 
+/* Opt-in.  rb_classify_batch with up to 2 048 reads: the kernel that writes the call's last result also stores a sequence number into a
+ * word of page-locked host memory (behind a system-scope release), and the calling thread spins on that word instead of waiting for the
+ * stream -- the stream's own wait returns about 4 us later than the results are there (median of a call: one read 40.6 -> 36.1 us).  The
+ * price is the tail: the runtime retires its commands in the stream's wait, without it in bulk every few hundred calls (p99 of config 5's
+ * replay + 0-20 us from box to box), which is why this is off by default.  A word that has not arrived after 20 ms falls back to the
+ * stream, which also reports a failed kernel, and every 256th call waits for the stream as well.  0 = off (default), 1 = on, a value
+ * above 1 = on with that period instead of 256 (measurements).  Results are identical. */
+RB_API int rb_engine_set_completion_word(rb_engine *e, int enabled);
+
 /* Filters larger than table_bytes are gathered with non-temporal loads (default 512 MiB = 2x the Infinity
  * Cache; measured +2.4 % on the 8 GiB filter, -1.9 % on a 0.41 GB one).  Results are identical. */
 RB_API int rb_engine_set_nt_threshold(rb_engine *e, uint64_t table_bytes);

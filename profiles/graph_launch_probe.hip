@@ -27,6 +27,21 @@ __global__ void spin_kernel(uint32_t *out, uint32_t ticks, uint32_t tag)
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = tag;
 }
 
+// the same, but the last kernel of the chain announces completion itself: a sequence number stored to pinned host memory behind a
+// system-scope fence; the host spins on that word instead of calling hipStreamSynchronize
+__global__ void spin_flag_kernel(uint32_t *out, uint32_t ticks, uint32_t tag, volatile uint32_t *host_flag, uint32_t seq)
+{
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {}
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = tag;
+        if (host_flag) {
+            __threadfence_system();
+            *host_flag = seq;
+        }
+    }
+}
+
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static void report(const char *name, int kernels, double spin_us, std::vector<double> &t)
@@ -58,6 +73,25 @@ int main()
                 t.push_back(now_us() - a);
             }
             report("launched one by one + hipStreamSynchronize", kernels, spin_us, t);
+
+            {
+                uint32_t *flag = nullptr;
+                CK(hipHostMalloc((void **)&flag, 64, hipHostMallocCoherent));
+                *flag = 0;
+                uint32_t seq = 0;
+                t.clear();
+                for (int i = 0; i < calls + 200; ++i) {
+                    const double a = now_us();
+                    ++seq;
+                    for (int k = 0; k < kernels; ++k)
+                        hipLaunchKernelGGL(spin_flag_kernel, dim3(8), dim3(256), 0, st, d, ticks, (uint32_t)(i + k), k == kernels - 1 ? flag : nullptr, seq);
+                    while (*(volatile uint32_t *)flag != seq) {}
+                    if (i >= 200) t.push_back(now_us() - a);
+                }
+                CK(hipStreamSynchronize(st));
+                report("launched; host spins on a word the last kernel stores", kernels, spin_us, t);
+                CK(hipHostFree(flag));
+            }
 
             hipGraph_t g;
             hipGraphExec_t ge;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 session 19: would a hipGraph help the micro-batch chain?  two or three short dependent kernels + a synchronise, launched vs replayed
+# r05 session 19 (run twice: the second time with the completion-word variant in the probe): would a hipGraph help the micro-batch chain?  two or three short dependent kernels + a synchronise, launched vs replayed
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r05m
 mkdir -p $OUT

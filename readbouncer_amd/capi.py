@@ -130,6 +130,7 @@ SIGNATURES = {
     "rb_engine_set_overlap": (_int, [_vp, _int]),
     "rb_engine_set_split_parts": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_fold_decide": (_int, [_vp, _int]),
+    "rb_engine_set_completion_word": (_int, [_vp, _int]),
     "rb_engine_set_nt_threshold": (_int, [_vp, _u64]),
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_serial_table_bytes": (_int, [_vp, _u64]),
@@ -485,6 +486,9 @@ class Engine:
 
     def set_fold_decide(self, on):
         _check(lib().rb_engine_set_fold_decide(self.h, int(on)), "rb_engine_set_fold_decide")
+
+    def set_completion_word(self, on):
+        _check(lib().rb_engine_set_completion_word(self.h, int(on)), "rb_engine_set_completion_word")
 
     def set_nt_threshold(self, table_bytes):
         _check(lib().rb_engine_set_nt_threshold(self.h, table_bytes), "rb_engine_set_nt_threshold")

@@ -143,6 +143,13 @@ struct DecideParams {
     // the raw maximum of a (read, filter) is the max over them.  1 = a plain table.
     uint32_t n_parts;
     uint64_t part_stride;
+    // Completion word of the host micro-batch path (nullptr: none): when every result of the call is written, done_seq is stored -- behind a
+    // system-scope release -- into this word of page-locked host memory, and the host, which spins on it, does not wait for the stream
+    // (hipStreamSynchronize returns 4 us later than the word arrives: profiles/r05/graph_launch_probe.txt).  Decision kernels of more than one
+    // workgroup count their arrivals in done_count (zero between calls).
+    uint32_t *done_flag;
+    uint32_t done_seq;
+    uint32_t *done_count;
 };
 
 // The decision of a micro-batch made by the latency kernel itself, for engines with ONE filter: the workgroup that writes a read's raw

@@ -294,6 +294,22 @@ struct rb_engine {
     // nothing from 1 024 reads on: profiles/r05/fold_decide_ab.txt)
     bool fold_decide = true;
     uint32_t fold_max_reads = 512;
+    // Opt-in (rb_engine_set_completion_word): host micro-batches of up to completion_max_reads reads learn of their results from a word of
+    // page-locked memory that the call's last kernel stores, and the calling thread spins on that word instead of waiting for the stream --
+    // hipStreamSynchronize returns about 4 us after the word is there (one read 40.6 -> 36.1 us, 64 reads 64.5 -> 60.0, config 5's service time
+    // 37.9 -> 33.0 us: profiles/r05/completion_word_ab.txt).  Not the default because of the tail: the runtime retires its commands in
+    // hipStreamSynchronize, a stream that is not waited for retires them in bulk -- bursts of 5-8 calls of + 13 us every ~330 calls -- and
+    // p99 of the replay rises by 0-20 us from box to box (completion_word_tail.txt).  A word that does not arrive within completion_spin_us
+    // falls back to the stream (which also reports a failed kernel); every completion_sync_every-th call waits for the stream as well.
+    bool completion_word = false;
+    uint32_t completion_max_reads = 2048;
+    uint32_t completion_spin_us = 20000;
+    PinnedBuf h_done;         // the word
+    uint32_t done_seq = 0;    // last sequence number handed out (never 0)
+    DevBuf d_done_count;      // arrival counter of decision kernels with more than one workgroup; zero between calls
+    bool done_dirty = true;   // ... unless a call did not come back clean (or the counter is new)
+    uint32_t completion_sync_every = 256;
+    uint32_t word_calls = 0;  // calls since the stream was last waited for
     // threshold tables u16[len][filter][{r, r-0.02}], one per (error rate, significance) pair; the two most recently used
     // pairs stay resident so that a caller alternating two error rates never rebuilds (or waits for) a table.  A table
     // that is replaced or outgrown may still be read by queued kernels: its device block is parked in thr_retired.
@@ -853,11 +869,12 @@ void rb_engine_destroy(rb_engine *e)
     }
     for (void *r : e->thr_retired_dev) (void)hipFree(r);
     for (PinnedBuf &h : e->thr_retired_host) h.release();
-    for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_efflens, &e->d_prestatus, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
+    for (DevBuf *b : {&e->d_split_ws, &e->d_split_tickets, &e->d_done_count, &e->d_efflens, &e->d_prestatus, &e->d_maxcount, &e->d_seqs, &e->d_offsets, &e->d_lens, &e->d_best,
                       &e->d_decision, &e->d_status})
         b->release();
     e->h_in.release();
     e->h_out.release();
+    e->h_done.release();
     delete e;
 }
 
@@ -970,6 +987,15 @@ int rb_engine_set_fold_decide(rb_engine *e, int enabled)
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
     std::lock_guard<std::mutex> lock(e->mu);
     e->fold_decide = enabled != 0;
+    return RB_OK;
+}
+
+int rb_engine_set_completion_word(rb_engine *e, int enabled)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->completion_word = enabled != 0;
+    e->completion_sync_every = enabled > 1 ? (uint32_t)enabled : 256u;  // (measurement: another period, or -- INT_MAX -- none)
     return RB_OK;
 }
 
@@ -1360,7 +1386,8 @@ static int ensure_split_ws(rb_engine *e, CountLaunch &a, size_t n_filters, hipSt
 
 // what the decision needs besides the raw maxima (the threshold table is made on `st` when this (max_len, r, conf) is new)
 static int decide_params(rb_engine *e, uint32_t max_len, double r, double conf, hipStream_t st, uint16_t *maxcount_copy,
-                         uint32_t n_parts, uint64_t part_stride, DecideParams *out)
+                         uint32_t n_parts, uint64_t part_stride, DecideParams *out, uint32_t *done_flag = nullptr, uint32_t done_seq = 0,
+                         size_t n_reads = 0)
 {
     DecideParams P{};
     int rc = ensure_thresholds(e, max_len, r, conf, st, &P.thr, &P.thr_len);
@@ -1372,6 +1399,17 @@ static int decide_params(rb_engine *e, uint32_t max_len, double r, double conf, 
     P.maxcount_copy = maxcount_copy;
     P.n_parts = n_parts ? n_parts : 1;
     P.part_stride = part_stride;
+    if (done_flag) {
+        P.done_flag = done_flag;
+        P.done_seq = done_seq;
+        if (n_reads > 256) {  // a decision kernel of several workgroups counts its arrivals
+            const void *old = e->d_done_count.p;
+            if ((rc = e->d_done_count.ensure(64)) != RB_OK) return rc;
+            if (e->d_done_count.p != old || e->done_dirty) RB_HIP(hipMemsetAsync(e->d_done_count.p, 0, 64, st));
+            e->done_dirty = true;  // until the call returns RB_OK
+            P.done_count = (uint32_t *)e->d_done_count.p;
+        }
+    }
     *out = P;
     return RB_OK;
 }
@@ -1379,10 +1417,10 @@ static int decide_params(rb_engine *e, uint32_t max_len, double r, double conf, 
 static int run_decide(rb_engine *e, const uint16_t *d_maxcount, const uint32_t *d_lens, const uint8_t *d_pre_status,
                       size_t n_reads, uint32_t max_len, double r, double conf, int mode, int32_t *d_best,
                       uint8_t *d_decision, uint8_t *d_status, hipStream_t st, uint16_t *maxcount_copy = nullptr,
-                      uint32_t n_parts = 1, uint64_t part_stride = 0)
+                      uint32_t n_parts = 1, uint64_t part_stride = 0, uint32_t *done_flag = nullptr, uint32_t done_seq = 0)
 {
     DecideParams P{};
-    int rc = decide_params(e, max_len, r, conf, st, maxcount_copy, n_parts, part_stride, &P);
+    int rc = decide_params(e, max_len, r, conf, st, maxcount_copy, n_parts, part_stride, &P, done_flag, done_seq, n_reads);
     if (rc != RB_OK) return rc;
     RB_HIP(launch_decide(P, d_maxcount, d_lens, d_pre_status, (uint32_t)n_reads, mode, d_best, d_decision, d_status, st));
     return RB_OK;
@@ -1581,7 +1619,7 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
 // host_maxcount: optional pinned host destination for a copy of the maxcount rows, written by the decision kernel
 static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double error_rate, double significance, int mode,
                                 void *d_maxcount, void *d_best_target, void *d_decision, void *d_status, void *stream,
-                                uint16_t *host_maxcount)
+                                uint16_t *host_maxcount, uint32_t *done_flag = nullptr, uint32_t done_seq = 0)
 {
     if (!e || !desc) return rb::fail(RB_ERR_INVALID_ARG, "null engine or descriptor");
     if (mode != RB_MODE_CHECK_UNBLOCK && mode != RB_MODE_CLASSIFY_CHUNK && mode != RB_MODE_CLASSIFY_ANY)
@@ -1737,8 +1775,10 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     std::vector<CountLaunch> pending;
     std::vector<uint32_t> pending_fi;
     // may the count kernel of this call decide as well?  (one filter, in the latency form with one column slice: settled below)
+    // (a call that announces its completion through the host word folds only when it has ONE read: the deciding thread then holds the
+    // call's last result; with more reads the decision kernel, one workgroup up to 256 reads, announces)
     bool fold_ok = e->fold_decide && nf == 1 && e->shard_world == 1 && (d_best_target || d_decision || d_status) && !fan_out && !use_merged &&
-                   n_reads <= e->split_threshold && n_reads <= e->fold_max_reads;
+                   n_reads <= e->split_threshold && n_reads <= e->fold_max_reads && (!done_flag || n_reads == 1);
     bool folded = false;
     FoldJob job{};
     // Which filters may run side by side?  A table of a few tens of MB lives partly in the 4 MiB L2 of each XCD (hit rate
@@ -1786,7 +1826,7 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
                 pending_fi.push_back((uint32_t)fi);
             } else {
                 if (fold_ok) {  // the engine's only filter in the latency form: this launch decides
-                    if ((rc = decide_params(e, max_len, error_rate, significance, fs, host_maxcount, 1, 0, &job.P)) != RB_OK) return rc;
+                    if ((rc = decide_params(e, max_len, error_rate, significance, fs, host_maxcount, 1, 0, &job.P, done_flag, done_seq, n_reads)) != RB_OK) return rc;
                     job.on = 1;
                     job.mode = mode;
                     job.maxcount = maxcount;
@@ -1822,11 +1862,14 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     if (evp) RB_HIP(hipEventRecord(evp->second, st));
     if (!folded && e->shard_world == 1 && (d_best_target || d_decision || d_status)) {
         rc = run_decide(e, maxcount, (const uint32_t *)d_lens, d_pre_status, n_reads, max_len, error_rate, significance,
-                        mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st, host_maxcount);
+                        mode, (int32_t *)d_best_target, (uint8_t *)d_decision, (uint8_t *)d_status, st, host_maxcount, 1, 0, done_flag, done_seq);
         if (rc != RB_OK) return rc;
+    } else if (!folded && done_flag) {
+        return rb::fail(RB_ERR_INVALID_ARG, "completion word without a decision");
     }
     if (!stream) RB_HIP(hipStreamSynchronize(st));
     e->tickets_dirty = false;  // every launch of this call was accepted (and, on the engine's own stream, has finished)
+    e->done_dirty = false;
     return RB_OK;
 }
 
@@ -2111,11 +2154,26 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
         desc.n_items = n;
         desc.max_len = max_len;
         uint16_t *d_max = (uint16_t *)(dout + 4 * n);
+        if (e->word_calls >= e->completion_sync_every) {
+            RB_HIP(hipStreamSynchronize(st));
+            e->word_calls = 0;
+        }
+        // the call's last kernel announces the results itself (completion word), the host spins on the word: 4 us less than the stream's wait
+        uint32_t *done = nullptr;
+        uint32_t seq = 0;
+        if (e->completion_word && !sharded && n <= e->completion_max_reads) {
+            std::lock_guard<std::mutex> lock(e->mu);
+            if ((rc = e->h_done.ensure(64)) != RB_OK) return rc;
+            done = (uint32_t *)e->h_done.p;
+            if (++e->done_seq == 0) e->done_seq = 1;
+            seq = e->done_seq;
+            __atomic_store_n(done, 0u, __ATOMIC_RELAXED);
+        }
         if (!sharded) {
             // the decision kernel writes its results (and a copy of the maxcount rows) straight into the pinned block:
             // posted PCIe writes, no device-to-host copy command behind the kernels (one dependent launch less per call)
             rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max, hout, hout + 4 * n + 2 * nf * n,
-                                      hout + 4 * n + 2 * nf * n + n, (void *)st, (uint16_t *)(hout + 4 * n));
+                                      hout + 4 * n + 2 * nf * n + n, (void *)st, (uint16_t *)(hout + 4 * n), done, seq);
             if (rc != RB_OK) return rc;
         } else {
             rc = classify_device_impl(e, &desc, error_rate, significance, mode, d_max, nullptr, nullptr, nullptr, (void *)st,
@@ -2123,7 +2181,23 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
             if (rc != RB_OK) return rc;
             RB_HIP(hipMemcpyAsync(hout + 4 * n, d_max, 2 * nf * n, hipMemcpyDeviceToHost, st));
         }
-        RB_HIP(hipStreamSynchronize(st));
+        bool arrived = false;
+        if (done) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (uint32_t spins = 0;; ++spins) {
+                if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 1023u &&
+                    std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > (long long)e->completion_spin_us)
+                    break;  // overdue (or a kernel has failed): the stream says which
+            }
+        }
+        if (!arrived) {
+            RB_HIP(hipStreamSynchronize(st));
+            e->word_calls = 0;
+        } else {
+            ++e->word_calls;
+        }
         if (out_maxcount) std::memcpy(out_maxcount, hout + 4 * n, 2 * nf * n);
         if (!sharded) {
             if (out_best_target) std::memcpy(out_best_target, hout, 4 * n);

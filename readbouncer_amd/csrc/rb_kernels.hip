@@ -1186,12 +1186,29 @@ __device__ __forceinline__ void decide_one(const DecideParams &P, const uint16_t
     if (out_status) out_status[i] = status;
 }
 
+// every result of the call is in place: tell the host (DecideParams::done_flag).  Called by all threads of the decision kernel after their
+// reads; the barrier orders the workgroup's result stores before thread 0's release.
+__device__ __forceinline__ void announce_done(const DecideParams &P)
+{
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    if (gridDim.x > 1) {
+        const uint32_t t = __hip_atomic_fetch_add(P.done_count, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (t != gridDim.x - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *P.done_count = 0;  // ready for the next call on this stream
+    }
+    __hip_atomic_store(P.done_flag, P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // latency kernel of a one-filter engine, after its body: `fin` = the read whose raw maximum this workgroup has just written, or ~0u
 __device__ __forceinline__ void fold_decide(const FoldJob &job, uint32_t fin)
 {
     if (!job.on || fin == ~0u || threadIdx.x != 0) return;  // thread 0 wrote the maximum
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // own store before own load of the same element
     decide_one(job.P, job.maxcount, job.lens, job.pre_status, fin, job.mode, job.best_target, job.decision, job.status);
+    // a call of ONE read (the engine asks for the word in a folded launch only then): this thread holds the call's last result
+    if (job.P.done_flag) __hip_atomic_store(job.P.done_flag, job.P.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // latency form for micro-batches: `parts` workgroups per (read, column slice).  Wave w of part p takes strand w&1 and
@@ -1422,8 +1439,8 @@ __global__ void decide_kernel(DecideParams P, const uint16_t *__restrict__ maxco
                               uint8_t *__restrict__ out_status)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_reads) return;
-    decide_one(P, maxcount, lens, pre_status, i, mode, out_best_target, out_decision, out_status);
+    if (i < n_reads) decide_one(P, maxcount, lens, pre_status, i, mode, out_best_target, out_decision, out_status);
+    if (P.done_flag) announce_done(P);  // (kernel argument: uniform)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1873,6 +1890,7 @@ hipError_t launch_decide(const DecideParams &P, const uint16_t *maxcount, const 
                          hipStream_t st)
 {
     if (n_reads == 0) return hipSuccess;
+    if (P.done_flag && n_reads > 256 && !P.done_count) return hipErrorInvalidValue;
     hipLaunchKernelGGL(decide_kernel, dim3((n_reads + 255) / 256), dim3(256), 0, st, P, maxcount, lens, pre_status, n_reads,
                        mode, best_target, decision, status);
     return hipGetLastError();

@@ -1623,3 +1623,47 @@ def test_latency_kernel_makes_the_decisions_itself(setup):
         e_dec, e_st = po.batch_check_unblock(od, ot, b2, o2, l2, r=r, n_threads=4)
         got = eng.classify(b2, o2, l2, error_rate=r)
         assert np.array_equal(got[2], e_dec) and np.array_equal(got[3], e_st), r
+
+
+@pytest.mark.parametrize("nd,nt", [(1, 0), (1, 1), (1, 3), (0, 2)])
+def test_completion_word_of_the_micro_batch_path(nd, nt):
+    """rb_classify_batch with up to 2 048 reads returns when the word the last kernel stores has arrived, not when the stream is idle
+    (rb_engine_set_completion_word): same results as with the stream's wait at every batch size -- one read (the folded launch announces),
+    up to 256 (one workgroup of the decision kernel), above (several workgroups, arrival counter) -- in all three modes, call after call
+    without a pause, and the results of a call are complete when it returns (the output block is overwritten by the next call at once)."""
+    rng = np.random.default_rng(100 * nd + nt)
+    ref = H.random_dna(rng, 60000)
+    fs = []
+    for i in range(nd + nt):
+        n_bins = (8192, 43, 600, 122)[i % 4]
+        d = capi.DeviceIBF.create(0, n_bins, 3, 13, ((n_bins + 63) // 64) * 64 * (30011 if n_bins < 1000 else 211))
+        d.fill_synth(i + 1)
+        d.add_sequence(ref[15000 * i:15000 * (i + 1)], max(20, 15000 // n_bins + 1))
+        fs.append((d,) + oracle_view(d))
+    dep, tgt = fs[:nd], fs[nd:]
+    eng = capi.Engine(0, [x[0] for x in dep], [x[0] for x in tgt])
+    reads = make_reads(rng, ref, 2100, lo=5, hi=420)
+    buf, offs, lens = H.pack_reads(reads)
+    exp_dec, exp_st = po.batch_check_unblock([x[1] for x in dep], [x[1] for x in tgt], buf, offs, lens, n_threads=8)
+    exp_mc = np.stack([po.batch_raw_max(x[1], buf, offs, lens, 8) for x in fs], axis=1)
+    for mode in (capi.RB_MODE_CHECK_UNBLOCK, capi.RB_MODE_CLASSIFY_CHUNK, capi.RB_MODE_CLASSIFY_ANY):
+        for n_sub in (1, 2, 64, 256, 257, 700, 2048, 2100, 1):
+            eng.set_completion_word(False)
+            ref_out = eng.classify(buf, offs[:n_sub], lens[:n_sub], mode=mode)
+            eng.set_completion_word(True)
+            for fold in (True, False):
+                eng.set_fold_decide(fold)
+                for _ in range(3):
+                    out = eng.classify(buf, offs[:n_sub], lens[:n_sub], mode=mode)
+                    for a, b in zip(out, ref_out):
+                        assert np.array_equal(a, b), (mode, n_sub, fold)
+            if mode == capi.RB_MODE_CHECK_UNBLOCK:
+                assert np.array_equal(out[0], exp_mc[:n_sub]) and np.array_equal(out[2], exp_dec[:n_sub]) and np.array_equal(out[3], exp_st[:n_sub])
+    # calls of changing size back to back: each returns its own results (a late or early word would hand out the neighbour's)
+    sizes = rng.integers(1, 300, size=400)
+    starts = rng.integers(0, len(reads) - 300, size=400)
+    for n_sub, s in zip(sizes, starts):
+        o2 = (offs[s:s + n_sub] - offs[s]).astype(np.uint64)
+        b2 = buf[int(offs[s]):int(offs[s + n_sub - 1] + lens[s + n_sub - 1])]
+        out = eng.classify(b2, o2, lens[s:s + n_sub])
+        assert np.array_equal(out[0], exp_mc[s:s + n_sub]) and np.array_equal(out[2], exp_dec[s:s + n_sub]) and np.array_equal(out[3], exp_st[s:s + n_sub])
