@@ -18,6 +18,7 @@
 #include <shared_mutex>
 
 #include "rb_device.h"
+#include "rb_io.h"
 #include "rb_phase_plan.h"
 
 using namespace rb;
@@ -43,6 +44,11 @@ struct rb_dibf {
     // placement by trial (dibf_alloc): allocations that were probed for this table, what the kept one and the worst one delivered
     uint32_t placement_tries = 0;
     double placement_gbps = 0.0, placement_worst_gbps = 0.0;
+    // ... and the wait that follows a trial (the driver clears the freed candidates in the background), when the caller of dibf_alloc has
+    // work of its own to do first (streaming the file in): see dibf_settle
+    bool settle_pending = false;
+    uint32_t settle_row = 0;
+    std::chrono::steady_clock::time_point settle_t0{};
 };
 
 // Tables of 1 GiB and more are PLACED BY TRIAL: the same table allocated at another moment of one process gathers 1.7-2.9 % slower or
@@ -56,7 +62,18 @@ struct rb_dibf {
 static std::atomic<int> g_placement_tries{5};
 static constexpr uint64_t kPlacementMinBytes = 1ull << 30;
 
-static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uint64_t **out, uint32_t *tries_out, double *gbps_out, double *worst_out)
+// the wait after a trial: until the kept table probes like it did in the trial, at most 3 s after the candidates were freed
+static void settle_table(void *table, uint64_t bytes, uint32_t row, double trial_gbps, std::chrono::steady_clock::time_point t0)
+{
+    while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(3000)) {
+        double g = 0.0;
+        if (rb::probe_read_peak_raw(table, bytes - 64, row, bytes > (512ull << 20), 24, 30.0, &g, nullptr) != RB_OK) break;
+        if (g >= 0.993 * trial_gbps) break;
+    }
+}
+
+static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uint64_t **out, uint32_t *tries_out, double *gbps_out, double *worst_out,
+                                       rb_dibf *defer_settle_to = nullptr)
 {
     *tries_out = 0;
     *gbps_out = *worst_out = 0.0;
@@ -101,12 +118,16 @@ static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uin
     // ~2.4 % slower -- the driver clears released VRAM in the background (profiles/r05/placement/after_free_check.txt: 6 700 GB/s until 2 s
     // after the call, 6 870 from then on; no such stretch when nothing was freed).  A filter lives for hours, but a caller that measures or
     // serves at once should find a quiet device: wait, bounded, until the kept table probes like it did in the trial.
+    // A caller that fills the table from a file first (rb_dibf_open: 0.3-0.8 s for 8 GiB) does its work in that second and waits for the rest
+    // afterwards (dibf_settle).
     if (cand.size() > 1) {
         const auto t0 = std::chrono::steady_clock::now();
-        while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(3000)) {
-            double g = 0.0;
-            if (rb::probe_read_peak_raw(cand[best].second, bytes - 64, row, bytes > (512ull << 20), 24, 30.0, &g, nullptr) != RB_OK) break;
-            if (g >= 0.993 * cand[best].first) break;
+        if (defer_settle_to) {
+            defer_settle_to->settle_pending = true;
+            defer_settle_to->settle_row = row;
+            defer_settle_to->settle_t0 = t0;
+        } else {
+            settle_table(cand[best].second, bytes, row, cand[best].first, t0);
         }
     }
     *out = (uint64_t *)cand[best].second;
@@ -403,7 +424,7 @@ static int make_dev_desc(const rb_ibf_info &g, const uint64_t *d_words, uint64_t
 // device words of a filter: n_blocks * stride, plus a small zero tail (a 16-byte lane may read one word past a block)
 static uint64_t dibf_device_words(const rb_dibf *f) { return f->geo.n_blocks * f->stride + 8; }
 
-static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out)
+static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out, bool defer_settle = false)
 {
     int st = check_device(device);
     if (st != RB_OK) return st;
@@ -413,7 +434,7 @@ static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out
     f->geo = g;
     f->stride = hbm_stride(g.bin_width);
     hipError_t e = alloc_table_by_trial(dibf_device_words(f) * 8, (uint32_t)(f->stride * 8), &f->d_words, &f->placement_tries, &f->placement_gbps,
-                                        &f->placement_worst_gbps);
+                                        &f->placement_worst_gbps, defer_settle ? f : nullptr);
     if (e != hipSuccess) {
         delete f;
         return rb::fail(RB_ERR_HIP, std::string("hipMalloc of the IBF failed: ") + hipGetErrorString(e));
@@ -429,6 +450,51 @@ static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out
     if (st != RB_OK) { rb_dibf_free(f); return st; }
     *out = f;
     return RB_OK;
+}
+
+// the second half of a placement trial whose wait was deferred (dibf_alloc(..., defer_settle = true)): call it when the table is filled
+static void dibf_settle(rb_dibf *f)
+{
+    if (!f || !f->settle_pending) return;
+    f->settle_pending = false;
+    settle_table(f->d_words, dibf_device_words(f) * 8, f->settle_row, f->placement_gbps, f->settle_t0);
+}
+
+// `words` 64-bit words into d_dst through two page-locked 64 MiB staging buffers: `fill(dst, first_word, n_words)` produces chunk i + 1
+// (several threads: rb_io.h) while chunk i crosses PCIe.  Returns RB_OK, or the failure of fill (its own code) / of the runtime.
+template <typename Fill>
+static int stream_words_to_device(uint64_t *d_dst, uint64_t words, Fill fill)
+{
+    const size_t chunk_words = (size_t)8 << 20;  // 64 MiB
+    uint64_t *stage[2] = {nullptr, nullptr};
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreate(&s);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipHostMalloc((void **)&stage[i], std::min<uint64_t>(chunk_words, std::max<uint64_t>(words, 1)) * 8, hipHostMallocDefault);
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    int rc = RB_OK;
+    if (e != hipSuccess) rc = rb::fail(RB_ERR_HIP, std::string("staging setup: ") + hipGetErrorString(e));
+    uint64_t pos = 0;
+    int slot = 0;
+    bool used_slot[2] = {false, false};
+    while (rc == RB_OK && pos < words) {
+        const size_t nw = (size_t)std::min<uint64_t>(chunk_words, words - pos);
+        if (used_slot[slot]) (void)hipEventSynchronize(done[slot]);
+        if ((rc = fill(stage[slot], pos, nw)) != RB_OK) break;
+        e = hipMemcpyAsync(d_dst + pos, stage[slot], nw * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipEventRecord(done[slot], s);
+        if (e != hipSuccess) { rc = rb::fail(RB_ERR_HIP, hipGetErrorString(e)); break; }
+        used_slot[slot] = true;
+        pos += nw;
+        slot ^= 1;
+    }
+    if (s) (void)hipStreamSynchronize(s);
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (stage[i]) (void)hipHostFree(stage[i]);
+    }
+    if (s) (void)hipStreamDestroy(s);
+    return rc;
 }
 
 // file-layout words already on the device (d_compact: n_blocks * W words) -> this filter's padded layout
@@ -463,22 +529,27 @@ int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out)
 {
     if (!host || !out) return rb::fail(RB_ERR_INVALID_ARG, "null argument");
     rb_dibf *f = nullptr;
-    int st = dibf_alloc(device, host->geo, false, &f);
+    int st = dibf_alloc(device, host->geo, false, &f, true);
     if (st != RB_OK) return st;
     const uint64_t used = host->geo.n_blocks * host->geo.bin_width;  // block payload; tail bits and metadata stay on the host
-    hipError_t e = hipSuccess;
-    if (f->stride == host->geo.bin_width) {
-        e = hipMemcpy(f->d_words, host->words, used * 8, hipMemcpyHostToDevice);
-        if (e != hipSuccess) st = rb::fail(RB_ERR_HIP, hipGetErrorString(e));
-    } else {
-        uint64_t *tmp = nullptr;
-        e = hipMalloc((void **)&tmp, std::max<uint64_t>(used, 1) * 8);
-        if (e == hipSuccess) e = hipMemcpy(tmp, host->words, used * 8, hipMemcpyHostToDevice);
-        if (e != hipSuccess) st = rb::fail(RB_ERR_HIP, hipGetErrorString(e));
-        else st = dibf_from_compact(f, tmp);
-        if (tmp) (void)hipFree(tmp);
+    // the image is pageable memory: copied by the runtime it crosses PCIe at 3.9 GB/s (8 GiB: 2.2 s); staged through page-locked buffers by
+    // a few threads it does not wait for the host (profiles/r05/load_throughput.txt)
+    const bool padded = f->stride != host->geo.bin_width;
+    uint64_t *d_dst = f->d_words;
+    if (padded && hipMalloc((void **)&d_dst, std::max<uint64_t>(used, 1) * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        rb_dibf_free(f);
+        return rb::fail(RB_ERR_HIP, "hipMalloc of the file-layout buffer failed");
     }
+    const uint64_t *src = host->words;
+    st = stream_words_to_device(d_dst, used, [src](uint64_t *dst, uint64_t first, size_t n) {
+        rb::memcpy_parallel(dst, src + first, n * 8);
+        return (int)RB_OK;
+    });
+    if (st == RB_OK && padded) st = dibf_from_compact(f, d_dst);
+    if (padded && d_dst) (void)hipFree(d_dst);
     if (st != RB_OK) { rb_dibf_free(f); return st; }
+    dibf_settle(f);
     *out = f;
     return RB_OK;
 }
@@ -491,49 +562,32 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     int st = open_ibf_stream(path, &fp, &g);
     if (st != RB_OK) return st;
     rb_dibf *f = nullptr;
-    st = dibf_alloc(device, g, false, &f);
+    st = dibf_alloc(device, g, false, &f, true);
     if (st != RB_OK) { std::fclose(fp); return st; }
-    // stream the block payload through two pinned staging buffers: file read of chunk i+1 overlaps the H2D copy of
-    // chunk i; the 8 GB GRCh38 filter never needs a host-side image.  A padded layout lands in a temporary
-    // file-layout buffer on the device first and is widened there.
+    // stream the block payload through two pinned staging buffers: the file read of chunk i+1 (several threads, pread) overlaps the H2D
+    // copy of chunk i; the 8 GB GRCh38 filter never needs a host-side image.  A padded layout lands in a temporary file-layout buffer
+    // on the device first and is widened there.
     const uint64_t used = g.n_blocks * g.bin_width;
     const bool padded = f->stride != g.bin_width;
     uint64_t *d_dst = f->d_words;
-    hipError_t e = hipSuccess;
-    if (padded) e = hipMalloc((void **)&d_dst, std::max<uint64_t>(used, 1) * 8);
-    const size_t chunk_words = (size_t)8 << 20;  // 64 MiB
-    uint64_t *stage[2] = {nullptr, nullptr};
-    hipStream_t s = nullptr;
-    if (e == hipSuccess) e = hipStreamCreate(&s);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipHostMalloc((void **)&stage[i], chunk_words * 8, hipHostMallocDefault);
-    hipEvent_t done[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
     int rc = RB_OK;
-    if (e != hipSuccess) rc = rb::fail(RB_ERR_HIP, std::string("staging setup: ") + hipGetErrorString(e));
-    uint64_t pos = 0;
-    int slot = 0;
-    bool used_slot[2] = {false, false};
-    while (rc == RB_OK && pos < used) {
-        const size_t nw = (size_t)std::min<uint64_t>(chunk_words, used - pos);
-        if (used_slot[slot]) (void)hipEventSynchronize(done[slot]);
-        if (std::fread(stage[slot], 8, nw, fp) != nw) { rc = rb::fail(RB_ERR_PARSE_IBF, std::string(path) + ": short read"); break; }
-        e = hipMemcpyAsync(d_dst + pos, stage[slot], nw * 8, hipMemcpyHostToDevice, s);
-        if (e == hipSuccess) e = hipEventRecord(done[slot], s);
-        if (e != hipSuccess) { rc = rb::fail(RB_ERR_HIP, hipGetErrorString(e)); break; }
-        used_slot[slot] = true;
-        pos += nw;
-        slot ^= 1;
+    if (padded && hipMalloc((void **)&d_dst, std::max<uint64_t>(used, 1) * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        d_dst = nullptr;
+        rc = rb::fail(RB_ERR_HIP, "hipMalloc of the file-layout buffer failed");
     }
-    if (s) (void)hipStreamSynchronize(s);
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) (void)hipEventDestroy(done[i]);
-        if (stage[i]) (void)hipHostFree(stage[i]);
-    }
-    if (s) (void)hipStreamDestroy(s);
+    const int fd = fileno(fp);
+    const std::string name = path;
+    if (rc == RB_OK)
+        rc = stream_words_to_device(d_dst, used, [fd, &name](uint64_t *dst, uint64_t first, size_t n) {
+            if (!rb::pread_parallel(fd, (off_t)(8 + first * 8), dst, n * 8)) return rb::fail(RB_ERR_PARSE_IBF, name + ": short read");
+            return (int)RB_OK;
+        });
     std::fclose(fp);
     if (rc == RB_OK && padded) rc = dibf_from_compact(f, d_dst);
     if (padded && d_dst) (void)hipFree(d_dst);
     if (rc != RB_OK) { rb_dibf_free(f); return rc; }
+    dibf_settle(f);
     *out = f;
     return RB_OK;
 }

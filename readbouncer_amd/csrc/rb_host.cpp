@@ -3,6 +3,7 @@
 // calculateCI, calculate_filter_size_bits, cutOutNNNs); all counting/decision work is in the
 // HIP files.  Written from the behaviour of the cited reference lines, not from their text.
 #include "rb_internal.h"
+#include "rb_io.h"
 
 #include <cerrno>
 #include <cmath>
@@ -229,7 +230,8 @@ int rb_ibf_open(const char *path, rb_ibf **out)
     f->geo = g;
     f->words = (uint64_t *)std::malloc(g.n_words * 8);
     if (!f->words) { std::fclose(fp); delete f; return fail(RB_ERR_NOMEM, "cannot allocate IBF image"); }
-    if (std::fread(f->words, 8, g.n_words, fp) != g.n_words) {
+    // (the stream is positioned behind the 8-byte header; the words are read past it, by several threads for a large file)
+    if (!rb::pread_parallel(fileno(fp), (off_t)8, f->words, (size_t)g.n_words * 8)) {
         std::fclose(fp);
         rb_ibf_close(f);
         return fail(RB_ERR_PARSE_IBF, std::string(path) + ": short read");

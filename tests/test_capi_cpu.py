@@ -127,6 +127,32 @@ def test_build_helpers_match_oracle():
         assert o.add_sequence(np.zeros(L, dtype=np.uint8), F, 0) == len(s)
 
 
+def test_large_ibf_file_is_read_by_several_threads(tmp_path):
+    """rb_ibf_open reads files of 8 MiB and more with several pread threads (csrc/rb_io.h): same image as the oracle's loader, byte for
+    byte the same file when stored again; a file cut short is still a parse error, whichever thread meets the end."""
+    rng = np.random.default_rng(5)
+    n_bits = 128 * 1400003 + 17
+    c = capi.HostIBF.create(70, 3, 13, n_bits)
+    w = c.words()
+    nw = n_bits // 64
+    w[:nw] = rng.integers(0, 1 << 63, size=nw, dtype=np.uint64)
+    p = tmp_path / "big.ibf"
+    c.store(str(p))
+    assert os.path.getsize(p) > (16 << 20)
+    h = capi.HostIBF.open(str(p))
+    assert np.array_equal(h.words()[:nw], w[:nw])
+    o = po.OracleIBF.load(str(p))
+    assert np.array_equal(o.words()[:nw], h.words()[:nw])
+    q = tmp_path / "again.ibf"
+    h.store(str(q))
+    assert open(p, "rb").read() == open(q, "rb").read()
+    cut = tmp_path / "cut.ibf"
+    cut.write_bytes(open(p, "rb").read()[:-4096])
+    with pytest.raises(capi.RBError) as ei:
+        capi.HostIBF.open(str(cut))
+    assert ei.value.status == capi.RB_ERR_PARSE_IBF
+
+
 def test_ibf_file_io_against_oracle(tmp_path):
     rng = np.random.default_rng(2)
     o = po.OracleIBF(70, 3, 13, 128 * 1000 + 17)  # unaligned metadata

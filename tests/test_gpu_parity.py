@@ -1667,3 +1667,36 @@ def test_completion_word_of_the_micro_batch_path(nd, nt):
         b2 = buf[int(offs[s]):int(offs[s + n_sub - 1] + lens[s + n_sub - 1])]
         out = eng.classify(b2, o2, lens[s:s + n_sub])
         assert np.array_equal(out[0], exp_mc[s:s + n_sub]) and np.array_equal(out[2], exp_dec[s:s + n_sub]) and np.array_equal(out[3], exp_st[s:s + n_sub])
+
+
+@pytest.mark.parametrize("n_bins,n_blocks", [(8192, 150001), (600, 1700003)])
+def test_large_filter_files_stream_into_hbm(tmp_path, n_bins, n_blocks):
+    """IBF::load_filter at a size where the loader's machinery is in play (several 64 MiB chunks, several reader threads, the padded layout
+    widened on the device): rb_dibf_open and rb_ibf_open + rb_dibf_upload give the device image the file describes, bit for bit."""
+    W = (n_bins + 63) // 64
+    n_bits = n_blocks * W * 64 + 29
+    d = capi.DeviceIBF.create(0, n_bins, 3, 13, n_bits)
+    d.fill_synth(n_bins)
+    host = d.download()
+    want = host.words().copy()
+    p = tmp_path / "f.ibf"
+    host.store(str(p))
+    assert os.path.getsize(p) > (128 << 20)  # three chunks of the staged copy
+    a = capi.DeviceIBF.open(0, str(p))
+    ha = a.download()
+    assert np.array_equal(ha.words(), want)
+    h = capi.HostIBF.open(str(p))
+    nw = n_bits // 64  # (the words behind carry the metadata block in a file image, zeros in a downloaded one)
+    assert np.array_equal(h.words()[:nw], want[:nw])
+    b = capi.DeviceIBF.upload(0, h)
+    hb = b.download()
+    assert np.array_equal(hb.words(), want)
+    # and the opened filter classifies like the one it was stored from
+    rng = np.random.default_rng(3)
+    reads = [H.random_dna(rng, 300) for _ in range(64)]
+    buf, offs, lens = H.pack_reads(reads)
+    r0 = capi.Engine(0, [d], []).classify(buf, offs, lens)
+    r1 = capi.Engine(0, [a], []).classify(buf, offs, lens)
+    r2 = capi.Engine(0, [b], []).classify(buf, offs, lens)
+    for x, y, z in zip(r0, r1, r2):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
