@@ -75,11 +75,31 @@ static int replicate(rb_pool *p, rb_dibf *first, const int *devices, size_t n_de
 #else
     const bool fail_start = false, fail_finish = false;
 #endif
-    for (size_t d = from; d < n_devices; ++d) {
-        rb_dibf *f = nullptr;
-        int peer = 0;
-        if (!fail_start && rb_dibf_clone_start(first, devices[d], &f, &streams[d], &peer) == RB_OK) p->workers[d]->filters.push_back(f);
-        else fallback[d] = true;
+    // Allocating a replica includes the placement trial of its table (1-2 s for a table of 1 GiB and more): the destinations do that side
+    // by side, one thread per distinct GPU (workers that share a GPU take turns in their thread: trials probe the device they run on).
+    {
+        std::vector<rb_dibf *> made(n_devices, nullptr);
+        std::vector<int> distinct;
+        for (size_t d = from; d < n_devices; ++d)
+            if (std::find(distinct.begin(), distinct.end(), devices[d]) == distinct.end()) distinct.push_back(devices[d]);
+        auto start_on = [&](int dev) {
+            for (size_t d = from; d < n_devices; ++d) {
+                if (devices[d] != dev) continue;
+                int peer = 0;
+                if (fail_start || rb_dibf_clone_start(first, devices[d], &made[d], &streams[d], &peer) != RB_OK) made[d] = nullptr;
+            }
+        };
+        if (distinct.size() <= 1) {
+            for (int dev : distinct) start_on(dev);
+        } else {
+            std::vector<std::thread> th;
+            for (int dev : distinct) th.emplace_back(start_on, dev);
+            for (std::thread &t : th) t.join();
+        }
+        for (size_t d = from; d < n_devices; ++d) {
+            if (made[d]) p->workers[d]->filters.push_back(made[d]);
+            else fallback[d] = true;
+        }
     }
     for (size_t d = from; d < n_devices; ++d) {
         if (fallback[d]) continue;
