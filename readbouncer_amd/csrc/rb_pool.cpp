@@ -72,8 +72,12 @@ static int replicate(rb_pool *p, rb_dibf *first, const int *devices, size_t n_de
     const char *inject = std::getenv("RB_POOL_TEST_FAIL_CLONE");
     const bool fail_start = inject && std::strcmp(inject, "start") == 0;
     const bool fail_finish = inject && std::strcmp(inject, "finish") == 0;
+    // RB_POOL_TEST_THREAD_PER_WORKER=1: workers that share a GPU are started from threads of their own as if they sat on different GPUs
+    // (the side-by-side start below is otherwise never walked on a one-GPU box)
+    const char *tpw = std::getenv("RB_POOL_TEST_THREAD_PER_WORKER");
+    const bool thread_per_worker = tpw && tpw[0] == '1';
 #else
-    const bool fail_start = false, fail_finish = false;
+    const bool fail_start = false, fail_finish = false, thread_per_worker = false;
 #endif
     // Allocating a replica includes the placement trial of its table (1-2 s for a table of 1 GiB and more): the destinations do that side
     // by side, one thread per distinct GPU (workers that share a GPU take turns in their thread: trials probe the device they run on).
@@ -82,14 +86,19 @@ static int replicate(rb_pool *p, rb_dibf *first, const int *devices, size_t n_de
         std::vector<int> distinct;
         for (size_t d = from; d < n_devices; ++d)
             if (std::find(distinct.begin(), distinct.end(), devices[d]) == distinct.end()) distinct.push_back(devices[d]);
-        auto start_on = [&](int dev) {
-            for (size_t d = from; d < n_devices; ++d) {
-                if (devices[d] != dev) continue;
-                int peer = 0;
-                if (fail_start || rb_dibf_clone_start(first, devices[d], &made[d], &streams[d], &peer) != RB_OK) made[d] = nullptr;
-            }
+        auto start_one = [&](size_t d) {
+            int peer = 0;
+            if (fail_start || rb_dibf_clone_start(first, devices[d], &made[d], &streams[d], &peer) != RB_OK) made[d] = nullptr;
         };
-        if (distinct.size() <= 1) {
+        auto start_on = [&](int dev) {
+            for (size_t d = from; d < n_devices; ++d)
+                if (devices[d] == dev) start_one(d);
+        };
+        if (thread_per_worker) {
+            std::vector<std::thread> th;
+            for (size_t d = from; d < n_devices; ++d) th.emplace_back(start_one, d);
+            for (std::thread &t : th) t.join();
+        } else if (distinct.size() <= 1) {
             for (int dev : distinct) start_on(dev);
         } else {
             std::vector<std::thread> th;

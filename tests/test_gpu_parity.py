@@ -548,6 +548,12 @@ def test_pool_shards_reads_across_engines():
             env = dict(os.environ, RB_POOL_TEST_FAIL_CLONE=where, RB_AMD_LIBRARY=testing_lib)
             r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0 and "ladder ok " + where in r.stdout, (where, r.stdout[-500:], r.stderr[-1500:])
+        # replicas of different GPUs are allocated (placement trial included) from a thread per GPU: on one GPU the testing build starts
+        # every worker's replica from a thread of its own instead
+        env = dict(os.environ, RB_POOL_TEST_THREAD_PER_WORKER="1", RB_AMD_LIBRARY=testing_lib)
+        env.pop("RB_POOL_TEST_FAIL_CLONE", None)
+        r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "ladder ok None" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
         os.environ["RB_POOL_TEST_FAIL_CLONE"] = "start"  # the product library has no such switch: nothing changes
         try:
             pool = capi.Pool.from_files([0, 0, 0], paths[:1], paths[1:])
@@ -1700,3 +1706,34 @@ def test_large_filter_files_stream_into_hbm(tmp_path, n_bins, n_blocks):
     r2 = capi.Engine(0, [b], []).classify(buf, offs, lens)
     for x, y, z in zip(r0, r1, r2):
         assert np.array_equal(x, y) and np.array_equal(x, z)
+
+
+def test_pool_replicas_of_a_large_filter_started_side_by_side():
+    """Replicas of a table of 1 GiB (placed by trial) for three workers, each started from a thread of its own -- what a pool over several
+    GPUs does, one thread per GPU; here, on one GPU, by the testing build's switch -- give a pool that classifies like a single engine."""
+    import subprocess
+    child = ("import os, sys, numpy as np\n"
+             "sys.path.insert(0, %r)\n"
+             "from readbouncer_amd import capi\n"
+             "from tests import helpers as H\n"
+             "d = capi.DeviceIBF.create(0, 8192, 3, 13, 1 << 33)\n"
+             "d.fill_synth(3)\n"
+             "rng = np.random.default_rng(8)\n"
+             "ref = H.random_dna(rng, 40000)\n"
+             "d.add_sequence(ref, 1000)\n"
+             "reads = [H.mutate(rng, ref[s:s + 360], 0.05) if i %% 2 else H.random_dna(rng, 360) for i, s in enumerate(rng.integers(0, 39000, size=3000))]\n"
+             "buf, offs, lens = H.pack_reads(reads)\n"
+             "want = capi.Engine(0, [d], []).classify(buf, offs, lens)\n"
+             "pool = capi.Pool.from_device([0, 0, 0], [d], [])\n"
+             "assert pool.size() == 3\n"
+             "pool.set_min_split(200)\n"
+             "got = pool.classify(buf, offs, lens)\n"
+             "same = [bool(np.array_equal(a, b)) for a, b in zip(got, want)]\n"
+             "print('same', same, 'decisions', np.bincount(want[2], minlength=3).tolist(), 'differing reads', np.nonzero(got[0][:, 0] != want[0][:, 0])[0][:10].tolist())\n"
+             "assert all(same) and len(set(want[2].tolist())) == 2\n"
+             "pool.destroy()\n"
+             "print('side by side ok', d.placement()[0])\n") % (ROOT,)
+    testing_lib = os.path.join(ROOT, "readbouncer_amd", "libreadbouncer_amd_testing.so")
+    env = dict(os.environ, RB_POOL_TEST_THREAD_PER_WORKER="1", RB_AMD_LIBRARY=testing_lib)
+    r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "side by side ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
