@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #define CK(x)                                                                         \
@@ -51,8 +52,16 @@ static void report(const char *name, int kernels, double spin_us, std::vector<do
                 t[t.size() / 2], t[t.size() * 99 / 100], t[t.size() / 2] - kernels * spin_us);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    // how the host waits inside hipStreamSynchronize: "spin" / "yield" / "block" set the device's schedule flag before anything else
+    // touches the device (default: hipDeviceScheduleAuto); the runtime's environment switches are tried from the shell (sessions/s30.sh)
+    if (argc > 1) {
+        const std::string how = argv[1];
+        const unsigned flag = how == "spin" ? hipDeviceScheduleSpin : how == "yield" ? hipDeviceScheduleYield : how == "block" ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto;
+        CK(hipSetDeviceFlags(flag));
+        std::printf("# hipSetDeviceFlags(%s)\n", how.c_str());
+    }
     uint32_t *d = nullptr;
     CK(hipMalloc(&d, 256));
     hipStream_t st;
