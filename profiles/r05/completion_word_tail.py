@@ -1,6 +1,7 @@
 """The tail of the completion-word path: rb_engine_set_completion_word modes 0 (stream wait in every call), 1 (word; the stream is waited for
 every 256th call), n > 1 (that period instead; 2147483647 = never).  (An earlier version of the library also had "word + hipStreamQuery / hipStreamSynchronize
-at the start of every next call": both cost what the word saves, kept in completion_word_tail_first.txt.)  Per mode and batch size: p50 / p90 / p99 / p99.9 / max over 4 000 calls, how many
+at the start of every next call": both cost what the word saves -- one read: stream wait 40.6, word 36.1, word + query 41.8, word + synchronise 45.4 us; the numbers are in
+negative_results.md, entry 12.)  Per mode and batch size: p50 / p90 / p99 / p99.9 / max over 4 000 calls, how many
 calls took more than p50 + 8 us and the gaps (in calls) between them; then the config 5 replay per mode, three times."""
 import os, sys, time
 import numpy as np, torch
