@@ -1066,7 +1066,12 @@ def pool_child(ctx, steps, timeout_s=600):
         return ctx._pool_child
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
-                        "TORCHELASTIC_RUN_ID", "RB_BENCH_SELF_LAUNCHED", "RB_BENCH_BACKEND", "RB_BENCH_SAME_GPU", "RB_BENCH_FORCE_GROUP")}
+                        "TORCHELASTIC_RUN_ID", "RB_BENCH_SELF_LAUNCHED", "RB_BENCH_BACKEND", "RB_BENCH_SAME_GPU", "RB_BENCH_FORCE_GROUP",
+                        # (the parent's checkpoint file and its "you have a supervisor" mark are the parent's: a child that raised outside
+                        # run_pool would otherwise report the PARENT's headline as its own result)
+                        "RB_BENCH_PARTIAL", "RB_BENCH_SUPERVISED")}
+    env["RB_BENCH_NO_SUPERVISOR"] = "1"   # the child measures itself; this process is its supervisor
+    env["RB_BENCH_CHILD_OF_BENCH"] = "1"  # ... and it dies with this process (die_with_parent)
     env["RB_BENCH_POOL_CHILD"] = "0"
     env["RB_BENCH_POOL_PREFLIGHT"] = "1"
     if "RB_BENCH_POOL_DEVICES" not in env:
@@ -1094,7 +1099,7 @@ def pool_child(ctx, steps, timeout_s=600):
                 os.unlink(side)
         if not lines or head is None:
             out = failed("child exit code %d, no line; stderr tail: %s" % (p.returncode, p.stderr.strip()[-300:]))
-        elif head.get("error") and not head.get("value"):
+        elif head.get("error") and (not head.get("value") or p.returncode != 0):
             out = failed("child exit code %d: %s" % (p.returncode, head["error"]))
         else:
             c4 = (head.pop("other_configs", None) or {}).get("pool_c4")
@@ -1411,12 +1416,30 @@ def null_engine_run(args, torch, dist, world, rank, backend):
         dist.destroy_process_group()
 
 
+def die_with_parent():
+    """A measuring process started by this file (the supervisor's child, a self-launched rank, the pool child) must not outlive the
+    process that started it: a supervisor that is SIGKILLed -- a driver's hard timeout, `timeout -k`, the OOM killer -- cannot forward
+    anything, and its orphan would go on running legs of 8 GiB filters for minutes, holding HBM and skewing whoever measures next
+    (ADVICE r5).  PR_SET_PDEATHSIG asks the kernel for a SIGKILL when the parent is gone; the getppid() check closes the window before
+    the call."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)  # PR_SET_PDEATHSIG = 1
+    except Exception:  # noqa: BLE001
+        return
+    if os.getppid() == 1:  # the parent went away before the call took effect
+        os._exit(1)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus)  # before anything touches the GPU
     if int(os.environ.get("RANK", "0")) == 0 and os.environ.get("RB_BENCH_SUPERVISED") != "1" and os.environ.get("RB_BENCH_NO_SUPERVISOR") != "1":
         return supervise(sys.argv[1:])  # N = 1, or rank 0 under torchrun: the measuring process is a child of this one
+    if os.environ.get("RB_BENCH_SUPERVISED") == "1" or os.environ.get("RB_BENCH_SELF_LAUNCHED") == "1" or os.environ.get("RB_BENCH_CHILD_OF_BENCH") == "1":
+        die_with_parent()
     import torch
 
     t_start = time.time()

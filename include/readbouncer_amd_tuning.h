@@ -64,11 +64,17 @@ RB_API int rb_live_replay_arrivals(rb_live *lv, const uint32_t *read_ids, const 
  * the next (where the driver finds the pages -- an 8 GiB power-of-two table always gets the fast kind, a reference-sized 4.7 GB one does
  * or does not), so rb_dibf_create / _upload / _open / _clone_to / _resize_bins allocate up to `tries` candidates (default 5), probe each
  * with random whole-block gathers (~0.1 s), stop early only when one is 3 % faster than the slowest seen, keep the best and free the others.
- * Transient cost: up to (tries - 1) x the table of HBM at load time (never more than half of what is free).  tries = 0 or 1: off.
- * Process-wide; results never depend on it.  rb_dibf_placement: how many allocations were probed for this filter (0: not placed by
+ * Transient cost: up to (tries - 1) x the table of HBM at load time (never more than half of what is free) and 1-2 s.  tries = 0 or 1: off.
+ * Never done on a device where an engine of this process is alive (see rb_dibf_placement_cost).  Process-wide; results never depend on it.  rb_dibf_placement: how many allocations were probed for this filter (0: not placed by
  * trial), what the kept one and the slowest one delivered in GB/s. */
 RB_API int rb_set_placement_tries(int tries);
 RB_API int rb_dibf_placement(const rb_dibf *f, uint32_t *tries, double *kept_gbps, double *worst_gbps);
+/* What the trial cost for this filter: seconds spent allocating and probing the candidates, seconds waited afterwards until the kept
+ * table probed as in the trial (bounded by 3 s; the driver clears the freed candidates in the background), the most HBM the candidates
+ * held at once, and -- for a table of 1 GiB or more that was NOT placed by trial -- why: 1 = an engine was alive on the device (a
+ * process that is already classifying there is not stalled by probe launches and transient copies: the table takes the first
+ * allocation), 2 = less than twice the table was free.  bench.py keeps these per filter in bench_detail.json.  Any pointer may be NULL. */
+RB_API int rb_dibf_placement_cost(const rb_dibf *f, double *trial_seconds, double *settle_seconds, uint64_t *peak_bytes, uint32_t *skipped);
 
 /* ---- engine: kernel forms, planner, timing, probe ------------------------------------------------ */
 /* Filters of one hash geometry in one table.  Every filter the reference builds with one fragment_size has noOfBits =
@@ -179,6 +185,21 @@ RB_API int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_len, 
  * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and
  * never more than max_slices (1-32, default 32; a table that would need more gets larger slices).  Results are identical. */
 RB_API int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_slices);
+
+/* Two-word tables (65-128 bins, or two to three small targets merged) of up to 2^21 - 1 blocks (32 MiB), reads of up to 256 k-mers, phased
+ * form: `reads` = 2 or 3 takes the build that carries that many reads per wave through one pass of the windows -- AND accumulators in
+ * registers, block numbers packed into LDS -- so that a pass, which reloads the table once per XCD whatever rides along, serves more
+ * reads (40 instead of 28 per CU at two reads per wave); 1 = one read per wave with the offsets in LDS (eight waves per SIMD);
+ * 0 = the one-read build that keeps the offsets in registers.  On a merged table these builds gather from a complemented twin of the
+ * copy (the bounds check's zero is then neutral and the masking goes away); + 16 keeps the AND form there too (measurements).
+ * Results are identical. */
+RB_API int rb_engine_set_reads_per_wave(rb_engine *e, uint32_t reads);
+
+/* How the eight XCDs walk the slices of a phased table (each has an L2 of its own, so each reloads every slice): bit 0 of `mode` -- at
+ * any time every XCD works on a different slice (slice = (window + XCD number) mod slices); bit 1 -- the XCDs' windows start an eighth
+ * of a window apart, so that they refill their L2s one after the other instead of all in the same instant.  0 (default): one clock, one
+ * slice for the whole chip.  Results are identical. */
+RB_API int rb_engine_set_phase_xcd_skew(rb_engine *e, uint32_t mode);
 
 /* Host batches above 8 MB of read bytes cross PCIe in slices of about slice_bytes (default 32 MiB): slice i+1 is
  * copied on a copy stream while slice i is counted.  0 = one slice (no overlap).  Results are identical. */

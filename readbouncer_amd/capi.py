@@ -124,6 +124,7 @@ SIGNATURES = {
     "rb_set_default_revcomp_of_n": (_int, [_u32]),
     "rb_set_placement_tries": (_int, [_int]),
     "rb_dibf_placement": (_int, [_vp, C.POINTER(_u32), C.POINTER(_dbl), C.POINTER(_dbl)]),
+    "rb_dibf_placement_cost": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_dbl), C.POINTER(_u64), C.POINTER(_u32)]),
     "rb_engine_set_merge": (_int, [_vp, _int]),
     "rb_engine_merge_info": (_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     "rb_engine_set_split_threshold": (_int, [_vp, _u32]),
@@ -135,6 +136,8 @@ SIGNATURES = {
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_serial_table_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_phase_slices": (_int, [_vp, _u32, _u32]),
+    "rb_engine_set_reads_per_wave": (_int, [_vp, _u32]),
+    "rb_engine_set_phase_xcd_skew": (_int, [_vp, _u32]),
     "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -309,6 +312,12 @@ class DeviceIBF:
         t, g, w = _u32(0), _dbl(0.0), _dbl(0.0)
         _check(lib().rb_dibf_placement(self.h, C.byref(t), C.byref(g), C.byref(w)), "rb_dibf_placement")
         return t.value, g.value, w.value
+
+    def placement_cost(self):
+        """-> dict: seconds of the trial, seconds waited after it, most HBM its candidates held, why a large table was not tried (0 / 1 / 2)"""
+        ts, ss, pk, sk = _dbl(0.0), _dbl(0.0), _u64(0), _u32(0)
+        _check(lib().rb_dibf_placement_cost(self.h, C.byref(ts), C.byref(ss), C.byref(pk), C.byref(sk)), "rb_dibf_placement_cost")
+        return {"trial_s": ts.value, "settle_s": ss.value, "peak_bytes": pk.value, "skipped": sk.value}
 
     def resize_bins(self, new_bins):
         h = C.c_void_p()
@@ -503,6 +512,14 @@ class Engine:
     def set_phase_slices(self, slice_log2=0, max_slices=32):
         """slices of 2^slice_log2 bytes (0: built-in rule; 1-5: as small as max_slices allows), at most max_slices"""
         _check(lib().rb_engine_set_phase_slices(self.h, slice_log2, max_slices), "rb_engine_set_phase_slices")
+
+    def set_reads_per_wave(self, reads):
+        """two-word phased tables, reads of up to 256 k-mers: reads a wave carries through a pass of the windows (0: the one-read build)"""
+        _check(lib().rb_engine_set_reads_per_wave(self.h, reads), "rb_engine_set_reads_per_wave")
+
+    def set_phase_xcd_skew(self, mode):
+        """bit 0: every XCD on a different slice at any time; bit 1: the XCDs' windows start an eighth of a window apart"""
+        _check(lib().rb_engine_set_phase_xcd_skew(self.h, mode), "rb_engine_set_phase_xcd_skew")
 
     def set_host_slice_bytes(self, slice_bytes):
         _check(lib().rb_engine_set_host_slice_bytes(self.h, slice_bytes), "rb_engine_set_host_slice_bytes")

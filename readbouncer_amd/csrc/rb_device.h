@@ -45,6 +45,8 @@ struct PhaseCfg {
     uint32_t inv_ticks;  // floor(2^32 / window length in 10 ns ticks)
     uint32_t skew;       // added to the window number: 0, or this wave's XCD number when xcd_skew is set (experiment)
     uint32_t xcd_skew;   // 1: every XCD works on a different slice at any time (slice = (window + XCD) mod n_slices)
+    uint32_t tskew;      // wall-clock ticks by which each XCD's windows start later than the previous XCD's (the kernel multiplies by its XCD
+                         // number): the XCDs then refill their L2s one after the other, not all in the same instant.  0: one clock for the chip
 };
 
 constexpr unsigned kMaxFused = 8;
@@ -115,6 +117,9 @@ struct CountLaunch {
     uint32_t phase_rule_ticks;               // ... and what the planner's table alone would give (rb_engine_calibrate may have replaced it)
     uint64_t phase_slice_bytes;              // ... and the slice length in effect (2^phase_slice_log2, or the equal-length slices of the four-word builds)
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
+    int multi_reads;              // phased form, two-word blocks, short_only 1: reads per wave of ibf_count_max_phased_multi_kernel (0: the one-read build)
+    int multi_aux;                // ... cache-policy bits of its gathers (experiments; 0 = default)
+    int multi_inv;                // ... and f.words is the COMPLEMENTED twin of a merged copy (the build that ORs instead of masking and ANDing)
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)
     int grid_parts;               // latency form: workgroups launched per (read, slice) = max parts of the fused filters
@@ -171,6 +176,7 @@ struct FoldJob {
 hipError_t launch_ibf_count_max(const CountLaunch &a, hipStream_t st);
 hipError_t launch_ibf_count_max_merged(const CountLaunch &a, const MergeMap &map, hipStream_t st);
 // block b of a filter (width words at stride s_src, n_bins bins) -> bits [dst_bit, dst_bit + n_bins) of block b of dst (ORed in: dst starts zeroed)
+hipError_t launch_invert_words(const uint64_t *src, uint64_t *dst, uint64_t n_words, hipStream_t st);
 hipError_t launch_merge_bits(const uint64_t *src, uint32_t s_src, uint32_t width, uint32_t n_bins, uint64_t *dst, uint32_t s_dst, uint32_t dst_bit,
                              uint64_t n_blocks, hipStream_t st);
 int split_waves_limit(int wpl, int planes, uint32_t max_kmers, int lg);

@@ -44,6 +44,11 @@ struct rb_dibf {
     // placement by trial (dibf_alloc): allocations that were probed for this table, what the kept one and the worst one delivered
     uint32_t placement_tries = 0;
     double placement_gbps = 0.0, placement_worst_gbps = 0.0;
+    // ... and what the trial cost (rb_dibf_placement_cost): seconds spent allocating and probing candidates, seconds waited afterwards
+    // for the device to calm down, the most HBM the candidates held at once, and why a table of that size was NOT placed by trial
+    double placement_trial_s = 0.0, placement_settle_s = 0.0;
+    uint64_t placement_peak_bytes = 0;
+    uint32_t placement_skipped = 0;  // 0: placed by trial (or too small / switched off); 1: an engine was live on the device; 2: not enough free HBM
     // ... and the wait that follows a trial (the driver clears the freed candidates in the background), when the caller of dibf_alloc has
     // work of its own to do first (streaming the file in): see dibf_settle
     bool settle_pending = false;
@@ -61,30 +66,46 @@ struct rb_dibf {
 // for a fraction of a second at load time; results never depend on it.  rb_set_placement_tries(1) switches it off.
 static std::atomic<int> g_placement_tries{5};
 static constexpr uint64_t kPlacementMinBytes = 1ull << 30;
+// engines alive per device: a process that is already classifying on a device is not stalled for seconds (probe launches of 32 k waves,
+// up to four more copies of the table held at once) because a second filter is loaded or cloned there -- such a table takes the first
+// allocation.  The trial is for the start-up of a process: filters first, engines afterwards.
+static constexpr int kPlacementDevices = 64;
+static std::atomic<int> g_engines_on_device[kPlacementDevices];
 
 // the wait after a trial: until the kept table probes like it did in the trial, at most 3 s after the candidates were freed
-static void settle_table(void *table, uint64_t bytes, uint32_t row, double trial_gbps, std::chrono::steady_clock::time_point t0)
+static double settle_table(void *table, uint64_t bytes, uint32_t row, double trial_gbps, std::chrono::steady_clock::time_point t0)
 {
+    const auto begin = std::chrono::steady_clock::now();
     while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(3000)) {
         double g = 0.0;
         if (rb::probe_read_peak_raw(table, bytes - 64, row, bytes > (512ull << 20), 24, 30.0, &g, nullptr) != RB_OK) break;
         if (g >= 0.993 * trial_gbps) break;
     }
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - begin).count();
 }
 
 static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uint64_t **out, uint32_t *tries_out, double *gbps_out, double *worst_out,
-                                       rb_dibf *defer_settle_to = nullptr)
+                                       rb_dibf *account, bool defer_settle)
 {
     *tries_out = 0;
     *gbps_out = *worst_out = 0.0;
     int tries = g_placement_tries.load();
     size_t free_b = 0, total_b = 0;
-    if (bytes >= kPlacementMinBytes && tries > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        tries = (int)std::min<uint64_t>((uint64_t)tries, (uint64_t)free_b / 2 / bytes);  // never more than half of what is free
+    int dev = 0;
+    if (bytes >= kPlacementMinBytes && tries > 1 && hipGetDevice(&dev) == hipSuccess && g_engines_on_device[(unsigned)dev % kPlacementDevices].load() > 0) {
+        tries = 1;
+        if (account) account->placement_skipped = 1;
+    }
+    if (bytes >= kPlacementMinBytes && tries > 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const int room = (int)std::min<uint64_t>((uint64_t)tries, (uint64_t)free_b / 2 / bytes);  // never more than half of what is free
+        if (room <= 1 && account) account->placement_skipped = 2;
+        tries = room;
+    }
     if (bytes < kPlacementMinBytes || tries <= 1) {
         (void)hipGetLastError();
         return hipMalloc((void **)out, bytes);
     }
+    const auto trial_t0 = std::chrono::steady_clock::now();
     const uint32_t row = block_bytes >= 3072 ? 4096u : block_bytes >= 1024 ? 1024u : 128u;
     std::vector<std::pair<double, void *>> cand;
     double worst = 0.0, best_g = 0.0;
@@ -120,14 +141,19 @@ static hipError_t alloc_table_by_trial(uint64_t bytes, uint32_t block_bytes, uin
     // serves at once should find a quiet device: wait, bounded, until the kept table probes like it did in the trial.
     // A caller that fills the table from a file first (rb_dibf_open: 0.3-0.8 s for 8 GiB) does its work in that second and waits for the rest
     // afterwards (dibf_settle).
+    if (account) {
+        account->placement_trial_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - trial_t0).count();
+        account->placement_peak_bytes = (uint64_t)cand.size() * bytes;
+    }
     if (cand.size() > 1) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (defer_settle_to) {
-            defer_settle_to->settle_pending = true;
-            defer_settle_to->settle_row = row;
-            defer_settle_to->settle_t0 = t0;
+        if (defer_settle && account) {
+            account->settle_pending = true;
+            account->settle_row = row;
+            account->settle_t0 = t0;
         } else {
-            settle_table(cand[best].second, bytes, row, cand[best].first, t0);
+            const double waited = settle_table(cand[best].second, bytes, row, cand[best].first, t0);
+            if (account) account->placement_settle_s = waited;
         }
     }
     *out = (uint64_t *)cand[best].second;
@@ -205,6 +231,8 @@ struct MergedTable {
     std::vector<const rb_dibf *> key_filters;  // the members, in the order their bins sit in a merged block
     std::vector<uint32_t> key_bit_begin;
     uint64_t *d_words = nullptr;
+    uint64_t *d_inv = nullptr;  // two-word copies of fewer than 2^21 - 1 blocks: the COMPLEMENT of the copy, behind it in the same allocation (the
+                                // multi-read build of the phased kernel ORs complemented words instead of masking and ANDing: rb_kernels.hip)
     uint64_t stride = 0, width = 0, n_blocks = 0;
     IbfDev dev{};
     std::vector<uint64_t> versions;  // rb_dibf::version of each member when the copy was made
@@ -265,6 +293,7 @@ static std::atomic<uint32_t> g_default_revcomp_of_n{rbspec::kRevCompOfN};
 
 struct rb_engine {
     int device = 0;
+    bool counted_on_device = false;  // g_engines_on_device (placement by trial is skipped on a device that is already classifying)
     std::vector<rb_dibf *> filters;  // deplete first, then target (borrowed)
     uint32_t nd = 0, nt = 0;
     hipStream_t stream = nullptr;
@@ -294,7 +323,15 @@ struct rb_engine {
     uint32_t phase_max_slices = 32;   // slices a table is cut into (<= 32: a wave keeps a bit per slice)
     uint32_t phase_slice_log2 = 0;    // slices of 2^n bytes instead of the rule of phase_slice_log2(); 1-5: as small as phase_max_slices allows
     uint32_t phase_n_slices = 0;      // RB_PHASE_N_SLICES: that many equal-length slices for the four-word one-lane builds (0: phase_equal_slices())
-    uint32_t phase_xcd_skew = 0;      // experiment (RB_PHASE_XCD_SKEW=1): slice = (window + XCD number) mod n_slices
+    uint32_t phase_xcd_skew = 0;      // rb_engine_set_phase_xcd_skew (RB_PHASE_XCD_SKEW): bit 0: slice = (window + XCD number) mod n_slices; bit 1: the
+                                      // XCDs' windows start an eighth of a window apart (they refill their L2s one after the other)
+    // rb_engine_set_reads_per_wave: two-word tables of up to 2^21 - 1 blocks, reads of up to 256 k-mers, phased: the build that carries
+    // that many reads per wave through a pass of the windows, offsets in LDS (rb_kernels.hip, ibf_count_max_phased_multi_kernel); 0: the
+    // one-read build
+    uint32_t multi_reads = 0;
+    uint32_t multi_aux = 0;     // RB_MULTI_AUX: cache-policy bits of the multi-read build's gathers (experiments)
+    uint32_t phase_tskew_div = 8;  // RB_PHASE_TSKEW_DIV: the XCDs' windows start 1 / this of a window apart (time skew)
+    bool multi_no_inv = false;  // (bit 4 of rb_engine_set_reads_per_wave's argument: the AND form on merged copies too; measurements)
     // rb_engine_calibrate: window lengths measured on this device that replace the planner's for a (table, kernel shape, slice size)
     struct PhaseOverride {
         uint64_t table_bytes;
@@ -434,7 +471,7 @@ static int dibf_alloc(int device, const rb_ibf_info &g, bool zero, rb_dibf **out
     f->geo = g;
     f->stride = hbm_stride(g.bin_width);
     hipError_t e = alloc_table_by_trial(dibf_device_words(f) * 8, (uint32_t)(f->stride * 8), &f->d_words, &f->placement_tries, &f->placement_gbps,
-                                        &f->placement_worst_gbps, defer_settle ? f : nullptr);
+                                        &f->placement_worst_gbps, f, defer_settle);
     if (e != hipSuccess) {
         delete f;
         return rb::fail(RB_ERR_HIP, std::string("hipMalloc of the IBF failed: ") + hipGetErrorString(e));
@@ -457,7 +494,7 @@ static void dibf_settle(rb_dibf *f)
 {
     if (!f || !f->settle_pending) return;
     f->settle_pending = false;
-    settle_table(f->d_words, dibf_device_words(f) * 8, f->settle_row, f->placement_gbps, f->settle_t0);
+    f->placement_settle_s = settle_table(f->d_words, dibf_device_words(f) * 8, f->settle_row, f->placement_gbps, f->settle_t0);
 }
 
 // `words` 64-bit words into d_dst through two page-locked 64 MiB staging buffers: `fill(dst, first_word, n_words)` produces chunk i + 1
@@ -880,7 +917,12 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
             if (std::atoi(v) >= 1 && std::atoi(v) <= 26) { e->phase_slice_log2 = (uint32_t)std::atoi(v); note("RB_PHASE_SLICE_LOG2", v); }
         }
         if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
-        if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = std::atoi(v) != 0; note("RB_PHASE_XCD_SKEW", v); }
+        if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = (uint32_t)std::atoi(v) & 3u; note("RB_PHASE_XCD_SKEW", v); }
+        if (const char *v = std::getenv("RB_MULTI_AUX")) { e->multi_aux = (uint32_t)std::atoi(v); note("RB_MULTI_AUX", v); }
+        if (const char *v = std::getenv("RB_PHASE_TSKEW_DIV")) { if (std::atoi(v) >= 1) { e->phase_tskew_div = (uint32_t)std::atoi(v); note("RB_PHASE_TSKEW_DIV", v); } }
+        if (const char *v = std::getenv("RB_MULTI_READS")) {  // rb_engine_set_reads_per_wave is the API
+            if (std::atoi(v) >= 0 && std::atoi(v) <= 3) { e->multi_reads = (uint32_t)std::atoi(v); note("RB_MULTI_READS", v); }
+        }
         if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
         if (const char *v = std::getenv("RB_MICRO_COPY_KERNEL_BYTES")) { e->micro_copy_kernel_bytes = std::strtoull(v, nullptr, 10); note("RB_MICRO_COPY_KERNEL_BYTES", v); }
     }
@@ -898,6 +940,8 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
     }
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming);
     if (he == hipSuccess) he = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+    e->counted_on_device = true;  // (before the failure path below: rb_engine_destroy takes the count back)
+    g_engines_on_device[(unsigned)device % kPlacementDevices].fetch_add(1);
     if (he != hipSuccess) { rb_engine_destroy(e); return rb::fail(RB_ERR_HIP, hipGetErrorString(he)); }
     *out = e;
     return RB_OK;
@@ -906,6 +950,7 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
 void rb_engine_destroy(rb_engine *e)
 {
     if (!e) return;
+    if (e->counted_on_device) g_engines_on_device[(unsigned)e->device % kPlacementDevices].fetch_sub(1);
     (void)hipSetDevice(e->device);
     if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
     for (auto &p : e->ev_ring) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -946,6 +991,16 @@ int rb_set_placement_tries(int tries)
 {
     if (tries < 0 || tries > 8) return rb::fail(RB_ERR_INVALID_ARG, "placement tries: 0 / 1 (off) to 8");
     g_placement_tries.store(tries);
+    return RB_OK;
+}
+
+int rb_dibf_placement_cost(const rb_dibf *f, double *trial_seconds, double *settle_seconds, uint64_t *peak_bytes, uint32_t *skipped)
+{
+    if (!f) return rb::fail(RB_ERR_INVALID_ARG, "null filter");
+    if (trial_seconds) *trial_seconds = f->placement_trial_s;
+    if (settle_seconds) *settle_seconds = f->placement_settle_s;
+    if (peak_bytes) *peak_bytes = f->placement_peak_bytes;
+    if (skipped) *skipped = f->placement_skipped;
     return RB_OK;
 }
 
@@ -1097,6 +1152,25 @@ int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_s
     std::lock_guard<std::mutex> lock(e->mu);
     e->phase_slice_log2 = slice_log2;
     e->phase_max_slices = max_slices;
+    e->phase_overrides.clear();
+    return RB_OK;
+}
+
+int rb_engine_set_phase_xcd_skew(rb_engine *e, uint32_t mode)
+{
+    if (!e || mode > 3) return rb::fail(RB_ERR_INVALID_ARG, "mode 0..3 (bit 0: slice skew, bit 1: time skew)");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->phase_xcd_skew = mode;
+    e->phase_overrides.clear();
+    return RB_OK;
+}
+
+int rb_engine_set_reads_per_wave(rb_engine *e, uint32_t reads)
+{
+    if (!e || (reads & ~16u) > 3) return rb::fail(RB_ERR_INVALID_ARG, "0 (the one-read build) to 3 reads per wave");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->multi_reads = reads & 3u;
+    e->multi_no_inv = (reads & 16u) != 0;
     e->phase_overrides.clear();
     return RB_OK;
 }
@@ -1258,6 +1332,9 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     if (e->split_threshold && (uint64_t)n_reads * a.n_slices <= e->split_threshold && f->geo.n_hash == 3)
         a.split_waves = split_waves_limit(a.wpl, a.planes, kmers, a.lg);
     a.phase = PhaseCfg{0, 0, 0, 0, 0};
+    a.multi_reads = 0;
+    a.multi_inv = 0;
+    a.multi_aux = 0;
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
     // (profiles/r03/window_sweep.txt: with the bounds-checked gathers and its own window length the six-tile kernel takes 28 %
@@ -1330,8 +1407,16 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.shift = blocks_per_slice ? (0x80000000u | (uint32_t)blocks_per_slice) : sh;  // bit 31: the low bits are blocks per slice, any number
             a.phase.n_slices = n_sl;
             a.phase.inv_ticks = (uint32_t)((1ull << 32) / ticks);
-            a.phase.xcd_skew = e->phase_xcd_skew;
+            a.phase.xcd_skew = e->phase_xcd_skew & 1u;
+            a.phase.tskew = (e->phase_xcd_skew & 2u) ? (uint32_t)(ticks / e->phase_tskew_div) : 0u;  // each XCD's windows start an eighth of a window after the previous one's
             a.phase_slice_bytes = blocks_per_slice ? blocks_per_slice * f->stride * 8 : (f->stride * 8) << sh;
+            // several reads per wave (two-word blocks, up to 256 k-mers, block numbers of 21 bits)
+            if (e->multi_reads && a.lg == 1 && a.short_only == 1 && a.planes <= 10 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2 &&
+                f->geo.n_blocks < (1ull << 21) - 1)
+            {
+                a.multi_reads = (int)e->multi_reads;
+                a.multi_aux = (int)e->multi_aux;
+            }
         } else if ((a.lg == 0 || (shape != PhaseShape::General && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
                     ((shape == PhaseShape::WideFourTiles || shape == PhaseShape::Wide3FourTiles) && phase_fill(shape, kmers) >= 0.8 &&
                      table_bytes < phase_shape_min_bytes(shape, a.lg, 1.0))) && e->short_read_kernel) {
@@ -1640,12 +1725,14 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
         if (!t->d_words) {
             t->stride = hbm_stride(g->width);
             t->n_blocks = g->n_blocks;
-            if (hipMalloc((void **)&t->d_words, (t->n_blocks * t->stride + 8) * 8) != hipSuccess) {
+            const bool twin = t->stride == 2 && g->width == 2 && t->n_blocks < (1ull << 21) - 1;
+            if (hipMalloc((void **)&t->d_words, (t->n_blocks * t->stride + 8) * 8 * (twin ? 2 : 1)) != hipSuccess) {
                 (void)hipGetLastError();
                 t->d_words = nullptr;
                 g->tab.reset();
                 return kMergeNoMemory;
             }
+            t->d_inv = twin ? t->d_words + (t->n_blocks * t->stride + 8) : nullptr;
         } else {
             RB_HIP(hipDeviceSynchronize());  // made again: a kernel of an earlier call (of any engine, on any stream) may still read the old copy
         }
@@ -1657,6 +1744,7 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
             RB_HIP(launch_merge_bits(f->d_words, (uint32_t)f->stride, (uint32_t)f->geo.bin_width, (uint32_t)f->geo.n_bins, t->d_words,
                                      (uint32_t)t->stride, g->bit_begin[i], t->n_blocks, st));
         }
+        if (t->d_inv) RB_HIP(launch_invert_words(t->d_words, t->d_inv, t->n_blocks * t->stride + 8, st));
         rb_ibf_info geo = e->filters[g->members[0]]->geo;  // noOfBlocks, k, h of the members
         geo.bin_width = g->width;
         geo.n_bins = g->width * 64;
@@ -1784,6 +1872,10 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
                 if (planned && p.phase.n_slices && p.split_waves < 2 && p.planes <= 10 && one_lane && g->map.n <= kMaxNarrow) {
                     p.f = g->dev;
                     p.f.comp_n = e->revcomp_of_n;
+                    if (p.multi_reads && g->tab && g->tab->d_inv && !e->multi_no_inv) {  // the complemented twin of the copy: the OR form of the multi-read build
+                        p.f.words = g->tab->d_inv;
+                        p.multi_inv = 1;
+                    }
                     p.narrow = NarrowMerge{};
                     p.narrow.n = g->map.n;
                     for (uint32_t c = 0; c < 4; ++c) {  // bins of a column are its low bits in both layouts: up to the end of the last member in it
@@ -1969,8 +2061,9 @@ extern "C" int rb_engine_plan(rb_engine *e, size_t filter_index, size_t n_reads,
     const char *form = "ibf_count_max_kernel";
     if (a.split_waves >= 2) form = "ibf_count_max_split_kernel";
     else if (merged_plain) form = "ibf_count_max_merged_kernel";
-    else if (a.phase.n_slices) form = "ibf_count_max_phased_kernel";
+    else if (a.phase.n_slices) form = a.multi_reads ? "ibf_count_max_phased_multi_kernel" : "ibf_count_max_phased_kernel";
     std::snprintf(out->kernel, sizeof out->kernel, "%s", form);
+    out->reserved0 = (uint32_t)a.multi_reads;  // reads per wave of the multi build (0: the one-read build)
     if (!merged_plain && a.split_waves < 2 && a.phase.n_slices) {
         out->phase_shape = (uint32_t)a.phase_shape;
         std::snprintf(out->phase_shape_name, sizeof out->phase_shape_name, "%s", phase_rule((PhaseShape)a.phase_shape, a.lg).name);

@@ -333,13 +333,13 @@ constexpr int kBufRsrcWord3 = 0x00020000;  // raw buffer, DATA_FORMAT = 32 bit (
 __device__ __forceinline__ uint32_t phase_next_slice(uint32_t done, const PhaseCfg &ph)
 {
     for (;;) {
-        const uint32_t wn = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+        const uint32_t wn = (uint32_t)(((uint64_t)((uint32_t)wall_clock64() + ph.tskew) * ph.inv_ticks) >> 32);
         const uint32_t cur = (wn + ph.skew) % ph.n_slices;
         if (!((done >> cur) & 1u)) return cur;
         bool moved = false;
         for (uint32_t guard = 0; guard < 2048; ++guard) {
             __builtin_amdgcn_s_sleep(2);
-            const uint32_t w2 = (uint32_t)(((uint64_t)(uint32_t)wall_clock64() * ph.inv_ticks) >> 32);
+            const uint32_t w2 = (uint32_t)(((uint64_t)((uint32_t)wall_clock64() + ph.tskew) * ph.inv_ticks) >> 32);
             if (w2 != wn) { moved = true; break; }
         }
         if (!moved) return (uint32_t)__builtin_ctz(~done);  // done has a zero bit below n_slices: the caller loops while it does
@@ -850,6 +850,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
     if (ph.xcd_skew) ph.skew = xcc_id();
+    if (ph.tskew) ph.tskew *= xcc_id();
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const uint32_t read = blockIdx.x * kWavesPerBlock + wave;
@@ -1062,6 +1063,238 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
         out[(size_t)read * out_read_stride + nm.out_offset[0]] = (uint16_t)best;
         for (uint32_t g = 1; g < nm.n; ++g) out[(size_t)read * out_read_stride + nm.out_offset[g]] = 0;  // (merged tables: SHORT builds only)
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SEVERAL READS PER WAVE through one pass of the clock-phased windows (round 6; two-word blocks, reads of up to 256 k-mers: the
+// build ibf_count_max_phased_kernel<1,10,1,4> serves with one read per wave).  Why: a pass of the chip over all slices reloads the
+// table once per XCD, whatever the number of reads that ride along, so the fabric's share of a read's time falls with the reads a CU
+// holds per pass -- and those are bounded by on-chip state: per read 8 slots x 64 lanes x (16 bytes of AND accumulator + three
+// offsets).  The shipped build keeps both in registers (72 VGPRs, seven waves per SIMD: 28 reads per CU).  Here the accumulators of R
+// reads stay in registers and the offsets live in LDS, three block numbers of 21 bits packed into one 64-bit word per (read, slot,
+// lane) -- 4 KiB per read, read back once per window (ds_read_b64, lane-consecutive: conflict-free) and unpacked with four VALU
+// operations; recomputing them per window from the staged bases instead (3 x 64-bit multiply + xor-shift + Barrett per k-mer) would
+// cost more VALU time than a window has.  R = 2 at five waves per SIMD: 40 reads per CU, 160 KiB of LDS -- all of it, which is why
+// a read's bases are staged inside its own last slot's region (the slot is hashed into registers before it is overwritten) and a
+// workgroup is ONE wave (LDS is granted per workgroup: 8 KiB units pack where 32 KiB units would not).
+// Packed block numbers: tables of at most 2^21 - 1 blocks (32 MiB of two-word blocks); 0x1FFFFF = no lookup, out of range of every
+// slice because a slice's descriptor ends with the table.  Same windows, same slices, same counting as the one-read build; results
+// are identical by construction (the same AND of the same words).
+constexpr uint32_t kPackBits = 21;
+constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
+#ifndef RB_MULTI_WAVES
+#define RB_MULTI_WAVES 5
+#endif
+
+// three packed block numbers of one k-mer (kPackBits each)
+__device__ __forceinline__ uint64_t pack_lookups(uint64_t v, const IbfDev &f)
+{
+    const uint64_t b0 = rbspec::block_index(v, f.precalc[0], f.n_blocks, f.magic, f.pow2_mask);
+    const uint64_t b1 = rbspec::block_index(v, f.precalc[1], f.n_blocks, f.magic, f.pow2_mask);
+    const uint64_t b2 = rbspec::block_index(v, f.precalc[2], f.n_blocks, f.magic, f.pow2_mask);
+    return b0 | (b1 << kPackBits) | (b2 << (2 * kPackBits));
+}
+
+// Phase A of the multi-read build for ONE read: its k-mers' packed block numbers go to slots[j * 64 + lane], j = 0..3 the forward
+// k-mers at p = 64 j + lane, j = 4..7 the k-mers of the reverse complement over the same windows (~0: no such k-mer).  Returns the
+// number of k-mers (0: no such read, a read shorter than k, or one longer than the build was promised -- it counts 0 like the
+// one-read build).  The read's bases are staged INSIDE the regions of its own slots 6 and 7 (1 KiB; the wave has no other LDS), so
+// those two slots are hashed into registers and stored after every lane is through with the staged bases.
+// k <= 13 (the reference's default; 5^13 < 2^31): the k-mer values are 32-bit and come from staged TRIPLES of bases -- f3[i] =
+// 25 b[i] + 5 b[i+1] + b[i+2], r3[i] the same of the complemented bases in reverse order -- so a value is four v_mad_u32_u24 by 125
+// and one step by 5 instead of thirteen 64-bit multiply-adds per strand (~20 instead of ~180 VALU instructions per window position
+// and both strands).  The count kernels of the narrow filters are three quarters VALU-busy (profiles/r05/pmc_summary.csv, targets3:
+// SQ_INSTS_VALU 4 207 per read, x 4 cycles over 1024 SIMDs = 7.3 of the kernel's 9.5 ms).  Longer k: 64-bit Horner over the bases.
+__device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDev &f, const ReadSrc &src, uint32_t rid, uint32_t n_reads, int lane)
+{
+    constexpr int T = 4;
+    const uint32_t k = f.k;
+    uint32_t len = 0, n = 0;
+    uint8_t *ord = reinterpret_cast<uint8_t *>(slots + 6 * 64);  // 1 KiB: ord[0..272), f3 at +272, r3 at +544
+    uint8_t *f3 = ord + 272, *r3 = ord + 544;
+    if (rid < n_reads) {
+        const BaseSrc seq = make_base_src(src, rid, &len);
+        n = len >= k ? len - k + 1 : 0;
+        if (n > 256u) n = 0;
+        if (n)
+            for (uint32_t i = lane; i < len; i += 64) ord[i] = (uint8_t)seq.ord(i);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const bool small_k = k <= 13u;
+    if (small_k && n) {
+        for (uint32_t i = lane; i + 2 < len; i += 64) {
+            const uint32_t a = ord[i], b = ord[i + 1], c = ord[i + 2];
+            f3[i] = (uint8_t)(a * 25u + b * 5u + c);
+            r3[i] = (uint8_t)(rbspec::dna5_comp(c, f.comp_n) * 25u + rbspec::dna5_comp(b, f.comp_n) * 5u + rbspec::dna5_comp(a, f.comp_n));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t q3 = k / 3u, s1 = k - 3u * q3;  // k = 3 q3 + s1
+    uint64_t held_r[2] = {~0ULL, ~0ULL};  // tiles 2 and 3: their reverse slots 6 and 7 hold the staged bases
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        const uint32_t p = (uint32_t)(j * 64 + lane);
+        uint64_t pf = ~0ULL, pr = ~0ULL;
+        if (p < n) {
+            uint64_t vf, vr;
+            if (small_k) {
+                // forward: q3 triples from the left, then s1 single bases; reverse complement: the s1 bases from the right end
+                // first, then the triples from the right (every x 125 step starts below 5^10 < 2^24: the 24-bit multiply is exact)
+                uint32_t a = 0, b = 0;
+                for (uint32_t t = 0; t < q3; ++t) a = __umul24(a, 125u) + f3[p + 3u * t];
+                for (uint32_t t = 0; t < s1; ++t) a = a * 5u + ord[p + 3u * q3 + t];
+                for (uint32_t t = 0; t < s1; ++t) b = b * 5u + rbspec::dna5_comp(ord[p + k - 1u - t], f.comp_n);
+                for (uint32_t t = q3; t-- > 0;) b = __umul24(b, 125u) + r3[p + 3u * t];
+                vf = a;
+                vr = b;
+            } else {
+                const uint8_t *bs = ord + p;
+                vf = 0;
+                vr = 0;
+                for (uint32_t i = 0; i < k; ++i) vf = vf * 5u + bs[i];
+                for (uint32_t i = 0; i < k; ++i) vr = vr * 5u + rbspec::dna5_comp(bs[k - 1 - i], f.comp_n);
+            }
+            pf = pack_lookups(vf, f);
+            pr = pack_lookups(vr, f);
+        }
+        slots[j * 64 + lane] = pf;
+        if (j < 2) slots[(j + T) * 64 + lane] = pr;
+        else held_r[j - 2] = pr;
+        __builtin_amdgcn_sched_barrier(0);  // one window position's hash chains at a time (registers)
+    }
+    // every lane has hashed its k-mers by now: slots 6 and 7 take over the staging area
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    slots[6 * 64 + lane] = held_r[0];
+    slots[7 * 64 + lane] = held_r[1];
+    return n;
+}
+
+template <int R, bool INV, int AUX = 0>  // AUX: cache policy bits of the gathers (0 default; 1 sc0, 2 nt, 16 sc1 -- measurements)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : (R == 2 ? RB_MULTI_WAVES : 4), 8))) void ibf_count_max_phased_multi_kernel(
+    IbfDev f, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out, uint32_t out_read_stride, NarrowMerge nm)
+{
+    constexpr int T = 4, S = 2 * T;  // 64-k-mer tiles per strand; slots per lane (forward tiles, then reverse-complement tiles)
+    __shared__ uint64_t s_off[R][S][64];
+    if (ph.xcd_skew) ph.skew = xcc_id();
+    if (ph.tskew) ph.tskew *= xcc_id();
+    const int lane = threadIdx.x;
+    const uint32_t read0 = blockIdx.x * (uint32_t)R;
+    uint32_t nk[R];  // k-mers of each read (0: no such read, or a read longer than promised -- it writes 0 like the one-read build)
+
+    // ---- phase A: hash every k-mer of every read once; the block numbers go to LDS
+#pragma unroll
+    for (int r = 0; r < R; ++r) nk[r] = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const uint32_t n = multi_hash_read(&s_off[r][0][0], f, src, read0 + (uint32_t)r, n_reads, lane);
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (q == r) nk[q] = n;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase B: the windows.  x0 / x1: the two word columns of every slot, combined over the three lookups.
+    // !INV: x = AND of the table words (a lane that loaded nothing got 0 from the bounds check and ORs in its all-ones mask first).
+    // INV: the table holds the COMPLEMENT of the filter's bits (the engine's merged copy has such a twin, rb_engine.hip), x = OR of
+    // the loaded words -- the bounds check's 0 is then neutral by itself: no compare, no mask, four ORs per lookup instead of a
+    // compare, a select, four ORs and four ANDs, and the relative offsets need not outlive the loads (six registers).  A bin is hit
+    // where x stays 0; slots without a k-mer start all-ones, bits beyond a column's bins as well.
+    const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
+    uint64_t x0[R][S], x1[R][S];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            const bool ok = (uint32_t)((j % T) * 64 + lane) < nk[r];
+            x0[r][j] = INV ? (ok ? ~valid0 : ~0ULL) : (ok ? valid0 : 0ULL);
+            x1[r][j] = INV ? (ok ? ~valid1 : ~0ULL) : (ok ? valid1 : 0ULL);
+        }
+    }
+    const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 16u)) : min(31u, ph.shift + 4u);
+    const uint32_t table_bytes = f.n_blocks * 16u;  // (<= 2^25: the launcher checked)
+    const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
+    uint32_t done = 0;
+    // reads whose gathers of a slot go out together: all of them where the registers allow (INV: no offsets kept), else one by one
+    constexpr int RB = (INV && R <= 2) ? R : 1;
+#pragma unroll 1
+    while (done != all) {
+        const uint32_t cur = phase_next_slice(done, ph);
+        done |= 1u << cur;
+        asm volatile("" ::: "memory");  // the packed offsets are read again in every window, never carried in registers
+        const bool any_len = (slice_shift >> 31) != 0 && slice_shift != 0x80000000u;
+        const uint32_t span0 = any_len ? (slice_shift & 0x7FFFFFFFu) : 1u << min(slice_shift, 31u);
+        const uint32_t start = any_len ? cur * span0 : cur << min(slice_shift, 31u);
+        // a slice ends with the table: "no lookup" lies beyond it (made scalar by hand: left to itself the compiler takes the clamp to
+        // the vector unit and then wraps every gather in a readfirstlane loop over a descriptor it no longer knows to be uniform)
+        const uint32_t span = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(span0, table_bytes - min(start, table_bytes)));
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(reinterpret_cast<const char *>(f.words)) + start, 0, (int)span, kBufRsrcWord3);
+        const uint32_t nstart = 0u - start;
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+#pragma unroll
+            for (int r0 = 0; r0 < R; r0 += RB) {
+                rb_u32x4 d[RB][3];
+                uint32_t rel[RB][3];
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+                    const uint64_t pk = s_off[r0 + rr][u][lane];
+                    const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
+                    // (field extract + shift-and-add of the negated slice start: seven VALU operations per k-mer)
+                    rel[rr][0] = ((lo & kPackMask) << 4) + nstart;
+                    rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << 4) + nstart;
+                    rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << 4) + nstart;
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) d[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel[rr][h], 0, AUX);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < RB; ++rr) {
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) {
+                        if constexpr (INV) {
+                            x0[r0 + rr][u] |= (((uint64_t)d[rr][h].y) << 32) | d[rr][h].x;
+                            x1[r0 + rr][u] |= (((uint64_t)d[rr][h].w) << 32) | d[rr][h].z;
+                        } else {
+                            const uint32_t o = rel[rr][h] >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
+                            x0[r0 + rr][u] &= (((uint64_t)(d[rr][h].y | o)) << 32) | (d[rr][h].x | o);
+                            x1[r0 + rr][u] &= (((uint64_t)(d[rr][h].w | o)) << 32) | (d[rr][h].z | o);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- per-bin sums across the wave, maxima per member
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t rid = read0 + (uint32_t)r;
+        if (rid >= n_reads) break;  // wave-uniform
+        if constexpr (INV) {
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                x0[r][j] = ~x0[r][j];
+                x1[r][j] = ~x1[r][j];
+            }
+        }
+        const uint32_t cf = wave_bin_counts<T>(x0[r], lane) | (wave_bin_counts<T>(x1[r], lane) << 16);
+        const uint32_t cr = wave_bin_counts<T>(x0[r] + T, lane) | (wave_bin_counts<T>(x1[r] + T, lane) << 16);
+        const uint32_t colmax[2] = {max(cf & 0xFFFFu, cr & 0xFFFFu), max(cf >> 16, cr >> 16)};
+        write_member_maxima<2>(colmax, nm, lane, out + (size_t)rid * out_read_stride);
+    }
+}
+
+// the inverted twin of a merged copy (ibf_count_max_phased_multi_kernel<R, true>): dst = ~src, word by word
+__global__ void invert_words_kernel(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint64_t n_words)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) dst[i] = ~src[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1754,6 +1987,37 @@ template <int LG, int NP>
 static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
 {
     dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+    // two-word blocks, reads of up to 256 k-mers, tables whose block numbers fit 21 bits: several reads per wave, offsets in LDS
+    if constexpr (LG == 1 && NP == 10) {
+        if (a.multi_reads && a.short_only == 1 && a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2) {
+            if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
+            const uint32_t R = (uint32_t)a.multi_reads;
+            dim3 g2((a.n_reads + R - 1) / R);
+#define RB_LAUNCH_MULTI(RR, INV)                                                                                                        \
+    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<RR, INV>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
+                       a.out_read_stride, a.narrow)
+            if (R == 1 && a.multi_inv && a.multi_aux) {  // (cache-policy experiments, R = 1 OR form only)
+#define RB_LAUNCH_AUX(AUX) hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, true, AUX>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow)
+                switch (a.multi_aux) {
+                case 1: RB_LAUNCH_AUX(1); break;
+                case 2: RB_LAUNCH_AUX(2); break;
+                case 3: RB_LAUNCH_AUX(3); break;
+                case 17: RB_LAUNCH_AUX(17); break;
+                default: return hipErrorInvalidValue;
+                }
+#undef RB_LAUNCH_AUX
+            } else if (R == 1 && a.multi_inv) RB_LAUNCH_MULTI(1, true);
+            else if (R == 1) RB_LAUNCH_MULTI(1, false);
+            else if (R == 2 && a.multi_inv) RB_LAUNCH_MULTI(2, true);
+            else if (R == 2) RB_LAUNCH_MULTI(2, false);
+            else if (R == 3 && a.multi_inv) RB_LAUNCH_MULTI(3, true);
+            else if (R == 3) RB_LAUNCH_MULTI(3, false);
+#undef RB_LAUNCH_MULTI
+            else
+                return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
     // both-strands-only build when every read of the batch fits it (LG 0/1, whole blocks owned by this rank)
     if constexpr (LG <= 1 && NP == 10) {
         if (a.short_only == 1 && (LG == 0 || (a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2))) {
@@ -1873,6 +2137,15 @@ hipError_t launch_merge_bits(const uint64_t *src, uint32_t s_src, uint32_t width
     uint64_t blocks = (n_blocks * width + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(merge_bits_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, s_src, width, n_bins, dst, s_dst, dst_bit, n_blocks);
+    return hipGetLastError();
+}
+
+hipError_t launch_invert_words(const uint64_t *src, uint64_t *dst, uint64_t n_words, hipStream_t st)
+{
+    if (n_words == 0) return hipSuccess;
+    uint64_t blocks = (n_words + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(invert_words_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, src, dst, n_words);
     return hipGetLastError();
 }
 

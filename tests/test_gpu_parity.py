@@ -1518,12 +1518,19 @@ def test_large_tables_are_placed_by_trial():
     buf, offs, lens = H.pack_reads(reads)
     eng = capi.Engine(0, [d], [])
     assert np.array_equal(eng.classify(buf, offs, lens)[0][:, 0], po.batch_raw_max(o, buf, offs, lens, 8))
+    cost = d.placement_cost()
+    assert cost["skipped"] == 0 and cost["trial_s"] > 0.0 and cost["peak_bytes"] == tries * (8192 // 8 * n_blocks + 64), cost
+    # a device that is already classifying is not stalled by probe launches and transient copies: with an engine alive the clone takes
+    # the first allocation, and says why (rb_dibf_placement_cost)
     clone, _, _ = d.clone_to_ex(0)
-    assert clone.placement()[0] >= 1
+    assert clone.placement()[0] == 0 and clone.placement_cost()["skipped"] == 1
     cmp_ = d.compare(clone)
     assert cmp_["new_bits"] == 0 and cmp_["file_bits"] == cmp_["rebuilt_bits"]
     clone.free()
     eng.destroy()
+    clone, _, _ = d.clone_to_ex(0)  # no engine on the device any more: placed by trial again
+    assert clone.placement()[0] >= 2 and clone.placement_cost()["skipped"] == 0
+    clone.free()
     capi.set_placement_tries(1)
     try:
         off = capi.DeviceIBF.create(0, 8192, 3, 13, 8192 * n_blocks)
@@ -1737,3 +1744,112 @@ def test_pool_replicas_of_a_large_filter_started_side_by_side():
     env = dict(os.environ, RB_POOL_TEST_THREAD_PER_WORKER="1", RB_AMD_LIBRARY=testing_lib)
     r = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0 and "side by side ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("widths,n_blocks", [((100,), 2053), ((128,), 4096), ((65,), 30011), ((60, 50), 30011), ((43, 29, 49), 30011), ((64, 64), 8192)])
+def test_several_reads_per_wave_match_oracle(widths, n_blocks):
+    """Round 6: the build of the phased kernel that carries two (or three) reads per wave through a pass of the windows, block numbers
+    packed into LDS (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- two-word blocks, reads of up to 256 k-mers.
+    Raw maxima against the oracle and decisions against the one-read build: a filter on its own (Barrett and mask modulus) and merged
+    pairs / triples of small targets, odd batch sizes (the last wave has a read too few), empty / short / all-N reads, windows from
+    far too short to far too long, the table cut into 1 to 32 slices (the last one ending with the table)."""
+    rng = np.random.default_rng(sum(widths) + n_blocks)
+    ref = H.random_dna(rng, 40000)
+    filters = []
+    for i, bins in enumerate(widths):
+        W = (bins + 63) // 64
+        d = capi.DeviceIBF.create(0, bins, 3, 13, W * 64 * n_blocks + int(rng.integers(0, 64 * W)))
+        assert d.info["n_blocks"] == n_blocks
+        d.fill_synth(300 + i)
+        lo = (i * 7000) % 30000
+        d.add_sequence(ref[lo:lo + 8000], 8000 // min(bins, 40) + 1)
+        filters.append(d)
+    views, keep = [], []
+    for d in filters:
+        h = d.download()
+        keep.append(h)
+        views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
+    reads = make_reads(rng, ref, 2299, lo=5, hi=268, err=0.1, n_frac=0.2) + ["", "ACGT", "N" * 268, ref[100:368], "A" * 13, "A" * 12]
+    assert len(reads) % 2 == 1 and len(reads) % 3 != 0
+    buf, offs, lens = H.pack_reads(reads)
+    nd = 1 if len(widths) == 1 else 0
+    eng = capi.Engine(0, filters[:nd], filters[nd:])
+    eng.set_merge(2)
+    exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+    assert exp.max() > 100
+    base = None
+    for reads_per_wave in (0, 1, 2, 3, 16 + 1, 16 + 2):  # (+ 16: merged tables keep the AND form instead of the complemented twin's OR form)
+        eng.set_reads_per_wave(reads_per_wave)
+        for base_ticks, max_slices in ((1, 8), (300, 32), (2000, 3), (150, 1)):
+            eng.set_phased(0, 1 << 40, base_ticks, 0, 1)
+            eng.set_phase_slices(1, max_slices)
+            pl = eng.plan(0, len(lens), int(lens.max()))
+            assert pl["kernel"] == ("ibf_count_max_phased_multi_kernel" if reads_per_wave else "ibf_count_max_phased_kernel"), pl
+            assert pl["block_words"] == 2 and pl["reserved0"] == (reads_per_wave & 3)
+            got = eng.classify(buf, offs, lens)
+            assert np.array_equal(got[0], exp), (reads_per_wave, base_ticks, max_slices)
+            if base is None:
+                base = got
+            assert all(np.array_equal(a, b) for a, b in zip(got, base)), (reads_per_wave, base_ticks, max_slices)
+        # sub-batches: every remainder of the batch size modulo the reads per wave
+        for n_sub in (2049, 2050, 2051):
+            got = eng.classify(buf, offs[:n_sub], lens[:n_sub])
+            assert np.array_equal(got[0], exp[:n_sub]), (reads_per_wave, n_sub)
+    eng.set_phased()
+    eng.set_phase_slices()
+    # reads longer than the build takes: the engine plans the one-read builds for the batch
+    eng.set_reads_per_wave(2)
+    assert eng.plan(0, 4096, 300)["kernel"] != "ibf_count_max_phased_multi_kernel"
+
+
+def test_device_thresholds_match_the_reference_compiled_table():
+    """SURVEY a.5 / a.6 on the device: the threshold table K2 reads is checked against tests/golden/thresholds_reference.json -- values the
+    REFERENCE'S OWN calculateCI (src/IBF/IBF.hpp:268-338) computed when compiled under its own -Ofast, with the threshold expression of
+    src/IBF/IBFClassify.cpp:154-159 (tests/golden/make_thresholds_reference.py) -- not against the oracle.  The table is observed through
+    decisions: for a read of length L a prefix is inserted into one bin so that exactly m of its k-mers hit, once with m = t(L) and once
+    with m = t(L) - 1; a deplete-only check_unblock says "unblock" for the first and "keep" for the second iff the device's threshold for
+    L is the reference's t(L) (Read::classify, IBFClassify.cpp:262-273: a match needs count >= threshold and count > 0).  Both error rates
+    of adaptive_sampling.hpp:55 (r and r - 0.02), micro-batch and throughput forms, lengths from below the int16 wrap (negative
+    thresholds arrive as 65 5xx: never a match) up to 4 000."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_thresholds_reference as ref
+    fx, full = ref.load_fixture()
+    k = 13
+    rng = np.random.default_rng(2026)
+    for rate in (0.1, 0.1 - 0.02):
+        d = capi.DeviceIBF.create(0, 64, 3, k, 64 << 20)  # sparse: the planted k-mers are the only hits
+        eng = capi.Engine(0, [d], [])
+        table = full[ref.key(k, rate)]  # index L - k
+        lengths = sorted(set(list(range(20, 140, 3)) + list(range(140, 700, 7)) + list(range(700, 4000, 97)) + [35, 131, 250, 360, 1500]))
+        reads, want_m, want_dec, ins_start, ins_end, ins_bin = [], [], [], [], [], []
+        at = 0
+        for L in lengths:
+            t = int(table[L - k])
+            n_kmers = L - k + 1
+            for m in (t, t - 1):
+                if t >= 32768:        # a negative int16 threshold: received as uint16 it is beyond any count -- all k-mers hit, no match
+                    m = n_kmers
+                if m < 0 or m > n_kmers:
+                    continue
+                r = H.random_dna(rng, L)
+                reads.append(r)
+                want_m.append(m)
+                want_dec.append(1 if (m >= t and m > 0) else 0)
+                if m > 0:
+                    ins_start.append(at)
+                    ins_end.append(at + m + k - 1)
+                    ins_bin.append(len(reads) % 64)
+                at += L
+        d.insert("".join(reads), np.array(ins_start, dtype=np.uint64), np.array(ins_end, dtype=np.uint64), np.array(ins_bin, dtype=np.uint64))
+        buf, offs, lens = H.pack_reads(reads)
+        want_m, want_dec = np.array(want_m), np.array(want_dec, dtype=np.uint8)
+        assert want_dec.sum() > 100 and (want_dec == 0).sum() > 100
+        for split in (2048, 0):  # latency form (sub-batches of up to 512 reads: the count kernel decides itself) and throughput form + K2
+            eng.set_split_threshold(split)
+            for lo in range(0, len(reads), 500 if split else len(reads)):
+                hi = min(len(reads), lo + (500 if split else len(reads)))
+                mc, _, dec, st = eng.classify(buf, offs[lo:hi], lens[lo:hi], error_rate=rate)
+                assert np.array_equal(mc[:, 0], want_m[lo:hi]), "the planted counts are not what the test built"
+                bad = np.nonzero(dec != want_dec[lo:hi])[0]
+                assert len(bad) == 0, [(int(lens[lo + i]), int(mc[i, 0]), int(table[int(lens[lo + i]) - k])) for i in bad[:5]]
+        eng.destroy()
