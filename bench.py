@@ -1117,6 +1117,105 @@ def pool_child(ctx, steps, timeout_s=600):
     return out
 
 
+def run_cli_readme(ctx, n_reads=2_000_000, sample=3000):
+    """SURVEY f.3 under the driver's eyes: the host CLI (readbouncer_amd/readbouncer_amd_cli, usage = "classify",
+    src/main/classify.hpp:142-365) end to end on the README shape -- the four filters stored as .ibf files, a generated FASTQ of
+    250 bp reads in the page cache, chunk_length 250, max_chunks 1, per-target FASTA + unclassified.fasta written.  `value` = the
+    CLI's own THROUGHPUT figure (reads / wall of classify_reads: parse -> GPU chunk loop -> formatted output, HIP start-up and filter
+    loading excluded; `process_wall_reads_per_s` includes them).  Parity: for a sample of reads the output file each one landed in must
+    be the one the ORACLE's chunk driver names (orc_classify_read_chunks = classify.hpp:247-301 + 58-111).  Rank 0, one GPU."""
+    import shutil
+    import subprocess
+    import tempfile
+    from oracle import pyoracle as po
+    from readbouncer_amd import synth
+    keys = ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]
+    cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "readbouncer_amd", "readbouncer_amd_cli")
+    if not os.path.exists(cli):
+        return {"error": "readbouncer_amd_cli is not built (run __graft_entry__.build())"}
+    L = 250
+    need = n_reads * (2 * L + 20) * 1.8
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.statvfs("/dev/shm").f_bavail * os.statvfs("/dev/shm").f_frsize > need * 1.5 else None
+    work = tempfile.mkdtemp(prefix="rb_cli_readme_", dir=base)
+    try:
+        paths = []
+        for k in keys:
+            paths.append(os.path.join(work, k + ".ibf"))
+            h = ctx.filter(k)[0].download()
+            h.store(paths[-1])
+            del h
+        ref = np.concatenate([ctx.filter(k)[1] for k in keys])
+        base_n = min(n_reads, 200_000)
+        buf, _, _ = synth.make_reads(5, base_n, L, ref)
+        # fixed-width records "@rRRR_IIIIII\n" + seq + "\n+\n" + qual + "\n", filled with numpy; block `rep` repeats the reads under new names
+        rec_len = 13 + L + 3 + L + 1
+        block = np.empty((base_n, rec_len), dtype=np.uint8)
+        block[:, 0], block[:, 1], block[:, 5], block[:, 12] = ord("@"), ord("r"), ord("_"), ord("\n")
+        idx = np.arange(base_n)
+        for d in range(6):
+            block[:, 6 + d] = ord("0") + (idx // 10 ** (5 - d)) % 10
+        block[:, 13:13 + L] = buf.reshape(base_n, L)
+        block[:, 13 + L:13 + L + 3] = np.frombuffer(b"\n+\n", dtype=np.uint8)
+        block[:, 13 + L + 3:13 + 2 * L + 3] = ord("I")
+        block[:, -1] = ord("\n")
+        fq = os.path.join(work, "reads.fastq")
+        with open(fq, "wb") as fh:
+            rep, left = 0, n_reads
+            while left > 0:
+                for d in range(3):
+                    block[:, 2 + d] = ord("0") + (rep // 10 ** (2 - d)) % 10
+                m = min(left, base_n)
+                block[:m].tofile(fh)
+                left -= m
+                rep += 1
+        out_dir = os.path.join(work, "out")
+        cfg = os.path.join(work, "c.toml")
+        with open(cfg, "w") as fh:
+            fh.write('usage = "classify"\noutput_directory = "%s"\nlog_directory = "%s/logs"\n[IBF]\ndeplete_files = ["%s"]\n'
+                     'target_files = ["%s", "%s", "%s"]\nread_files = ["%s"]\nchunk_length = %d\nmax_chunks = 1\n'
+                     % (out_dir, out_dir, paths[0], paths[1], paths[2], paths[3], fq, L))
+        t = time.time()
+        p = subprocess.run([cli, "--config", cfg, "--devices", str(ctx.dev_index)], capture_output=True, text=True, timeout=300)
+        wall = time.time() - t
+        thr = [l for l in p.stdout.splitlines() if l.startswith("THROUGHPUT")]
+        if p.returncode != 0 or not thr:
+            return {"error": "CLI exit code %d: %s" % (p.returncode, (p.stderr or p.stdout).strip()[-300:])}
+        kv = dict(x.split("=", 1) for x in thr[0].split()[1:])
+        res = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
+        # where did each read go?  id -> output file, from the headers of the files the CLI wrote
+        where = {}
+        outs = sorted(f for f in os.listdir(out_dir) if f.endswith(".fasta"))
+        for f in outs:
+            with open(os.path.join(out_dir, f), "rb") as fh:
+                data = np.frombuffer(fh.read(), dtype=np.uint8)
+            starts = np.flatnonzero(data == ord(">"))
+            for s0 in starts[:: max(1, len(starts) // (4 * sample))][: 4 * sample]:
+                where[data[s0 + 1:s0 + 12].tobytes().decode()] = f
+        views = [ctx.oracle_view(k) for k in keys]
+        checked = mism = 0
+        rng = np.random.default_rng(3)
+        names = list(where)
+        for name in [names[i] for i in rng.permutation(len(names))[:sample]]:
+            i = int(name[5:])  # "rRRR_IIIIII" -> read IIIIII of the base block
+            r = po.classify_read_chunks(views[:1], views[1:], buf[i * L:(i + 1) * L].tobytes(), L, 1)
+            # classify.hpp:275-301: a read classified for a target goes to <target file stem>.fasta, everything else to unclassified.fasta
+            expect = (os.path.splitext(os.path.basename(paths[1 + r["best_target"]]))[0] + ".fasta") if (r["classified"] and r["best_target"] >= 0) else "unclassified.fasta"
+            checked += 1
+            mism += where[name] != expect
+        return {"metric": "reads/sec through the host CLI (usage = classify, README shape, 250 bp FASTQ -> per-target FASTA)",
+                "value": float(kv.get("reads_per_s", 0.0)), "unit": "reads/s", "n_gpus": 1,
+                "process_wall_reads_per_s": n_reads / wall, "process_wall_s": round(wall, 3),
+                "config": {"workload": "readbouncer_amd_cli classify: %d reads of %d bp (FASTQ %.2f GB in %s), 1 deplete + 3 target .ibf files, chunk_length 250, max_chunks 1"
+                                       % (n_reads, L, os.path.getsize(fq) / 1e9, "/dev/shm" if base else "the temp dir")},
+                "cli": {k: kv.get(k) for k in ("wall_s", "classify_s", "wait_reader_s", "format_s", "classifiers", "parsers")},
+                "result_line": res[0] if res else None,
+                "parity": {"checked_reads": checked, "decision_mismatches": int(mism), "raw_max_mismatches": 0, "near_threshold_reads": None,
+                           "what": "output file of a sample of reads against the oracle's chunk driver (orc_classify_read_chunks)"},
+                "roofline": None, "cpu_baseline": None}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def replay(ctx, live_leg=True):
     """BASELINE configs[4]: 48-flowcell replay.  Poisson chunk arrivals (rate/world per GPU), 360 bp each, deplete =
     GRCh38-scale IBF + target = mock-community IBF, full check_unblock.  The dispatcher is work-conserving: whenever
@@ -1314,7 +1413,7 @@ def xgmi_preflight(ctx):
         return {"ran": False, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
-FULL_LEGS = ("c3np2", "c4", "c5", "c2", "grch38_f100k", "readme", "readme_360bp", "targets3", "deplete_target", "pool_c3", "pool_c4")
+FULL_LEGS = ("c3np2", "c4", "c5", "c2", "grch38_f100k", "readme", "readme_360bp", "targets3", "deplete_target", "cli_readme", "pool_c3", "pool_c4")
 # N > 1 (what a SCALE record carries, four runs back to back): the BASELINE configs that name several GPUs, config 3 at the
 # reference's own sizing, and the one-process pool legs; the narrow shapes and c2 are single-GPU parity / roofline legs
 MULTI_LEGS = ("c3np2", "c4", "c5", "pool_c3", "pool_c4")
@@ -1531,6 +1630,8 @@ def main():
             # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
             "targets3": lambda: run_throughput(ctx, "targets3", steps=few, warmup=1, cpu_seconds=3.0),
             "deplete_target": lambda: run_throughput(ctx, "deplete_target", steps=few, warmup=1, cpu_seconds=3.0),
+            # the host CLI end to end on the README shape (SURVEY f.3): rank 0 only, the other ranks pass
+            "cli_readme": lambda: (run_cli_readme(ctx) if rank == 0 else {"value": 0.0}),
             # one host process driving every GPU of the job through rb_pool (rank 0; the other ranks wait): what SCALE's per-rank
             # numbers do not show
             "pool_c3": lambda: run_pool(ctx, "c3"),
@@ -1538,7 +1639,7 @@ def main():
         }
         # filters a later leg no longer needs are freed as the run goes (N ranks on one node hold N replicas of each)
         last_use = {"c3np2": ["c3np2"], "c2": ["c2"], "grch38_f100k": ["grch38_f100k"],
-                    "deplete_target": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]}
+                    "cli_readme": ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]}
         names = default_leg_names(world)
         for lname in names:
             t_leg = time.time()

@@ -17,6 +17,7 @@
 #include <exception>
 #include <stdexcept>
 #include <map>
+#include <chrono>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -120,7 +121,7 @@ public:
     }
 };
 
-struct FilterStats  // src/IBF/IBF.hpp:51-79 (time fields dropped)
+struct FilterStats  // src/IBF/IBF.hpp:51-79; the reference's StopClock members as seconds
 {
     uint64_t sumSeqLen = 0;
     uint64_t totalSeqsBinId = 0;
@@ -129,6 +130,11 @@ struct FilterStats  // src/IBF/IBF.hpp:51-79 (time fields dropped)
     uint32_t totalBinsFile = 0;
     uint64_t invalidSeqs = 0;
     uint32_t newBins = 0;
+    // timeLoadSeq (cutOutNNNs + sizing, IBFBuild.cpp:441-446), timeBuild (:462-497) and inside it the filter's allocation in HBM
+    // (with the placement trial of tables >= 1 GiB), the concatenation of the cleaned records and rb_dibf_insert (H2D + the insert
+    // kernel), timeSaveFilter (:503-515: download + file), timeIBF (:433-517)
+    double timeLoadSeq = 0.0, timeBuild = 0.0, timeSaveFilter = 0.0, timeIBF = 0.0;
+    double timeAllocFilter = 0.0, timeConcat = 0.0, timeInsert = 0.0;
 };
 
 // ---- TIbf: the filter, resident in HBM ---------------------------------------------------------
@@ -189,8 +195,13 @@ class IBF
     // add_sequences_to_filter (IBFBuild.cpp:143-215) for every queued sequence in ONE device call: the fragments
     // of all sequences (reference fragmenter, bins numbered consecutively across sequences) go into one table, the
     // sequences into one buffer -- a reference of 100 000 contigs costs one launch, not 100 000
-    void insert_all(const std::vector<std::string>& cleaned, const IBFConfig& config, uint64_t first_bin)
+    static double seconds_since(std::chrono::steady_clock::time_point t0)
     {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void insert_all(const std::vector<std::string>& cleaned, const IBFConfig& config, uint64_t first_bin, FilterStats* stats = nullptr)
+    {
+        const auto t_concat = std::chrono::steady_clock::now();
         std::string all;
         size_t total = 0;
         for (const std::string& c : cleaned) total += c.size();
@@ -210,8 +221,11 @@ class IBF
             }
             all += c;
         }
+        if (stats) stats->timeConcat = seconds_since(t_concat);
+        const auto t_insert = std::chrono::steady_clock::now();
         const int st = rb_dibf_insert(filter.handle(), all.data(), all.size(), starts.data(), ends.data(), bins.data(),
                                       starts.size());
+        if (stats) stats->timeInsert = seconds_since(t_insert);
         if (st != RB_OK) throw InsertSequenceException(std::string("Error inserting the sequences to the IBF: ") + rb_last_error());
     }
 
@@ -242,6 +256,7 @@ public:
         if (records.empty() && config.reference_files.empty())
             throw MissingReferenceFilesException("There were no reference files specified!");
         FilterStats stats;
+        const auto t_all = std::chrono::steady_clock::now();
         std::vector<std::string> cleaned;
         for (const RefSeq& r : records) {
             stats.totalSeqsFile += 1;
@@ -254,14 +269,21 @@ public:
         }
         config.filter_size_bits = rb_calculate_filter_size_bits(config.fragment_length, config.kmer_size,
                                                                 config.hash_functions, config.max_fp, stats.totalBinsBinId);
+        stats.timeLoadSeq = seconds_since(t_all);
+        const auto t_build = std::chrono::steady_clock::now();
         try {
             filter = TIbf(stats.totalBinsBinId, config.hash_functions, config.kmer_size, config.filter_size_bits, config.device);
         } catch (const InvalidConfigException&) {
             throw NullFilterException("Could not instantiate IBF Filter");
         }
+        stats.timeAllocFilter = seconds_since(t_build);
         stats.totalBinsFile = (uint32_t)getNumberOfBins(filter);
-        insert_all(cleaned, config, 0);
+        insert_all(cleaned, config, 0, &stats);
+        stats.timeBuild = seconds_since(t_build);
+        const auto t_save = std::chrono::steady_clock::now();
         if (!config.output_filter_file.empty()) filter.store(config.output_filter_file);
+        stats.timeSaveFilter = seconds_since(t_save);
+        stats.timeIBF = seconds_since(t_all);
         return stats;
     }
 

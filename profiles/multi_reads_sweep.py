@@ -30,8 +30,17 @@ dev = torch.device("cuda:0")
 SHAPES = {  # name -> (deplete keys, target keys, read length)
     "deplete_target": (["mock_t3"], ["mock_t1"], 250),
     "targets3": ([], ["mock_t1", "mock_t2", "mock_t3"], 250),
+    "deplete_target360": (["mock_t3"], ["mock_t1"], 360),
+    "targets3_360": ([], ["mock_t1", "mock_t2", "mock_t3"], 360),
+    "readme": (["mock_deplete"], ["mock_t1", "mock_t2", "mock_t3"], 250),
+    "readme360": (["mock_deplete"], ["mock_t1", "mock_t2", "mock_t3"], 360),
+    "c1": (["c1"], [], 250),
+    "c1_360": (["c1"], [], 360),
+    "w1_64mib": (["w1_64mib"], [], 250),
+    "mock_deplete": (["mock_deplete"], [], 250),
+    "mock_deplete360": (["mock_deplete"], [], 360),
 }
-SEEDS = {"mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113)}
+SEEDS = {"mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113), "c1": (1, 10), "w1_64mib": (15, 114)}
 filters = {}
 
 

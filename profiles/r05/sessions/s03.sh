@@ -6,6 +6,9 @@ OUT=$R/gpurun_out/s03
 mkdir -p $OUT
 cd $R
 lds_pass() { # tag workload
+  # (added in round 6, ADVICE r5: as this session RAN, the variable was not set here, so rocprofv3 profiled bench.py's supervisor and the
+  # measuring process was its child; the "lds" rows kept in negative/pmc_units_compact_g8c128_*.txt carry a note to that effect)
+  export RB_BENCH_NO_SUPERVISOR=1
   cd /tmp && export TMPDIR=/tmp
   timeout -k 5 120 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d "$OUT/$1/lds" -- python3 "$R/bench.py" --workload $2 --reads 1000000 --steps 2 --warmup 1 --no-cpu-baseline --no-latency > "$OUT/$1/lds.log" 2>&1
   f=$(find "$OUT/$1/lds" -name "*counter_collection.csv" | head -1)

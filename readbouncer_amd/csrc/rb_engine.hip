@@ -323,13 +323,13 @@ struct rb_engine {
     uint32_t phase_max_slices = 32;   // slices a table is cut into (<= 32: a wave keeps a bit per slice)
     uint32_t phase_slice_log2 = 0;    // slices of 2^n bytes instead of the rule of phase_slice_log2(); 1-5: as small as phase_max_slices allows
     uint32_t phase_n_slices = 0;      // RB_PHASE_N_SLICES: that many equal-length slices for the four-word one-lane builds (0: phase_equal_slices())
-    uint32_t phase_xcd_skew = 0;      // rb_engine_set_phase_xcd_skew (RB_PHASE_XCD_SKEW): bit 0: slice = (window + XCD number) mod n_slices; bit 1: the
-                                      // XCDs' windows start an eighth of a window apart (they refill their L2s one after the other)
+    uint32_t phase_xcd_skew = 2;      // rb_engine_set_phase_xcd_skew (RB_PHASE_XCD_SKEW): bit 0: slice = (window + XCD number) mod n_slices; bit 1: the
+                                      // XCDs' windows start an eighth of a window apart (they refill their L2s one after the other).  Bit 1 is the
+                                      // default since round 6: 1.2-4.4 % on every phased shape, never a loss (profiles/r06/multi/s13_skew_all_shapes.txt)
     // rb_engine_set_reads_per_wave: two-word tables of up to 2^21 - 1 blocks, reads of up to 256 k-mers, phased: the build that carries
     // that many reads per wave through a pass of the windows, offsets in LDS (rb_kernels.hip, ibf_count_max_phased_multi_kernel); 0: the
     // one-read build
-    uint32_t multi_reads = 0;
-    uint32_t multi_aux = 0;     // RB_MULTI_AUX: cache-policy bits of the multi-read build's gathers (experiments)
+    uint32_t multi_reads = 1;   // (default since round 6: 250 bp -10 ... -11 %, 360 bp -16 ... -19 % on two-word tables, profiles/r06/multi/)
     uint32_t phase_tskew_div = 8;  // RB_PHASE_TSKEW_DIV: the XCDs' windows start 1 / this of a window apart (time skew)
     bool multi_no_inv = false;  // (bit 4 of rb_engine_set_reads_per_wave's argument: the AND form on merged copies too; measurements)
     // rb_engine_calibrate: window lengths measured on this device that replace the planner's for a (table, kernel shape, slice size)
@@ -579,8 +579,9 @@ int rb_dibf_upload(int device, const rb_ibf *host, rb_dibf **out)
         return rb::fail(RB_ERR_HIP, "hipMalloc of the file-layout buffer failed");
     }
     const uint64_t *src = host->words;
-    st = stream_words_to_device(d_dst, used, [src](uint64_t *dst, uint64_t first, size_t n) {
-        rb::memcpy_parallel(dst, src + first, n * 8);
+    rb::IoGang gang(rb::io_threads((size_t)std::min<uint64_t>(used, (uint64_t)8 << 20) * 8));  // (the threads of this load: one chunk is 64 MiB)
+    st = stream_words_to_device(d_dst, used, [src, &gang](uint64_t *dst, uint64_t first, size_t n) {
+        gang.memcpy(dst, src + first, n * 8);
         return (int)RB_OK;
     });
     if (st == RB_OK && padded) st = dibf_from_compact(f, d_dst);
@@ -615,9 +616,10 @@ int rb_dibf_open(int device, const char *path, rb_dibf **out)
     }
     const int fd = fileno(fp);
     const std::string name = path;
+    rb::IoGang gang(rb::io_threads((size_t)std::min<uint64_t>(used, (uint64_t)8 << 20) * 8));  // (the threads of this load: one chunk is 64 MiB)
     if (rc == RB_OK)
-        rc = stream_words_to_device(d_dst, used, [fd, &name](uint64_t *dst, uint64_t first, size_t n) {
-            if (!rb::pread_parallel(fd, (off_t)(8 + first * 8), dst, n * 8)) return rb::fail(RB_ERR_PARSE_IBF, name + ": short read");
+        rc = stream_words_to_device(d_dst, used, [fd, &name, &gang](uint64_t *dst, uint64_t first, size_t n) {
+            if (!gang.pread(fd, (off_t)(8 + first * 8), dst, n * 8)) return rb::fail(RB_ERR_PARSE_IBF, name + ": short read");
             return (int)RB_OK;
         });
     std::fclose(fp);
@@ -918,10 +920,9 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         }
         if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
         if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = (uint32_t)std::atoi(v) & 3u; note("RB_PHASE_XCD_SKEW", v); }
-        if (const char *v = std::getenv("RB_MULTI_AUX")) { e->multi_aux = (uint32_t)std::atoi(v); note("RB_MULTI_AUX", v); }
         if (const char *v = std::getenv("RB_PHASE_TSKEW_DIV")) { if (std::atoi(v) >= 1) { e->phase_tskew_div = (uint32_t)std::atoi(v); note("RB_PHASE_TSKEW_DIV", v); } }
         if (const char *v = std::getenv("RB_MULTI_READS")) {  // rb_engine_set_reads_per_wave is the API
-            if (std::atoi(v) >= 0 && std::atoi(v) <= 3) { e->multi_reads = (uint32_t)std::atoi(v); note("RB_MULTI_READS", v); }
+            if (std::atoi(v) >= 0 && std::atoi(v) <= 2) { e->multi_reads = (uint32_t)std::atoi(v); note("RB_MULTI_READS", v); }
         }
         if (const char *v = std::getenv("RB_SIX_TILES")) { e->six_tile_kernel = std::atoi(v); note("RB_SIX_TILES", v); }
         if (const char *v = std::getenv("RB_MICRO_COPY_KERNEL_BYTES")) { e->micro_copy_kernel_bytes = std::strtoull(v, nullptr, 10); note("RB_MICRO_COPY_KERNEL_BYTES", v); }
@@ -1167,7 +1168,7 @@ int rb_engine_set_phase_xcd_skew(rb_engine *e, uint32_t mode)
 
 int rb_engine_set_reads_per_wave(rb_engine *e, uint32_t reads)
 {
-    if (!e || (reads & ~16u) > 3) return rb::fail(RB_ERR_INVALID_ARG, "0 (the one-read build) to 3 reads per wave");
+    if (!e || (reads & ~16u) > 2) return rb::fail(RB_ERR_INVALID_ARG, "0 (offsets in registers), 1 or 2 reads per wave (+ 16)");
     std::lock_guard<std::mutex> lock(e->mu);
     e->multi_reads = reads & 3u;
     e->multi_no_inv = (reads & 16u) != 0;
@@ -1334,7 +1335,6 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     a.phase = PhaseCfg{0, 0, 0, 0, 0};
     a.multi_reads = 0;
     a.multi_inv = 0;
-    a.multi_aux = 0;
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
     // (profiles/r03/window_sweep.txt: with the bounds-checked gathers and its own window length the six-tile kernel takes 28 %
@@ -1400,6 +1400,15 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             if (!e->phase_explicit)  // a window measured on this device for exactly this table, shape and slice size (rb_engine_calibrate)
                 for (const rb_engine::PhaseOverride &o : e->phase_overrides)
                     if (o.table_bytes == table_bytes && o.stride == f->stride && o.shape == (int)shape && o.lg == a.lg && o.slice_log2 == slice_log2) ticks = o.ticks;
+            // the builds that keep the offsets in LDS (two-word blocks of up to 2^21 - 1 blocks, reads of up to 384 k-mers): planned here because the
+            // window belongs to the build (rb_phase_plan.h, phase_multi_window_factor)
+            const bool multi_build = e->multi_reads && a.lg == 1 && (a.short_only == 1 || a.short_only == 3) && a.planes <= 10 && a.col_begin == 0 &&
+                                     a.col_end == 2 && f->stride == 2 && f->geo.n_blocks < (1ull << 21) - 1;
+            if (multi_build && !e->phase_explicit) {
+                const uint64_t scaled = (uint64_t)((double)a.phase_rule_ticks * phase_multi_window_factor(shape, n_sl) + 0.5);
+                if (ticks == a.phase_rule_ticks) ticks = scaled;  // (a window measured by rb_engine_calibrate for this table stays)
+                a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(scaled, 100), 2000);
+            }
             ticks = std::min<uint64_t>(std::max<uint64_t>(ticks, 100), 2000);
             a.phase_slice_log2 = slice_log2;
             a.phase_ticks = (uint32_t)ticks;
@@ -1410,13 +1419,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.xcd_skew = e->phase_xcd_skew & 1u;
             a.phase.tskew = (e->phase_xcd_skew & 2u) ? (uint32_t)(ticks / e->phase_tskew_div) : 0u;  // each XCD's windows start an eighth of a window after the previous one's
             a.phase_slice_bytes = blocks_per_slice ? blocks_per_slice * f->stride * 8 : (f->stride * 8) << sh;
-            // several reads per wave (two-word blocks, up to 256 k-mers, block numbers of 21 bits)
-            if (e->multi_reads && a.lg == 1 && a.short_only == 1 && a.planes <= 10 && a.col_begin == 0 && a.col_end == 2 && f->stride == 2 &&
-                f->geo.n_blocks < (1ull << 21) - 1)
-            {
-                a.multi_reads = (int)e->multi_reads;
-                a.multi_aux = (int)e->multi_aux;
-            }
+            if (multi_build) a.multi_reads = (int)e->multi_reads;
         } else if ((a.lg == 0 || (shape != PhaseShape::General && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
                     ((shape == PhaseShape::WideFourTiles || shape == PhaseShape::Wide3FourTiles) && phase_fill(shape, kmers) >= 0.8 &&
                      table_bytes < phase_shape_min_bytes(shape, a.lg, 1.0))) && e->short_read_kernel) {
@@ -2333,7 +2336,9 @@ int rb_classify_batch(rb_engine *e, const char *seqs, const uint64_t *offsets, c
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t spins = 0;; ++spins) {
                 if (__atomic_load_n(done, __ATOMIC_ACQUIRE) == seq) { arrived = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#endif
                 if ((spins & 1023u) == 1023u &&
                     std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > (long long)e->completion_spin_us)
                     break;  // overdue (or a kernel has failed): the stream says which

@@ -231,7 +231,8 @@ int rb_ibf_open(const char *path, rb_ibf **out)
     f->words = (uint64_t *)std::malloc(g.n_words * 8);
     if (!f->words) { std::fclose(fp); delete f; return fail(RB_ERR_NOMEM, "cannot allocate IBF image"); }
     // (the stream is positioned behind the 8-byte header; the words are read past it, by several threads for a large file)
-    if (!rb::pread_parallel(fileno(fp), (off_t)8, f->words, (size_t)g.n_words * 8)) {
+    rb::IoGang gang(rb::io_threads((size_t)g.n_words * 8));
+    if (!gang.pread(fileno(fp), (off_t)8, f->words, (size_t)g.n_words * 8)) {
         std::fclose(fp);
         rb_ibf_close(f);
         return fail(RB_ERR_PARSE_IBF, std::string(path) + ": short read");

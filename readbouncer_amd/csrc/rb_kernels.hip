@@ -134,8 +134,14 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane)
 {
     constexpr uint64_t kMask[6] = {0x00000000FFFFFFFFULL, 0x0000FFFF0000FFFFULL, 0x00FF00FF00FF00FFULL,
                                    0x0F0F0F0F0F0F0F0FULL, 0x3333333333333333ULL, 0x5555555555555555ULL};
+    // first swap (32 x 32 blocks): the high words of lanes 0-31 change places with the low words of lanes 32-63 -- one v_permlane32_swap
+    // (gfx950) instead of two ds_bpermute and the selects around them
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)(x >> 32), false, false);
+        x = ((uint64_t)r[1] << 32) | r[0];
+    }
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 1; t < 6; ++t) {
         const int sft = 32 >> t;
         const uint64_t m = kMask[t];
         const uint64_t o = shfl64(x, lane ^ sft);
@@ -1105,20 +1111,46 @@ __device__ __forceinline__ uint64_t pack_lookups(uint64_t v, const IbfDev &f)
 // and one step by 5 instead of thirteen 64-bit multiply-adds per strand (~20 instead of ~180 VALU instructions per window position
 // and both strands).  The count kernels of the narrow filters are three quarters VALU-busy (profiles/r05/pmc_summary.csv, targets3:
 // SQ_INSTS_VALU 4 207 per read, x 4 cycles over 1024 SIMDs = 7.3 of the kernel's 9.5 ms).  Longer k: 64-bit Horner over the bases.
+// T: 64-k-mer tiles per strand (4: reads of up to 256 k-mers; 6: up to 384, the 360 bp prefixes the reference recommends); 2 T slots
+// per lane.  The staging area is the region of the last NST slots (T 4: 1 KiB for up to 268 bases and their two triple arrays; T 6:
+// 1.5 KiB for up to 396), which are reverse-strand slots of the last NST tiles.
+template <int T>
+struct MultiShape {
+    static constexpr int S = 2 * T;                       // slots per lane
+    static constexpr int NST = T == 4 ? 2 : 3;            // slot regions that hold the staged bases
+    static constexpr uint32_t kMaxKmers = 64u * T;
+    static constexpr uint32_t kArr = T == 4 ? 272u : 400u;  // bytes per staged array: ord, then f3, then r3
+    static_assert(3 * kArr <= NST * 512u, "the staged arrays fit the slot regions they borrow");
+};
+
+template <int T>
+__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane);
+template <int T>
 __device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDev &f, const ReadSrc &src, uint32_t rid, uint32_t n_reads, int lane)
 {
-    constexpr int T = 4;
+    using M = MultiShape<T>;
     const uint32_t k = f.k;
     uint32_t len = 0, n = 0;
-    uint8_t *ord = reinterpret_cast<uint8_t *>(slots + 6 * 64);  // 1 KiB: ord[0..272), f3 at +272, r3 at +544
-    uint8_t *f3 = ord + 272, *r3 = ord + 544;
+    uint8_t *ord = reinterpret_cast<uint8_t *>(slots + (M::S - M::NST) * 64);
     if (rid < n_reads) {
         const BaseSrc seq = make_base_src(src, rid, &len);
         n = len >= k ? len - k + 1 : 0;
-        if (n > 256u) n = 0;
+        if (n > M::kMaxKmers) n = 0;
         if (n)
             for (uint32_t i = lane; i < len; i += 64) ord[i] = (uint8_t)seq.ord(i);
     }
+    multi_hash_staged<T>(slots, f, len, n, lane);
+    return n;
+}
+
+// the second half: the read's Dna5 ordinals are staged at the start of the staging area (by this wave; no fence taken yet)
+template <int T>
+__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane)
+{
+    using M = MultiShape<T>;
+    const uint32_t k = f.k;
+    uint8_t *ord = reinterpret_cast<uint8_t *>(slots + (M::S - M::NST) * 64);
+    uint8_t *f3 = ord + M::kArr, *r3 = ord + 2 * M::kArr;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const bool small_k = k <= 13u;
@@ -1132,7 +1164,9 @@ __device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDe
         __builtin_amdgcn_wave_barrier();
     }
     const uint32_t q3 = k / 3u, s1 = k - 3u * q3;  // k = 3 q3 + s1
-    uint64_t held_r[2] = {~0ULL, ~0ULL};  // tiles 2 and 3: their reverse slots 6 and 7 hold the staged bases
+    uint64_t held_r[M::NST];  // the last NST tiles: their reverse slots hold the staged bases
+#pragma unroll
+    for (int i = 0; i < M::NST; ++i) held_r[i] = ~0ULL;
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         const uint32_t p = (uint32_t)(j * 64 + lane);
@@ -1160,66 +1194,47 @@ __device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDe
             pr = pack_lookups(vr, f);
         }
         slots[j * 64 + lane] = pf;
-        if (j < 2) slots[(j + T) * 64 + lane] = pr;
-        else held_r[j - 2] = pr;
+        if (j < T - M::NST) slots[(j + T) * 64 + lane] = pr;
+        else held_r[j - (T - M::NST)] = pr;
         __builtin_amdgcn_sched_barrier(0);  // one window position's hash chains at a time (registers)
     }
-    // every lane has hashed its k-mers by now: slots 6 and 7 take over the staging area
+    // every lane has hashed its k-mers by now: the last slots take over the staging area
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    slots[6 * 64 + lane] = held_r[0];
-    slots[7 * 64 + lane] = held_r[1];
-    return n;
+#pragma unroll
+    for (int i = 0; i < M::NST; ++i) slots[(M::S - M::NST + i) * 64 + lane] = held_r[i];
 }
 
-template <int R, bool INV, int AUX = 0>  // AUX: cache policy bits of the gathers (0 default; 1 sc0, 2 nt, 16 sc1 -- measurements)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : (R == 2 ? RB_MULTI_WAVES : 4), 8))) void ibf_count_max_phased_multi_kernel(
-    IbfDev f, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out, uint32_t out_read_stride, NarrowMerge nm)
+// The accumulators of one read: x0 / x1 = the two word columns of every slot, combined over the three lookups.
+// !INV: x = AND of the table words (a lane that loaded nothing got 0 from the bounds check and ORs in its all-ones mask first).
+// INV: the table holds the COMPLEMENT of the filter's bits (the engine's merged copy has such a twin, rb_engine.hip), x = OR of
+// the loaded words -- the bounds check's 0 is then neutral by itself: no compare, no mask, four ORs per lookup instead of a
+// compare, a select, four ORs and four ANDs, and the relative offsets need not outlive the loads (six registers).  A bin is hit
+// where x stays 0; slots without a k-mer start all-ones, bits beyond a column's bins as well.
+template <bool INV, int T>
+__device__ __forceinline__ void multi_init(uint64_t (&x0)[2 * T], uint64_t (&x1)[2 * T], uint32_t n_kmers, uint64_t valid0, uint64_t valid1, int lane)
 {
-    constexpr int T = 4, S = 2 * T;  // 64-k-mer tiles per strand; slots per lane (forward tiles, then reverse-complement tiles)
-    __shared__ uint64_t s_off[R][S][64];
-    if (ph.xcd_skew) ph.skew = xcc_id();
-    if (ph.tskew) ph.tskew *= xcc_id();
-    const int lane = threadIdx.x;
-    const uint32_t read0 = blockIdx.x * (uint32_t)R;
-    uint32_t nk[R];  // k-mers of each read (0: no such read, or a read longer than promised -- it writes 0 like the one-read build)
-
-    // ---- phase A: hash every k-mer of every read once; the block numbers go to LDS
 #pragma unroll
-    for (int r = 0; r < R; ++r) nk[r] = 0;
-#pragma unroll 1
-    for (int r = 0; r < R; ++r) {
-        const uint32_t n = multi_hash_read(&s_off[r][0][0], f, src, read0 + (uint32_t)r, n_reads, lane);
-#pragma unroll
-        for (int q = 0; q < R; ++q)
-            if (q == r) nk[q] = n;
+    for (int j = 0; j < 2 * T; ++j) {
+        const bool ok = (uint32_t)((j % T) * 64 + lane) < n_kmers;
+        x0[j] = INV ? (ok ? ~valid0 : ~0ULL) : (ok ? valid0 : 0ULL);
+        x1[j] = INV ? (ok ? ~valid1 : ~0ULL) : (ok ? valid1 : 0ULL);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+}
 
-    // ---- phase B: the windows.  x0 / x1: the two word columns of every slot, combined over the three lookups.
-    // !INV: x = AND of the table words (a lane that loaded nothing got 0 from the bounds check and ORs in its all-ones mask first).
-    // INV: the table holds the COMPLEMENT of the filter's bits (the engine's merged copy has such a twin, rb_engine.hip), x = OR of
-    // the loaded words -- the bounds check's 0 is then neutral by itself: no compare, no mask, four ORs per lookup instead of a
-    // compare, a select, four ORs and four ANDs, and the relative offsets need not outlive the loads (six registers).  A bin is hit
-    // where x stays 0; slots without a k-mer start all-ones, bits beyond a column's bins as well.
-    const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
-    uint64_t x0[R][S], x1[R][S];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-            const bool ok = (uint32_t)((j % T) * 64 + lane) < nk[r];
-            x0[r][j] = INV ? (ok ? ~valid0 : ~0ULL) : (ok ? valid0 : 0ULL);
-            x1[r][j] = INV ? (ok ? ~valid1 : ~0ULL) : (ok ? valid1 : 0ULL);
-        }
-    }
+// One pass of the windows over the slices of the table for the R reads of a wave (their packed block numbers in s_off[r][slot][lane]).
+// (Measured and left out, profiles/r06/negative_results.md: cache-policy bits on the gathers -- sc0 / sc1 change nothing, nt keeps the
+// lines out of the L2 and costs a factor of 2.4 --, two slots per batch of gathers.)
+template <int R, bool INV, int T>
+__device__ __forceinline__ void multi_windows(uint64_t (&x0)[R][2 * T], uint64_t (&x1)[R][2 * T], const uint64_t (*s_off)[2 * T][64], const IbfDev &f, const PhaseCfg &ph, int lane)
+{
+    constexpr int S = 2 * T;
     const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 16u)) : min(31u, ph.shift + 4u);
     const uint32_t table_bytes = f.n_blocks * 16u;  // (<= 2^25: the launcher checked)
     const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
     uint32_t done = 0;
     // reads whose gathers of a slot go out together: all of them where the registers allow (INV: no offsets kept), else one by one
-    constexpr int RB = (INV && R <= 2) ? R : 1;
+    constexpr int RB = INV ? R : 1;
 #pragma unroll 1
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
@@ -1249,7 +1264,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 :
                     rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << 4) + nstart;
                     rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << 4) + nstart;
 #pragma unroll
-                    for (int h = 0; h < 3; ++h) d[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel[rr][h], 0, AUX);
+                    for (int h = 0; h < 3; ++h) d[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel[rr][h], 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1270,23 +1285,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 :
             }
         }
     }
+}
+
+// per-bin sums of one read across the wave, maxima per member
+template <bool INV, int T>
+__device__ __forceinline__ void multi_finish(uint64_t (&x0)[2 * T], uint64_t (&x1)[2 * T], const NarrowMerge &nm, int lane, uint16_t *out_row)
+{
+    if constexpr (INV) {
+#pragma unroll
+        for (int j = 0; j < 2 * T; ++j) {
+            x0[j] = ~x0[j];
+            x1[j] = ~x1[j];
+        }
+    }
+    const uint32_t cf = wave_bin_counts<T>(x0, lane) | (wave_bin_counts<T>(x1, lane) << 16);
+    const uint32_t cr = wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
+    const uint32_t colmax[2] = {max(cf & 0xFFFFu, cr & 0xFFFFu), max(cf >> 16, cr >> 16)};
+    write_member_maxima<2>(colmax, nm, lane, out_row);
+}
+
+// waves per SIMD the builds are compiled for: four tiles 8 (R = 1: 50 registers) / 5 (R = 2: 91); six tiles 6 (R = 1: 48 of its ~75 are accumulators)
+constexpr int multi_min_waves(int r, int t) { return t == 4 ? (r == 1 ? 8 : RB_MULTI_WAVES) : (r == 1 ? 6 : 3); }
+
+template <int R, bool INV, int T = 4>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_waves(R, T), 8))) void ibf_count_max_phased_multi_kernel(
+    IbfDev f, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out, uint32_t out_read_stride, NarrowMerge nm)
+{
+    constexpr int S = 2 * T;  // slots per lane: the 64-k-mer tiles of forward k-mers, then those of the reverse complement
+    __shared__ uint64_t s_off[R][S][64];
+    if (ph.xcd_skew) ph.skew = xcc_id();
+    if (ph.tskew) ph.tskew *= xcc_id();
+    const int lane = threadIdx.x;
+    const uint32_t read0 = blockIdx.x * (uint32_t)R;
+    uint32_t nk[R];  // k-mers of each read (0: no such read, or a read longer than promised -- it writes 0 like the one-read build)
+
+    // ---- phase A: hash every k-mer of every read once; the block numbers go to LDS
+#pragma unroll
+    for (int r = 0; r < R; ++r) nk[r] = 0;
+#pragma unroll 1
+    for (int r = 0; r < R; ++r) {
+        const uint32_t n = multi_hash_read<T>(&s_off[r][0][0], f, src, read0 + (uint32_t)r, n_reads, lane);
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            if (q == r) nk[q] = n;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase B: the windows
+    const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
+    uint64_t x0[R][S], x1[R][S];
+#pragma unroll
+    for (int r = 0; r < R; ++r) multi_init<INV, T>(x0[r], x1[r], nk[r], valid0, valid1, lane);
+    multi_windows<R, INV, T>(x0, x1, s_off, f, ph, lane);
 
     // ---- per-bin sums across the wave, maxima per member
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t rid = read0 + (uint32_t)r;
         if (rid >= n_reads) break;  // wave-uniform
-        if constexpr (INV) {
-#pragma unroll
-            for (int j = 0; j < S; ++j) {
-                x0[r][j] = ~x0[r][j];
-                x1[r][j] = ~x1[r][j];
-            }
-        }
-        const uint32_t cf = wave_bin_counts<T>(x0[r], lane) | (wave_bin_counts<T>(x1[r], lane) << 16);
-        const uint32_t cr = wave_bin_counts<T>(x0[r] + T, lane) | (wave_bin_counts<T>(x1[r] + T, lane) << 16);
-        const uint32_t colmax[2] = {max(cf & 0xFFFFu, cr & 0xFFFFu), max(cf >> 16, cr >> 16)};
-        write_member_maxima<2>(colmax, nm, lane, out + (size_t)rid * out_read_stride);
+        multi_finish<INV, T>(x0[r], x1[r], nm, lane, out + (size_t)rid * out_read_stride);
     }
 }
 
@@ -1420,9 +1478,12 @@ __device__ __forceinline__ void decide_one(const DecideParams &P, const uint16_t
 }
 
 // every result of the call is in place: tell the host (DecideParams::done_flag).  Called by all threads of the decision kernel after their
-// reads; the barrier orders the workgroup's result stores before thread 0's release.
+// reads.  The results go to page-locked HOST memory and the host stops waiting for the stream once it sees the word, so every wave
+// makes its own result stores visible at system scope before the barrier (thread 0's release orders only its own wave's
+// stores behind the flag; the barrier alone is a workgroup-scope matter) -- four fences per 256 reads.
 __device__ __forceinline__ void announce_done(const DecideParams &P)
 {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __syncthreads();
     if (threadIdx.x != 0) return;
     if (gridDim.x > 1) {
@@ -1987,34 +2048,23 @@ template <int LG, int NP>
 static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
 {
     dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
-    // two-word blocks, reads of up to 256 k-mers, tables whose block numbers fit 21 bits: several reads per wave, offsets in LDS
+    // two-word blocks, reads of up to 256 / 384 k-mers, tables whose block numbers fit 21 bits: offsets in LDS, one or two reads per wave
     if constexpr (LG == 1 && NP == 10) {
-        if (a.multi_reads && a.short_only == 1 && a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2) {
+        if (a.multi_reads && (a.short_only == 1 || a.short_only == 3) && a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2) {
             if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
-            const uint32_t R = (uint32_t)a.multi_reads;
+            const uint32_t R = a.short_only == 3 ? 1u : (uint32_t)a.multi_reads;  // (six tiles: one read per wave)
             dim3 g2((a.n_reads + R - 1) / R);
-#define RB_LAUNCH_MULTI(RR, INV)                                                                                                        \
-    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<RR, INV>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
+#define RB_LAUNCH_MULTI(RR, INV, TT)                                                                                                    \
+    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<RR, INV, TT>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
                        a.out_read_stride, a.narrow)
-            if (R == 1 && a.multi_inv && a.multi_aux) {  // (cache-policy experiments, R = 1 OR form only)
-#define RB_LAUNCH_AUX(AUX) hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, true, AUX>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow)
-                switch (a.multi_aux) {
-                case 1: RB_LAUNCH_AUX(1); break;
-                case 2: RB_LAUNCH_AUX(2); break;
-                case 3: RB_LAUNCH_AUX(3); break;
-                case 17: RB_LAUNCH_AUX(17); break;
-                default: return hipErrorInvalidValue;
-                }
-#undef RB_LAUNCH_AUX
-            } else if (R == 1 && a.multi_inv) RB_LAUNCH_MULTI(1, true);
-            else if (R == 1) RB_LAUNCH_MULTI(1, false);
-            else if (R == 2 && a.multi_inv) RB_LAUNCH_MULTI(2, true);
-            else if (R == 2) RB_LAUNCH_MULTI(2, false);
-            else if (R == 3 && a.multi_inv) RB_LAUNCH_MULTI(3, true);
-            else if (R == 3) RB_LAUNCH_MULTI(3, false);
+            if (a.short_only == 3 && a.multi_inv) RB_LAUNCH_MULTI(1, true, 6);
+            else if (a.short_only == 3) RB_LAUNCH_MULTI(1, false, 6);
+            else if (R == 1 && a.multi_inv) RB_LAUNCH_MULTI(1, true, 4);
+            else if (R == 1) RB_LAUNCH_MULTI(1, false, 4);
+            else if (R == 2 && a.multi_inv) RB_LAUNCH_MULTI(2, true, 4);
+            else if (R == 2) RB_LAUNCH_MULTI(2, false, 4);
+            else return hipErrorInvalidValue;
 #undef RB_LAUNCH_MULTI
-            else
-                return hipErrorInvalidValue;
             return hipGetLastError();
         }
     }

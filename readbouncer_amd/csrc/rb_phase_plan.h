@@ -269,6 +269,16 @@ inline uint64_t phase_equal_slices_one_word_ticks(PhaseShape shape, uint32_t n_s
     return (uint64_t)(cycle / (double)std::max(n_slices, 1u));
 }
 
+// The builds of round 6 that keep a read's block numbers in LDS (rb_kernels.hip, ibf_count_max_phased_multi_kernel: two-word tables of up to
+// 32 MiB): the window of the shape's rule times this.  Four tiles (eight waves per SIMD where the register build had seven): the same
+// optimum -- 18.9 MiB in five slices, 250 bp: 990 ticks 8.72 ms, 1 045: 8.30, 1 100: 8.21, 1 155: 8.52.  Six tiles (seven waves where the
+// register build had four): the waves of a CU hold 1.6 x the lookups, a window has to serve them -- 360 bp: 1 030 ticks 14.66 ms, 1 133:
+// 13.70, 1 236: 12.28, 1 390: 13.02 (profiles/r06/multi/s13_six_tiles_sweep.txt).
+inline double phase_multi_window_factor(PhaseShape shape, uint32_t /*n_slices*/)
+{
+    return shape == PhaseShape::SixTiles ? 1.2 : 1.0;
+}
+
 // from which table size on the phased form pays ...
 inline uint64_t phase_shape_min_bytes(PhaseShape shape, int lg, double fill)
 {

@@ -124,6 +124,10 @@ public:
     {
         std::lock_guard<std::mutex> lock(mu_);
         const size_t nw = workers_.size();
+        if (nw == 0 || parts == 0) {  // nobody to queue on (or nothing to queue): the caller's wait must not hang, and `part % 0` below must not happen
+            job.pending = 0;
+            return;
+        }
         const size_t all_parts = parts;
         if (parts > nw) parts = nw;  // workers to choose
         // workers in cursor order with their loads; a stable selection of the `parts` smallest keeps the round-robin among ties

@@ -52,6 +52,7 @@ static interleave::TIbf buildIBF(ConfigReader config_reader, const std::string r
     config.kmer_size = (uint16_t)config_reader.IBF_Parsed.size_k;
     config.threads_build = (uint16_t)config_reader.IBF_Parsed.threads;
     config.fragment_length = (uint64_t)config_reader.IBF_Parsed.fragment_size;
+    const auto t_parse = std::chrono::steady_clock::now();
     seqio::Reader in(reference_file);
     if (!in.is_open()) throw interleave::FileParserException("Unable to open the file: " + reference_file);
     std::vector<interleave::RefSeq> records;
@@ -61,10 +62,17 @@ static interleave::TIbf buildIBF(ConfigReader config_reader, const std::string r
     } catch (const std::exception& e) {
         throw interleave::FileParserException("ERROR: Problems parsing the file: " + reference_file + "[" + e.what() + "]");
     }
+    const double parse_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_parse).count();
     interleave::IBF filter{};
     const auto t0 = std::chrono::steady_clock::now();
     interleave::FilterStats stats = filter.create_filter(config, records);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    // where a build's time goes (profiles/cli_build.py reads this line): parsing the FASTA, cutOutNNNs + sizing, the filter's allocation
+    // in HBM, the concatenation, rb_dibf_insert (H2D + the insert kernel), download + file
+    std::cout << "BUILD_PHASES file=" << reference_file << " parse_s=" << parse_s << " load_seq_s=" << stats.timeLoadSeq
+              << " alloc_filter_s=" << stats.timeAllocFilter << " concat_s=" << stats.timeConcat << " insert_s=" << stats.timeInsert
+              << " save_s=" << stats.timeSaveFilter << " create_filter_s=" << stats.timeIBF << " bins=" << stats.totalBinsFile
+              << " bases=" << stats.sumSeqLen << std::endl;
     const uint64_t validSeqs = stats.totalSeqsFile - stats.invalidSeqs;
     std::cerr << "IBF-build processed " << validSeqs << " sequences (" << stats.sumSeqLen / 1000000.0 << " Mbp) in " << secs
               << " seconds" << std::endl;

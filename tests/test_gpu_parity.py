@@ -1748,8 +1748,9 @@ def test_pool_replicas_of_a_large_filter_started_side_by_side():
 
 @pytest.mark.parametrize("widths,n_blocks", [((100,), 2053), ((128,), 4096), ((65,), 30011), ((60, 50), 30011), ((43, 29, 49), 30011), ((64, 64), 8192)])
 def test_several_reads_per_wave_match_oracle(widths, n_blocks):
-    """Round 6: the build of the phased kernel that carries two (or three) reads per wave through a pass of the windows, block numbers
-    packed into LDS (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- two-word blocks, reads of up to 256 k-mers.
+    """Round 6: the builds of the phased kernel that keep a read's block numbers packed in LDS and carry one or two reads per wave
+    through a pass of the windows (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- two-word blocks, reads of up to
+    256 k-mers (four tiles per strand) and up to 384 (six tiles).
     Raw maxima against the oracle and decisions against the one-read build: a filter on its own (Barrett and mask modulus) and merged
     pairs / triples of small targets, odd batch sizes (the last wave has a read too few), empty / short / all-N reads, windows from
     far too short to far too long, the table cut into 1 to 32 slices (the last one ending with the table)."""
@@ -1769,37 +1770,39 @@ def test_several_reads_per_wave_match_oracle(widths, n_blocks):
         h = d.download()
         keep.append(h)
         views.append(po.OracleIBF.wrap(h.info["n_bins"], 3, 13, h.info["n_bits"], h.words()))
-    reads = make_reads(rng, ref, 2299, lo=5, hi=268, err=0.1, n_frac=0.2) + ["", "ACGT", "N" * 268, ref[100:368], "A" * 13, "A" * 12]
-    assert len(reads) % 2 == 1 and len(reads) % 3 != 0
-    buf, offs, lens = H.pack_reads(reads)
     nd = 1 if len(widths) == 1 else 0
     eng = capi.Engine(0, filters[:nd], filters[nd:])
     eng.set_merge(2)
-    exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
-    assert exp.max() > 100
-    base = None
-    for reads_per_wave in (0, 1, 2, 3, 16 + 1, 16 + 2):  # (+ 16: merged tables keep the AND form instead of the complemented twin's OR form)
-        eng.set_reads_per_wave(reads_per_wave)
-        for base_ticks, max_slices in ((1, 8), (300, 32), (2000, 3), (150, 1)):
-            eng.set_phased(0, 1 << 40, base_ticks, 0, 1)
-            eng.set_phase_slices(1, max_slices)
-            pl = eng.plan(0, len(lens), int(lens.max()))
-            assert pl["kernel"] == ("ibf_count_max_phased_multi_kernel" if reads_per_wave else "ibf_count_max_phased_kernel"), pl
-            assert pl["block_words"] == 2 and pl["reserved0"] == (reads_per_wave & 3)
-            got = eng.classify(buf, offs, lens)
-            assert np.array_equal(got[0], exp), (reads_per_wave, base_ticks, max_slices)
-            if base is None:
-                base = got
-            assert all(np.array_equal(a, b) for a, b in zip(got, base)), (reads_per_wave, base_ticks, max_slices)
-        # sub-batches: every remainder of the batch size modulo the reads per wave
-        for n_sub in (2049, 2050, 2051):
-            got = eng.classify(buf, offs[:n_sub], lens[:n_sub])
-            assert np.array_equal(got[0], exp[:n_sub]), (reads_per_wave, n_sub)
+    for hi in (268, 396):  # four tiles per strand (up to 256 k-mers) and six (up to 384: 360 bp prefixes); k = 13
+        reads = make_reads(rng, ref, 2299, lo=5, hi=hi, err=0.1, n_frac=0.2) + ["", "ACGT", "N" * hi, ref[100:100 + hi], "A" * 13, "A" * 12]
+        assert len(reads) % 2 == 1
+        buf, offs, lens = H.pack_reads(reads)
+        exp = np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1)
+        assert exp.max() > 100
+        base = None
+        # (+ 16: merged tables keep the AND form instead of the complemented twin's OR form)
+        for reads_per_wave in (0, 1, 2, 16 + 1, 16 + 2):
+            eng.set_reads_per_wave(reads_per_wave)
+            for base_ticks, max_slices in ((1, 8), (300, 32), (2000, 3), (150, 1)):
+                eng.set_phased(0, 1 << 40, base_ticks, 0, 1)
+                eng.set_phase_slices(1, max_slices)
+                pl = eng.plan(0, len(lens), int(lens.max()))
+                assert pl["kernel"] == ("ibf_count_max_phased_multi_kernel" if reads_per_wave else "ibf_count_max_phased_kernel"), pl
+                assert pl["block_words"] == 2 and pl["reserved0"] == (reads_per_wave & 3)
+                got = eng.classify(buf, offs, lens)
+                assert np.array_equal(got[0], exp), (reads_per_wave, base_ticks, max_slices)
+                if base is None:
+                    base = got
+                assert all(np.array_equal(a, b) for a, b in zip(got, base)), (reads_per_wave, base_ticks, max_slices)
+            # sub-batches: every remainder of the batch size modulo the reads per wave
+            for n_sub in (2049, 2050, 2051):
+                got = eng.classify(buf, offs[:n_sub], lens[:n_sub])
+                assert np.array_equal(got[0], exp[:n_sub]), (reads_per_wave, n_sub)
     eng.set_phased()
     eng.set_phase_slices()
-    # reads longer than the build takes: the engine plans the one-read builds for the batch
+    # reads longer than the builds take: the engine plans the builds with the offsets in registers for the batch
     eng.set_reads_per_wave(2)
-    assert eng.plan(0, 4096, 300)["kernel"] != "ibf_count_max_phased_multi_kernel"
+    assert eng.plan(0, 4096, 500)["kernel"] != "ibf_count_max_phased_multi_kernel"
 
 
 def test_device_thresholds_match_the_reference_compiled_table():
@@ -1844,12 +1847,18 @@ def test_device_thresholds_match_the_reference_compiled_table():
         buf, offs, lens = H.pack_reads(reads)
         want_m, want_dec = np.array(want_m), np.array(want_dec, dtype=np.uint8)
         assert want_dec.sum() > 100 and (want_dec == 0).sum() > 100
+        thr_of = np.array([int(table[int(L) - k]) for L in lens])
         for split in (2048, 0):  # latency form (sub-batches of up to 512 reads: the count kernel decides itself) and throughput form + K2
             eng.set_split_threshold(split)
             for lo in range(0, len(reads), 500 if split else len(reads)):
                 hi = min(len(reads), lo + (500 if split else len(reads)))
                 mc, _, dec, st = eng.classify(buf, offs[lo:hi], lens[lo:hi], error_rate=rate)
-                assert np.array_equal(mc[:, 0], want_m[lo:hi]), "the planted counts are not what the test built"
-                bad = np.nonzero(dec != want_dec[lo:hi])[0]
-                assert len(bad) == 0, [(int(lens[lo + i]), int(mc[i, 0]), int(table[int(lens[lo + i]) - k])) for i in bad[:5]]
+                # (a long random read now and then repeats one of its own planted 13-mers further down: the count the device reports is
+                # the count -- verified against the oracle elsewhere -- and the decision must follow from IT and the reference's threshold)
+                got_m = mc[:, 0].astype(np.int64)
+                assert (got_m == want_m[lo:hi]).mean() > 0.97 and np.all(got_m >= want_m[lo:hi]), "the planted counts are not what the test built"
+                expect = ((got_m >= thr_of[lo:hi]) & (got_m > 0)).astype(np.uint8)
+                bad = np.nonzero(dec != expect)[0]
+                assert len(bad) == 0, [(int(lens[lo + i]), int(mc[i, 0]), int(thr_of[lo + i])) for i in bad[:5]]
+                assert (expect != want_dec[lo:hi]).sum() <= 3  # ... and nearly every read sits where it was put: one each side of t(L)
         eng.destroy()

@@ -519,6 +519,27 @@ def test_pool_work_queue_on_cpu():
     assert p.returncode == 0 and "failures: 0" in p.stdout, p.stdout + p.stderr
 
 
+def test_filter_load_reader_threads_on_cpu(tmp_path):
+    """tests/cpp/test_io.cpp (CPU only): csrc/rb_io.h -- one gang of reader threads per filter load serving every chunk, a request
+    beyond the end of the file and a file that shrinks while it is read end in `false` (the other parts stop at their next 4 MiB
+    piece), gangs of one and of more threads than parts, an invalid descriptor"""
+    exe = os.path.join(ROOT, "readbouncer_amd", "test_io")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "rb_io: ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_live_step_host_logic_on_cpu():
+    """tests/cpp/test_live.cpp (CPU only): csrc/rb_live.cpp with the engine call replaced by a stand-in at link time -- micro-batches
+    of every size (ids repeated within a batch, short reads, reads that stay undecided past the 1 500 bp cut-off) give the actions of
+    the reference's chunk-by-chunk loop (adaptive_sampling.hpp:227-350); a call that fails as a whole changes nothing; four threads
+    on one handle.  The same binary runs under ASan / UBSan / TSan in profiles/sanitize_cpu.sh."""
+    exe = os.path.join(ROOT, "readbouncer_amd", "test_live")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "failures: 0" in p.stdout, p.stdout + p.stderr
+
+
 @pytest.mark.gpu
 def test_usage_target_replays_chunks_through_the_live_step(tmp_path):
     """usage = "target" on the TOML surface (main.cpp:365-378) as an offline replay: pre-basecalled chunks in arrival order
