@@ -503,6 +503,7 @@ class Ctx:
         self.filters = {}  # workload key -> (DeviceIBF, planted reference)
         self.views = {}    # workload key -> (host image, oracle view of it)
         self.filter_setup_s = 0.0
+        self.create_s = {}  # key -> seconds of its build_device_filter (allocation with the placement trial, synthetic fill, planted inserts)
 
     SEEDS = {"c2": (2, 20), "c3": (4, 40), "c3np2": (4, 40), "c1": (1, 10), "zymo": (6, 60), "grch38_f100k": (8, 80),
              "zymo16": (6, 60), "mock_deplete": (11, 110), "mock_t1": (12, 111), "mock_t2": (13, 112), "mock_t3": (14, 113), "w1_64mib": (15, 114)}
@@ -517,6 +518,7 @@ class Ctx:
                                                           n_segments=seg)
             self.torch.cuda.synchronize()
             self.filter_setup_s += time.time() - t
+            self.create_s[key] = round(time.time() - t, 3)
         return self.filters[key]
 
     def oracle_view(self, key):
@@ -802,8 +804,16 @@ def run_throughput(ctx, name, n_reads=0, read_len=0, steps=None, warmup=None, cp
                               "table size, its misses = the share beyond the L2); hits / misses per read: " + str(tj_req.get("source", "profiles/traffic.json"))}
             except Exception as ex:  # noqa: BLE001  (a measurement aid never fails the bench)
                 roof["request_bound"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:160])}
-        try:  # tables of >= 1 GiB are placed by trial (rb_set_placement_tries): allocations probed, GB/s of the kept and of the slowest one
-            roof["placement"] = [dict(zip(("tries", "kept_GBps", "slowest_GBps"), f.placement())) for f in filters]
+        try:  # tables of >= 1 GiB are placed by trial (rb_set_placement_tries): allocations probed, GB/s of the kept and of the slowest one,
+            # and what the trial cost this filter: seconds probing, seconds waited afterwards, the most HBM its candidates held at once
+            # (create_s = the whole rb_dibf_create incl. the trial: without it the load would have taken create_s - trial_s - settle_s)
+            roof["placement"] = []
+            for kk, f in zip(dep_keys + tgt_keys, filters):
+                rec = dict(zip(("tries", "kept_GBps", "slowest_GBps"), f.placement()))
+                rec.update(f.placement_cost())
+                rec["create_s"] = ctx.create_s.get(kk)
+                rec["table_bytes"] = int(f.info["n_words"] * 8)
+                roof["placement"].append(rec)
         except Exception:  # noqa: BLE001
             pass
         table_bytes = sum(f.info["n_words"] * 8 for f in filters)
@@ -1572,8 +1582,9 @@ def main():
     if no_engine:
         return null_engine_run(args, torch, dist, world, rank, backend)
     torch.cuda.set_device(dev_index)
-    if same_gpu and world > 2:
-        # (test hook: many ranks on ONE device -- every rank's placement trial would hold up to five copies of an 8 GiB table at once)
+    if same_gpu or os.environ.get("RB_BENCH_PLACEMENT") == "off":
+        # (test hook: several ranks on ONE device -- every rank's placement trial would hold up to five copies of an 8 GiB table at once, and
+        # the `free HBM` it reads is not atomic with the other ranks' trials; RB_BENCH_PLACEMENT=off: the A/B run of profiles/r06)
         from readbouncer_amd import capi as _capi
         _capi.set_placement_tries(1)
     ctx = Ctx(args, torch, dist, world, rank, dev_index, backend, same_gpu, force_group)

@@ -118,6 +118,7 @@ struct CountLaunch {
     uint64_t phase_slice_bytes;              // ... and the slice length in effect (2^phase_slice_log2, or the equal-length slices of the four-word builds)
     int short_only;               // 1 / 3 / 2: the declared max_len gives at most 256 / 384 / 512 k-mers per read; 0: more
     int multi_reads;              // phased form, two-word blocks, short_only 1: reads per wave of ibf_count_max_phased_multi_kernel (0: the one-read build)
+    int multi_tiles;              // ... tiles per strand of that build: 4 (reads of up to 256 k-mers) or 6 (up to 384)
     int multi_inv;                // ... and f.words is the COMPLEMENTED twin of a merged copy (the build that ORs instead of masking and ANDing)
     int split_waves;              // >= 2: latency form, workgroups of split_waves waves
     int split_parts, split_sub;   // latency form: workgroups per (read, slice) and shares per macro tile (0/1 = one workgroup)

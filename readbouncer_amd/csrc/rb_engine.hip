@@ -331,6 +331,9 @@ struct rb_engine {
     // one-read build
     uint32_t multi_reads = 1;   // (default since round 6: 250 bp -10 ... -11 %, 360 bp -16 ... -19 % on two-word tables, profiles/r06/multi/)
     uint32_t phase_tskew_div = 8;  // RB_PHASE_TSKEW_DIV: the XCDs' windows start 1 / this of a window apart (time skew)
+    bool multi_one_word = true;  // ... for one-word blocks of up to 2^21 - 1 of them (16 MiB) (RB_MULTI_ONE_WORD=0: the register builds)
+    bool multi_wide = true;      // ... and for blocks of three and four words (RB_MULTI_WIDE=0: those keep the register builds)
+    bool multi_wide_six = true;  // ... six tiles in one round for their reads of 257-384 k-mers (RB_MULTI_WIDE_SIX=0: rounds of three tiles)
     bool multi_no_inv = false;  // (bit 4 of rb_engine_set_reads_per_wave's argument: the AND form on merged copies too; measurements)
     // rb_engine_calibrate: window lengths measured on this device that replace the planner's for a (table, kernel shape, slice size)
     struct PhaseOverride {
@@ -921,6 +924,9 @@ int rb_engine_create(int device, rb_dibf *const *deplete, size_t n_deplete, rb_d
         if (const char *v = std::getenv("RB_PHASE_N_SLICES")) { e->phase_n_slices = (uint32_t)std::max(0, std::atoi(v)); note("RB_PHASE_N_SLICES", v); }
         if (const char *v = std::getenv("RB_PHASE_XCD_SKEW")) { e->phase_xcd_skew = (uint32_t)std::atoi(v) & 3u; note("RB_PHASE_XCD_SKEW", v); }
         if (const char *v = std::getenv("RB_PHASE_TSKEW_DIV")) { if (std::atoi(v) >= 1) { e->phase_tskew_div = (uint32_t)std::atoi(v); note("RB_PHASE_TSKEW_DIV", v); } }
+        if (const char *v = std::getenv("RB_MULTI_ONE_WORD")) { e->multi_one_word = std::atoi(v) != 0; note("RB_MULTI_ONE_WORD", v); }
+        if (const char *v = std::getenv("RB_MULTI_WIDE")) { e->multi_wide = std::atoi(v) != 0; note("RB_MULTI_WIDE", v); }
+        if (const char *v = std::getenv("RB_MULTI_WIDE_SIX")) { e->multi_wide_six = std::atoi(v) != 0; note("RB_MULTI_WIDE_SIX", v); }
         if (const char *v = std::getenv("RB_MULTI_READS")) {  // rb_engine_set_reads_per_wave is the API
             if (std::atoi(v) >= 0 && std::atoi(v) <= 2) { e->multi_reads = (uint32_t)std::atoi(v); note("RB_MULTI_READS", v); }
         }
@@ -1335,6 +1341,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
     a.phase = PhaseCfg{0, 0, 0, 0, 0};
     a.multi_reads = 0;
     a.multi_inv = 0;
+    a.multi_tiles = 0;
     a.short_only = kmers <= 256 ? 1 : kmers <= 512 ? 2 : 0;
     // 257-384 k-mers (360 bp reads): one round of six tiles per strand instead of two rounds of four
     // (profiles/r03/window_sweep.txt: with the bounds-checked gathers and its own window length the six-tile kernel takes 28 %
@@ -1401,11 +1408,16 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
                 for (const rb_engine::PhaseOverride &o : e->phase_overrides)
                     if (o.table_bytes == table_bytes && o.stride == f->stride && o.shape == (int)shape && o.lg == a.lg && o.slice_log2 == slice_log2) ticks = o.ticks;
             // the builds that keep the offsets in LDS (two-word blocks of up to 2^21 - 1 blocks, reads of up to 384 k-mers): planned here because the
-            // window belongs to the build (rb_phase_plan.h, phase_multi_window_factor)
-            const bool multi_build = e->multi_reads && a.lg == 1 && (a.short_only == 1 || a.short_only == 3) && a.planes <= 10 && a.col_begin == 0 &&
-                                     a.col_end == 2 && f->stride == 2 && f->geo.n_blocks < (1ull << 21) - 1;
+            // window belongs to the build (rb_phase_plan.h, phase_multi_window_ticks)
+            // (lg 1: short_only 1 / 3 = at most 256 / 384 k-mers; lg 2, blocks of three and four words: short_only 5 = at most 256, 4 = at most 512 --
+            // up to 384 of them fit one round of six tiles)
+            const int multi_tiles = a.lg <= 1 ? (a.short_only == 1 ? 4 : a.short_only == 3 ? 6 : 0)
+                                    : (a.lg == 2 && wide_short) ? (a.short_only == 5 ? 4 : (a.short_only == 4 && kmers <= 384 && e->multi_wide_six) ? 6 : 0) : 0;
+            const bool multi_build = e->multi_reads && multi_tiles && a.planes <= 10 && a.col_begin == 0 && f->geo.n_blocks < (1ull << 21) - 1 &&
+                                     ((a.lg == 1 && a.col_end == 2 && f->stride == 2) || (a.lg == 2 && e->multi_wide && f->stride == 4) ||
+                                      (a.lg == 0 && e->multi_one_word && a.col_end == 1 && f->stride == 1 && W == 1));
             if (multi_build && !e->phase_explicit) {
-                const uint64_t scaled = (uint64_t)((double)a.phase_rule_ticks * phase_multi_window_factor(shape, n_sl) + 0.5);
+                const uint64_t scaled = phase_multi_window_ticks(shape, slice_log2, n_sl, kmers, a.phase_rule_ticks);
                 if (ticks == a.phase_rule_ticks) ticks = scaled;  // (a window measured by rb_engine_calibrate for this table stays)
                 a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(scaled, 100), 2000);
             }
@@ -1419,7 +1431,10 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             a.phase.xcd_skew = e->phase_xcd_skew & 1u;
             a.phase.tskew = (e->phase_xcd_skew & 2u) ? (uint32_t)(ticks / e->phase_tskew_div) : 0u;  // each XCD's windows start an eighth of a window after the previous one's
             a.phase_slice_bytes = blocks_per_slice ? blocks_per_slice * f->stride * 8 : (f->stride * 8) << sh;
-            if (multi_build) a.multi_reads = (int)e->multi_reads;
+            if (multi_build) {
+                a.multi_reads = (int)e->multi_reads;
+                a.multi_tiles = multi_tiles;
+            }
         } else if ((a.lg == 0 || (shape != PhaseShape::General && a.col_begin == 0 && a.col_end == 2 && f->stride == 2) ||
                     ((shape == PhaseShape::WideFourTiles || shape == PhaseShape::Wide3FourTiles) && phase_fill(shape, kmers) >= 0.8 &&
                      table_bytes < phase_shape_min_bytes(shape, a.lg, 1.0))) && e->short_read_kernel) {
@@ -1728,7 +1743,7 @@ static int ensure_merged_table(rb_engine *e, MergedGroup *g, hipStream_t st)
         if (!t->d_words) {
             t->stride = hbm_stride(g->width);
             t->n_blocks = g->n_blocks;
-            const bool twin = t->stride == 2 && g->width == 2 && t->n_blocks < (1ull << 21) - 1;
+            const bool twin = ((t->stride == 2 && g->width == 2) || (t->stride == 4 && g->width >= 3 && g->width <= 4)) && t->n_blocks < (1ull << 21) - 1;
             if (hipMalloc((void **)&t->d_words, (t->n_blocks * t->stride + 8) * 8 * (twin ? 2 : 1)) != hipSuccess) {
                 (void)hipGetLastError();
                 t->d_words = nullptr;

@@ -1091,6 +1091,9 @@ constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
 #ifndef RB_MULTI_WAVES
 #define RB_MULTI_WAVES 5
 #endif
+#ifndef RB_MULTI_WAVES_W4  // the four-word build of four tiles (64 accumulator registers)
+#define RB_MULTI_WAVES_W4 5
+#endif
 
 // three packed block numbers of one k-mer (kPackBits each)
 __device__ __forceinline__ uint64_t pack_lookups(uint64_t v, const IbfDev &f)
@@ -1211,30 +1214,38 @@ __device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev 
 // the loaded words -- the bounds check's 0 is then neutral by itself: no compare, no mask, four ORs per lookup instead of a
 // compare, a select, four ORs and four ANDs, and the relative offsets need not outlive the loads (six registers).  A bin is hit
 // where x stays 0; slots without a k-mer start all-ones, bits beyond a column's bins as well.
-template <bool INV, int T>
-__device__ __forceinline__ void multi_init(uint64_t (&x0)[2 * T], uint64_t (&x1)[2 * T], uint32_t n_kmers, uint64_t valid0, uint64_t valid1, int lane)
+template <bool INV, int T, int NW>
+__device__ __forceinline__ void multi_init(uint64_t (&x)[NW][2 * T], uint32_t n_kmers, const NarrowMerge &nm, int lane)
 {
 #pragma unroll
-    for (int j = 0; j < 2 * T; ++j) {
-        const bool ok = (uint32_t)((j % T) * 64 + lane) < n_kmers;
-        x0[j] = INV ? (ok ? ~valid0 : ~0ULL) : (ok ? valid0 : 0ULL);
-        x1[j] = INV ? (ok ? ~valid1 : ~0ULL) : (ok ? valid1 : 0ULL);
+    for (int c = 0; c < NW; ++c) {
+        const uint64_t valid = col_bits_mask(nm.col_bits[c]);
+#pragma unroll
+        for (int j = 0; j < 2 * T; ++j) {
+            const bool ok = (uint32_t)((j % T) * 64 + lane) < n_kmers;
+            x[c][j] = INV ? (ok ? ~valid : ~0ULL) : (ok ? valid : 0ULL);
+        }
     }
 }
 
 // One pass of the windows over the slices of the table for the R reads of a wave (their packed block numbers in s_off[r][slot][lane]).
-// (Measured and left out, profiles/r06/negative_results.md: cache-policy bits on the gathers -- sc0 / sc1 change nothing, nt keeps the
-// lines out of the L2 and costs a factor of 2.4 --, two slots per batch of gathers.)
-template <int R, bool INV, int T>
-__device__ __forceinline__ void multi_windows(uint64_t (&x0)[R][2 * T], uint64_t (&x1)[R][2 * T], const uint64_t (*s_off)[2 * T][64], const IbfDev &f, const PhaseCfg &ph, int lane)
+// NW: words per block (2: 16-byte blocks, one 16-byte gather per lookup; 4: blocks of three or four words at a stride of four, two
+// gathers).  (Measured and left out, profiles/r06/negative_results.md: cache-policy bits on the gathers -- sc0 / sc1 change nothing, nt
+// keeps the lines out of the L2 and costs a factor of 2.4 --, two slots per batch of gathers.)
+template <int R, bool INV, int T, int NW>
+__device__ __forceinline__ void multi_windows(uint64_t (&x)[R][NW][2 * T], const uint64_t (*s_off)[2 * T][64], const IbfDev &f, const PhaseCfg &ph, int lane)
 {
+    static_assert(NW == 1 || NW == 2 || NW == 4, "one- and two-word blocks, or the stride-4 layout of three- and four-word blocks");
     constexpr int S = 2 * T;
-    const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 16u)) : min(31u, ph.shift + 4u);
-    const uint32_t table_bytes = f.n_blocks * 16u;  // (<= 2^25: the launcher checked)
+    constexpr uint32_t kBlockShift = NW == 1 ? 3u : NW == 2 ? 4u : 5u;  // log2 bytes from one block to the next
+    const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) << kBlockShift)) : min(31u, ph.shift + kBlockShift);
+    const uint32_t table_bytes = f.n_blocks << kBlockShift;  // (< 2^26: the launcher checked)
     const uint32_t all = ph.n_slices >= 32 ? ~0u : (1u << ph.n_slices) - 1u;
     uint32_t done = 0;
-    // reads whose gathers of a slot go out together: all of them where the registers allow (INV: no offsets kept), else one by one
-    constexpr int RB = INV ? R : 1;
+    // reads whose gathers of a slot go out together: all of them where the registers allow (OR form of the two-word build: no offsets
+    // kept), else one by one
+    constexpr int RB = (INV && NW == 2) ? R : 1;
+    constexpr int G = NW == 1 ? 1 : NW / 2;  // gathers per lookup (8 bytes for one-word blocks, else 16)
 #pragma unroll 1
     while (done != all) {
         const uint32_t cur = phase_next_slice(done, ph);
@@ -1253,31 +1264,45 @@ __device__ __forceinline__ void multi_windows(uint64_t (&x0)[R][2 * T], uint64_t
         for (int u = 0; u < S; ++u) {
 #pragma unroll
             for (int r0 = 0; r0 < R; r0 += RB) {
-                rb_u32x4 d[RB][3];
+                rb_u32x4 d[RB][3][G];
                 uint32_t rel[RB][3];
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) {
                     const uint64_t pk = s_off[r0 + rr][u][lane];
                     const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
                     // (field extract + shift-and-add of the negated slice start: seven VALU operations per k-mer)
-                    rel[rr][0] = ((lo & kPackMask) << 4) + nstart;
-                    rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << 4) + nstart;
-                    rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << 4) + nstart;
+                    rel[rr][0] = ((lo & kPackMask) << kBlockShift) + nstart;
+                    rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << kBlockShift) + nstart;
+                    rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << kBlockShift) + nstart;
 #pragma unroll
-                    for (int h = 0; h < 3; ++h) d[rr][h] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel[rr][h], 0, 0);
+                    for (int h = 0; h < 3; ++h) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {  // ("no lookup" stays out of range with bit 4 set: its offset ends in zeros)
+                            if constexpr (NW == 1) {
+                                const rb_u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rs, rel[rr][h], 0, 0);
+                                d[rr][h][g] = rb_u32x4{w.x, w.y, 0u, 0u};
+                            } else {
+                                d[rr][h][g] = __builtin_amdgcn_raw_buffer_load_b128(rs, rel[rr][h] | (uint32_t)(16 * g), 0, 0);
+                            }
+                        }
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int rr = 0; rr < RB; ++rr) {
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
-                        if constexpr (INV) {
-                            x0[r0 + rr][u] |= (((uint64_t)d[rr][h].y) << 32) | d[rr][h].x;
-                            x1[r0 + rr][u] |= (((uint64_t)d[rr][h].w) << 32) | d[rr][h].z;
-                        } else {
-                            const uint32_t o = rel[rr][h] >= span ? 0xFFFFFFFFu : 0u;  // lanes that loaded nothing
-                            x0[r0 + rr][u] &= (((uint64_t)(d[rr][h].y | o)) << 32) | (d[rr][h].x | o);
-                            x1[r0 + rr][u] &= (((uint64_t)(d[rr][h].w | o)) << 32) | (d[rr][h].z | o);
+                        const uint32_t o = (!INV && rel[rr][h] >= span) ? 0xFFFFFFFFu : 0u;  // AND form: lanes that loaded nothing
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const uint64_t w0 = (((uint64_t)(d[rr][h][g].y | o)) << 32) | (d[rr][h][g].x | o);
+                            if constexpr (INV) x[r0 + rr][NW == 1 ? 0 : 2 * g][u] |= w0;
+                            else x[r0 + rr][NW == 1 ? 0 : 2 * g][u] &= w0;
+                            if constexpr (NW > 1) {
+                                const uint64_t w1 = (((uint64_t)(d[rr][h][g].w | o)) << 32) | (d[rr][h][g].z | o);
+                                if constexpr (INV) x[r0 + rr][2 * g + 1][u] |= w1;
+                                else x[r0 + rr][2 * g + 1][u] &= w1;
+                            }
                         }
                     }
                 }
@@ -1288,27 +1313,36 @@ __device__ __forceinline__ void multi_windows(uint64_t (&x0)[R][2 * T], uint64_t
 }
 
 // per-bin sums of one read across the wave, maxima per member
-template <bool INV, int T>
-__device__ __forceinline__ void multi_finish(uint64_t (&x0)[2 * T], uint64_t (&x1)[2 * T], const NarrowMerge &nm, int lane, uint16_t *out_row)
+template <bool INV, int T, int NW>
+__device__ __forceinline__ void multi_finish(uint64_t (&x)[NW][2 * T], const NarrowMerge &nm, int lane, uint16_t *out_row)
 {
     if constexpr (INV) {
 #pragma unroll
-        for (int j = 0; j < 2 * T; ++j) {
-            x0[j] = ~x0[j];
-            x1[j] = ~x1[j];
+        for (int c = 0; c < NW; ++c) {
+#pragma unroll
+            for (int j = 0; j < 2 * T; ++j) x[c][j] = ~x[c][j];
         }
     }
-    const uint32_t cf = wave_bin_counts<T>(x0, lane) | (wave_bin_counts<T>(x1, lane) << 16);
-    const uint32_t cr = wave_bin_counts<T>(x0 + T, lane) | (wave_bin_counts<T>(x1 + T, lane) << 16);
-    const uint32_t colmax[2] = {max(cf & 0xFFFFu, cr & 0xFFFFu), max(cf >> 16, cr >> 16)};
-    write_member_maxima<2>(colmax, nm, lane, out_row);
+    uint32_t colmax[NW];  // lane b: the larger of the two strands' counts of bin 64 c + b (at most 384 each: two share a register)
+    if constexpr (NW == 1) {
+        const uint32_t cf = wave_bin_counts<T>(x[0], lane), cr = wave_bin_counts<T>(x[0] + T, lane);
+        colmax[0] = max(cf, cr);
+    }
+#pragma unroll
+    for (int c = 0; c + 1 < NW; c += 2) {
+        const uint32_t cf = wave_bin_counts<T>(x[c], lane) | (wave_bin_counts<T>(x[c + 1], lane) << 16);
+        const uint32_t cr = wave_bin_counts<T>(x[c] + T, lane) | (wave_bin_counts<T>(x[c + 1] + T, lane) << 16);
+        colmax[c] = max(cf & 0xFFFFu, cr & 0xFFFFu);
+        colmax[c + 1] = max(cf >> 16, cr >> 16);
+    }
+    write_member_maxima<NW>(colmax, nm, lane, out_row);
 }
 
-// waves per SIMD the builds are compiled for: four tiles 8 (R = 1: 50 registers) / 5 (R = 2: 91); six tiles 6 (R = 1: 48 of its ~75 are accumulators)
-constexpr int multi_min_waves(int r, int t) { return t == 4 ? (r == 1 ? 8 : RB_MULTI_WAVES) : (r == 1 ? 6 : 3); }
+// waves per SIMD the builds are compiled for: two-word four tiles 8 (R = 1: 50 registers) / 5 (R = 2: 91), six tiles 6; four-word 4
+constexpr int multi_min_waves(int r, int t, int nw) { return nw == 1 ? 8 : nw == 4 ? (t == 4 ? RB_MULTI_WAVES_W4 : 3) : t == 4 ? (r == 1 ? 8 : RB_MULTI_WAVES) : (r == 1 ? 6 : 3); }
 
-template <int R, bool INV, int T = 4>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_waves(R, T), 8))) void ibf_count_max_phased_multi_kernel(
+template <int R, bool INV, int T = 4, int NW = 2>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_waves(R, T, NW), 8))) void ibf_count_max_phased_multi_kernel(
     IbfDev f, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out, uint32_t out_read_stride, NarrowMerge nm)
 {
     constexpr int S = 2 * T;  // slots per lane: the 64-k-mer tiles of forward k-mers, then those of the reverse complement
@@ -1333,18 +1367,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_wa
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase B: the windows
-    const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
-    uint64_t x0[R][S], x1[R][S];
+    uint64_t x[R][NW][S];
 #pragma unroll
-    for (int r = 0; r < R; ++r) multi_init<INV, T>(x0[r], x1[r], nk[r], valid0, valid1, lane);
-    multi_windows<R, INV, T>(x0, x1, s_off, f, ph, lane);
+    for (int r = 0; r < R; ++r) multi_init<INV, T, NW>(x[r], nk[r], nm, lane);
+    multi_windows<R, INV, T, NW>(x, s_off, f, ph, lane);
 
     // ---- per-bin sums across the wave, maxima per member
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t rid = read0 + (uint32_t)r;
         if (rid >= n_reads) break;  // wave-uniform
-        multi_finish<INV, T>(x0[r], x1[r], nm, lane, out + (size_t)rid * out_read_stride);
+        multi_finish<INV, T, NW>(x[r], nm, lane, out + (size_t)rid * out_read_stride);
     }
 }
 
@@ -2050,21 +2083,33 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
     dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
     // two-word blocks, reads of up to 256 / 384 k-mers, tables whose block numbers fit 21 bits: offsets in LDS, one or two reads per wave
     if constexpr (LG == 1 && NP == 10) {
-        if (a.multi_reads && (a.short_only == 1 || a.short_only == 3) && a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2) {
+        if (a.multi_reads && a.multi_tiles && a.col_begin == 0 && a.col_end == 2 && a.f.stride == 2) {
             if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
-            const uint32_t R = a.short_only == 3 ? 1u : (uint32_t)a.multi_reads;  // (six tiles: one read per wave)
+            const uint32_t R = a.multi_tiles == 6 ? 1u : (uint32_t)a.multi_reads;  // (six tiles: one read per wave)
             dim3 g2((a.n_reads + R - 1) / R);
 #define RB_LAUNCH_MULTI(RR, INV, TT)                                                                                                    \
-    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<RR, INV, TT>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
+    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<RR, INV, TT, 2>), g2, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
                        a.out_read_stride, a.narrow)
-            if (a.short_only == 3 && a.multi_inv) RB_LAUNCH_MULTI(1, true, 6);
-            else if (a.short_only == 3) RB_LAUNCH_MULTI(1, false, 6);
+            if (a.multi_tiles == 6 && a.multi_inv) RB_LAUNCH_MULTI(1, true, 6);
+            else if (a.multi_tiles == 6) RB_LAUNCH_MULTI(1, false, 6);
             else if (R == 1 && a.multi_inv) RB_LAUNCH_MULTI(1, true, 4);
             else if (R == 1) RB_LAUNCH_MULTI(1, false, 4);
             else if (R == 2 && a.multi_inv) RB_LAUNCH_MULTI(2, true, 4);
             else if (R == 2) RB_LAUNCH_MULTI(2, false, 4);
             else return hipErrorInvalidValue;
 #undef RB_LAUNCH_MULTI
+            return hipGetLastError();
+        }
+    }
+    // one-word blocks the same way (a filter of up to 64 bins on its own: the AND form)
+    if constexpr (LG == 0 && NP == 10) {
+        if (a.multi_reads && a.multi_tiles && a.col_begin == 0 && a.col_end == 1 && a.f.stride == 1) {
+            if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
+            dim3 g1(a.n_reads);
+            if (a.multi_tiles == 6)
+                hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, false, 6, 1>), g1, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
+            else
+                hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, false, 4, 1>), g1, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);
             return hipGetLastError();
         }
     }
@@ -2102,6 +2147,20 @@ static hipError_t dispatch_phased(const CountLaunch &a, hipStream_t st)
     // 512 k-mers (short_only 4); wider blocks gain nothing from phases (rb_engine.hip, phase_slice_log2)
     if (a.lg == 2) {
         if constexpr (NP == 10) {
+            // blocks of three and four words (stride 4), reads of up to 256 / 384 k-mers, block numbers of 21 bits: the builds with the offsets in LDS
+            if (a.multi_reads && a.multi_tiles && a.col_begin == 0 && (a.col_end == 3 || a.col_end == 4) && a.f.stride == 4) {
+                if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
+                dim3 g1(a.n_reads);
+#define RB_LAUNCH_MULTI4(INV, TT)                                                                                                       \
+    hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, INV, TT, 4>), g1, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, \
+                       a.out_read_stride, a.narrow)
+                if (a.multi_tiles == 6 && a.multi_inv) RB_LAUNCH_MULTI4(true, 6);
+                else if (a.multi_tiles == 6) RB_LAUNCH_MULTI4(false, 6);
+                else if (a.multi_inv) RB_LAUNCH_MULTI4(true, 4);
+                else RB_LAUNCH_MULTI4(false, 4);
+#undef RB_LAUNCH_MULTI4
+                return hipGetLastError();
+            }
             if ((a.short_only == 4 || a.short_only == 5) && a.col_begin == 0 && (a.col_end == 3 || a.col_end == 4) && a.f.stride == 4) {
                 dim3 grid((a.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
                 // short_only 5: every read of the batch has at most 256 k-mers: one round of four tiles per strand; three-word blocks

@@ -269,14 +269,39 @@ inline uint64_t phase_equal_slices_one_word_ticks(PhaseShape shape, uint32_t n_s
     return (uint64_t)(cycle / (double)std::max(n_slices, 1u));
 }
 
-// The builds of round 6 that keep a read's block numbers in LDS (rb_kernels.hip, ibf_count_max_phased_multi_kernel: two-word tables of up to
-// 32 MiB): the window of the shape's rule times this.  Four tiles (eight waves per SIMD where the register build had seven): the same
-// optimum -- 18.9 MiB in five slices, 250 bp: 990 ticks 8.72 ms, 1 045: 8.30, 1 100: 8.21, 1 155: 8.52.  Six tiles (seven waves where the
-// register build had four): the waves of a CU hold 1.6 x the lookups, a window has to serve them -- 360 bp: 1 030 ticks 14.66 ms, 1 133:
-// 13.70, 1 236: 12.28, 1 390: 13.02 (profiles/r06/multi/s13_six_tiles_sweep.txt).
-inline double phase_multi_window_factor(PhaseShape shape, uint32_t /*n_slices*/)
+// The builds of round 6 that keep a read's block numbers in LDS (rb_kernels.hip, ibf_count_max_phased_multi_kernel: two-word tables of
+// up to 32 MiB): more waves per SIMD than the register builds, so a CU's waves hold more lookups and a window has more to serve.  Where
+// that moves the optimum, the window is given here; elsewhere the shape's rule stands (`rule_ticks`).  K1 ms per 1 M reads,
+// profiles/r06/multi/ (s13_six_tiles_sweep.txt, s14_guard_first_run.txt, guard_two_word.txt):
+//  - four tiles (eight waves per SIMD; the register build had seven): the rule's windows hold -- 18.9 MiB in five slices of 4 MiB, 250 bp:
+//    990 ticks 8.72, 1 100: 8.21, 1 155: 8.52; 28 MiB, seven slices: 814 ticks 10.08, 976: 9.70 -- except for up to five slices of 2 MiB:
+//    8 MiB, 250 bp: 500 ticks 7.60, 550: 6.92, 600: 6.83, 675: 6.78, 750: 6.97;
+//  - six tiles (seven waves where the register build had four): a cliff on the short side -- 19 MiB, five slices of 4 MiB, 360 bp: 988 ticks
+//    13.85, 1 236: 12.81, 1 359: 12.94; 28 MiB, seven slices: 840 ticks 18.18, 934: 13.46, 1 027: 14.06; 30 MiB, eight slices, 300 bp: 695
+//    ticks 17.45, 764: 12.21, 834: 12.97 -- a whole cycle of 6 700 ticks, NOT scaled with the reads' fill (a wave walks all twelve slots of
+//    a lane whatever the read's length); slices of 2 MiB: 13 MiB, seven slices, 300 bp: 480 ticks 11.92, 576: 9.58, 648: 9.90; 8 MiB, four
+//    slices, 360 bp: 576 ticks 10.52, 648: 9.91, 720: 9.27.
+inline uint64_t phase_multi_window_ticks(PhaseShape shape, uint32_t slice_log2, uint32_t n_slices, uint32_t kmers, uint64_t rule_ticks)
 {
-    return shape == PhaseShape::SixTiles ? 1.2 : 1.0;
+    const uint32_t n = std::max(n_slices, 1u);
+    if (shape == PhaseShape::SixTiles) {
+        if (slice_log2 >= 22) return std::max<uint64_t>(rule_ticks, 6700u / n);
+        if (slice_log2 == 21) return std::max<uint64_t>(rule_ticks, 350u + 1700u / n);
+        return rule_ticks + rule_ticks / 2;
+    }
+    if (shape == PhaseShape::FourTiles && slice_log2 == 21 && n <= 5) {
+        const double fill = phase_fill(shape, kmers);
+        return std::max<uint64_t>(rule_ticks, (uint64_t)(620.0 * (0.5 + 0.5 * fill)));
+    }
+    // blocks of three and four words (five waves per SIMD where the register build had four; reads of 257-384 k-mers in ONE round of six
+    // tiles where it takes two rounds of three): README shape, 37.7 MiB in eight equal slices -- 250 bp: 500 ticks 18.23 ms, 550: 15.54,
+    // 600: 13.07, 675: 13.93 (register build: 14.82 at 500); 360 bp: 630 ticks 27.52, 735: 19.84, 840: 20.78 (register build: 22.18 at 378)
+    if (phase_shape_is_wide(shape) && slice_log2 >= 22) {
+        const bool six = shape == PhaseShape::WideRounds || shape == PhaseShape::Wide3Rounds;
+        return std::max<uint64_t>(rule_ticks, (six ? 6080u : 4960u) / n);
+    }
+    if (phase_shape_is_wide(shape)) return rule_ticks + rule_ticks / 5;
+    return rule_ticks;
 }
 
 // from which table size on the phased form pays ...

@@ -733,6 +733,10 @@ int main(int argc, char const* argv[])
         else if (!std::strcmp(argv[i], "--ingest-threads") && i + 1 < argc) opt.threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--classify-threads") && i + 1 < argc) opt.classify_threads = (unsigned)std::max(1, std::stoi(argv[++i]));
         else if (!std::strcmp(argv[i], "--calibrate")) opt.calibrate = true;
+        // tables of 1 GiB and more are placed by trial (up to five allocations probed, 1-2 s at load time): 1 switches it off
+        else if (!std::strcmp(argv[i], "--placement-tries") && i + 1 < argc) {
+            if (rb_set_placement_tries(std::stoi(argv[++i])) != RB_OK) { std::cerr << "ERROR: --placement-tries 0 .. 8" << std::endl; return 1; }
+        }
         else if (!std::strcmp(argv[i], "--revcomp-of-n") && i + 1 < argc) interleave::set_revcomp_of_n((uint32_t)std::stoul(argv[++i]));
         else if (!std::strcmp(argv[i], "--mmap-output")) opt.mmap_output = true;
         else if (!std::strcmp(argv[i], "--no-mmap-output")) opt.mmap_output = false;
@@ -763,7 +767,7 @@ int main(int argc, char const* argv[])
             return 0;
         }
         else if (!std::strcmp(argv[i], "--help") || !std::strcmp(argv[i], "-h")) {
-            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] [--calibrate] [--revcomp-of-n 3|4] "
+            std::cout << "readbouncer_amd --config <file.toml> [--dump-config] [--batch-reads N] [--ingest-threads N] [--classify-threads N] [--segment-mb N] [--mmap-output] [--calibrate] [--placement-tries N] [--revcomp-of-n 3|4] "
                          "[--devices 0,1,...] [--parse-stats file]\n"
                          "readbouncer_amd --verify-ibf <file.ibf> --reference <file.fasta> [--fragment-size N]" << std::endl;
             return 0;

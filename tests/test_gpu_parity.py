@@ -1746,10 +1746,15 @@ def test_pool_replicas_of_a_large_filter_started_side_by_side():
     assert r.returncode == 0 and "side by side ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("widths,n_blocks", [((100,), 2053), ((128,), 4096), ((65,), 30011), ((60, 50), 30011), ((43, 29, 49), 30011), ((64, 64), 8192)])
+@pytest.mark.parametrize("widths,n_blocks", [((100,), 2053), ((128,), 4096), ((65,), 30011), ((60, 50), 30011), ((43, 29, 49), 30011), ((64, 64), 8192),
+                                             # blocks of three and four words (stride 4): filters on their own, the README shape's packed table, a triple
+                                             ((130,), 2053), ((256,), 4096), ((200,), 30011), ((122, 43, 29, 49), 30011), ((100, 60, 30), 30011),
+                                             ((64, 64, 64, 64), 8192),
+                                             # one-word blocks (a filter of up to 64 bins on its own)
+                                             ((40,), 4099), ((64,), 4096)])
 def test_several_reads_per_wave_match_oracle(widths, n_blocks):
     """Round 6: the builds of the phased kernel that keep a read's block numbers packed in LDS and carry one or two reads per wave
-    through a pass of the windows (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- two-word blocks, reads of up to
+    through a pass of the windows (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- blocks of two, three and four words, reads of up to
     256 k-mers (four tiles per strand) and up to 384 (six tiles).
     Raw maxima against the oracle and decisions against the one-read build: a filter on its own (Barrett and mask modulus) and merged
     pairs / triples of small targets, odd batch sizes (the last wave has a read too few), empty / short / all-N reads, windows from
@@ -1788,7 +1793,7 @@ def test_several_reads_per_wave_match_oracle(widths, n_blocks):
                 eng.set_phase_slices(1, max_slices)
                 pl = eng.plan(0, len(lens), int(lens.max()))
                 assert pl["kernel"] == ("ibf_count_max_phased_multi_kernel" if reads_per_wave else "ibf_count_max_phased_kernel"), pl
-                assert pl["block_words"] == 2 and pl["reserved0"] == (reads_per_wave & 3)
+                assert pl["block_words"] == (sum(widths) + 63) // 64 and pl["reserved0"] == (reads_per_wave & 3)
                 got = eng.classify(buf, offs, lens)
                 assert np.array_equal(got[0], exp), (reads_per_wave, base_ticks, max_slices)
                 if base is None:

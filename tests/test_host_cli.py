@@ -206,9 +206,16 @@ def test_config1_build_and_classify(tmp_path, refdata):
     out = tmp_path / "RB_out"
     cfg = tmp_path / "build.toml"
     write_config(cfg, "build", out, kmer_size=13, fragment_size=100000, target_files=[ref])
-    run_cli("--config", str(cfg))
+    built = run_cli("--config", str(cfg), "--placement-tries", "1")
     ibf = out / "ecoli_like.ibf"
     assert ibf.exists()
+    # where the build's time went (profiles/cli_build.py reads this line at genome scale): every stage named, the totals consistent
+    phases = [l for l in built.stdout.splitlines() if l.startswith("BUILD_PHASES")]
+    assert len(phases) == 1
+    kv = dict(x.split("=", 1) for x in phases[0].split()[1:])
+    assert int(kv["bins"]) == 63 and int(kv["bases"]) == 6_299_999
+    stages = [float(kv[k]) for k in ("load_seq_s", "alloc_filter_s", "concat_s", "insert_s", "save_s")]
+    assert all(x >= 0.0 for x in stages) and float(kv["parse_s"]) > 0.0 and sum(stages) <= float(kv["create_filter_s"]) * 1.001
     # byte-identical to the oracle's restatement of create_filter + store
     o = H.build_filter_like_reference([genome], k=13, fragment_length=100000)
     assert o.n_bins == 63 and o.bin_width == 1  # 6 299 999 bases after cutOutNNNs' dropped base: 62 + 1 bins

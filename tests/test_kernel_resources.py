@@ -27,12 +27,16 @@ EXPECT = {
     "ibf_count_max_phased_kernel<2,10,2,3>": 5,
     "ibf_count_max_phased_kernel<2,10,2,4>": 4,
     "ibf_count_max_merged_kernel<3,10,0>": 4,
-    # round 6: two-word blocks with the offsets packed in LDS (<reads per wave, OR form over a complemented copy, tiles per strand>)
-    "ibf_count_max_phased_multi_kernel<1,1,4>": 8,   # merged pairs / triples of small targets, <= 256 k-mers (50 registers)
-    "ibf_count_max_phased_multi_kernel<1,0,4>": 8,   # a two-word filter on its own
-    "ibf_count_max_phased_multi_kernel<1,1,6>": 7,   # <= 384 k-mers: 360 bp prefixes (69 registers; the register build: 112, four waves)
-    "ibf_count_max_phased_multi_kernel<1,0,6>": 7,
-    "ibf_count_max_phased_multi_kernel<2,1,4>": 5,   # two reads per wave (91 registers): measured, not the default
+    # round 6: the builds with a read's block numbers packed in LDS <reads per wave, OR form over a complemented copy, tiles per strand, words per block>
+    "ibf_count_max_phased_multi_kernel<1,1,4,2>": 8,   # merged pairs / triples of small targets, <= 256 k-mers (50 registers)
+    "ibf_count_max_phased_multi_kernel<1,0,4,2>": 8,   # a two-word filter on its own
+    "ibf_count_max_phased_multi_kernel<1,1,6,2>": 7,   # <= 384 k-mers: 360 bp prefixes (69 registers; the register build: 112, four waves)
+    "ibf_count_max_phased_multi_kernel<1,0,6,2>": 7,
+    "ibf_count_max_phased_multi_kernel<2,1,4,2>": 5,   # two reads per wave (91 registers): measured, not the default
+    "ibf_count_max_phased_multi_kernel<1,1,4,4>": 5,   # four-word blocks: the README shape's packed table (92 registers; register build: 116, four waves)
+    "ibf_count_max_phased_multi_kernel<1,1,6,4>": 4,   # ... one round of six tiles where the register build takes two rounds of three
+    "ibf_count_max_phased_multi_kernel<1,0,4,1>": 8,   # one-word blocks
+    "ibf_count_max_phased_multi_kernel<1,0,6,1>": 7,
 }
 
 
