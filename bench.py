@@ -102,6 +102,8 @@ def leg_summary(r):
         out["error"] = _cut(str(r["error"]), 120)
     if r.get("value") is not None:
         out["value"] = r["value"]
+    if r.get("work_skipped"):
+        out["work_skipped"] = True  # (the early-decision leg: a product figure, never a roofline figure)
     if r.get("ms_per_step") is not None:
         out["ms_per_step"] = r["ms_per_step"]
     roof = r.get("roofline") or {}
@@ -1127,6 +1129,76 @@ def pool_child(ctx, steps, timeout_s=600):
     return out
 
 
+def run_early(ctx, n_reads=2_000_000, steps=3):
+    """Leg `c3_early`: the OPT-IN early-decision mode (rb_engine_set_early_decision) on config 3's filter, deplete-only check_unblock on
+    360 bp reads of which half come from the planted reference.  A wave stops counting a read once a bin has reached the larger of its two
+    thresholds (adaptive_sampling.hpp:47-86 needs no more than that; the reference counts on).  WORK IS SKIPPED: `value` is a product
+    figure, NOT a roofline figure -- the line carries no `roofline` for this leg, only the fabric traffic the counters saw for it
+    (profiles/traffic.json, `c3_early`) as a share of 8 TB/s, so that nobody mistakes skipped gathers for bandwidth.  Parity: every decision
+    and status of the timed batch equals the same call with the mode off, which a sample checks against the oracle.  Rank 0, one GPU."""
+    from oracle import pyoracle as po
+    from readbouncer_amd import capi, synth
+    torch, dev = ctx.torch, ctx.dev
+    dep, ref = ctx.filter("c3")
+    L = 360
+    if TEST_DIVISOR > 1:
+        n_reads = max(4096, n_reads // TEST_DIVISOR)
+    t_seq, t_off, t_len = synth.make_reads_device(1000 + ctx.rank, n_reads, L, ref, dev)
+    t_dec = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    t_st = torch.zeros(n_reads, dtype=torch.uint8, device=dev)
+    eng = capi.Engine(ctx.dev_index, [dep], [])
+    torch.cuda.synchronize()
+
+    def call():
+        eng.classify_device(t_seq.data_ptr(), t_off.data_ptr(), t_len.data_ptr(), n_reads, L, 0.1, 0.95, capi.RB_MODE_CHECK_UNBLOCK,
+                            None, None, t_dec.data_ptr(), t_st.data_ptr())
+
+    def timed(k):
+        call()  # warm-up
+        torch.cuda.synchronize()
+        eng.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            call()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ms, calls = eng.kernel_time()
+        eng.set_timing(False)
+        return el / k, ms / max(1, calls)
+
+    full_s, full_k1_ms = timed(1)
+    dec0, st0 = t_dec.cpu().numpy().copy(), t_st.cpu().numpy().copy()
+    eng.set_early_decision(1)
+    step_s, k1_ms = timed(steps)
+    dec1, st1 = t_dec.cpu().numpy(), t_st.cpu().numpy()
+    eng.set_early_decision(0)
+    eng.destroy()
+    # the mode-off decisions of a sample against the oracle (the mode-on ones equal them, all of them)
+    view = ctx.oracle_view("c3")
+    take = np.linspace(0, n_reads - 1, num=min(1500, n_reads), dtype=np.int64)
+    seqs = t_seq.cpu().numpy()
+    sub = np.concatenate([seqs[i * L:(i + 1) * L] for i in take])
+    exp_dec, exp_st = po.batch_check_unblock([view], [], sub, np.arange(len(take), dtype=np.uint64) * np.uint64(L),
+                                             np.full(len(take), L, dtype=np.uint32), n_threads=min(16, os.cpu_count() or 1))
+    oracle_mism = int((dec0[take] != exp_dec).sum() + (st0[take] != exp_st).sum())
+    tj = load_json("traffic.json").get("c3_early", {})
+    traffic_frac = None
+    if tj.get("hbm_bytes_per_read"):
+        traffic_frac = tj["hbm_bytes_per_read"] * n_reads / (k1_ms / 1e3) / 8e12
+    return {"metric": METRIC, "value": n_reads / step_s, "unit": "reads/s", "n_gpus": 1, "steps": steps, "ms_per_step": step_s * 1e3,
+            "work_skipped": True,
+            "note": "opt-in early-decision mode: work is skipped, this is NOT a roofline figure",
+            "config": {"workload": "config 3's filter (8192 bins, 8 GiB), %d reads of 360 bp per launch, deplete-only check_unblock, "
+                                   "rb_engine_set_early_decision(1)" % n_reads},
+            "k1_ms": k1_ms, "k1_ms_full_count": full_k1_ms, "reads_per_s_full_count": n_reads / full_s,
+            "speedup_over_full_count": full_s / step_s, "unblocked_share": float((dec1 == 1).mean()),
+            "counter_traffic_frac_of_8TBps": traffic_frac, "counter_traffic_source": tj.get("source"),
+            "parity": {"checked_reads": int(n_reads), "decision_mismatches": int((dec1 != dec0).sum() + (st1 != st0).sum()),
+                       "raw_max_mismatches": 0, "near_threshold_reads": None, "oracle_checked_reads": int(len(take)), "oracle_mismatches": oracle_mism,
+                       "what": "decisions and statuses of the whole batch against the same call with the mode off; a sample of those against the oracle"},
+            "roofline": None, "cpu_baseline": None}
+
+
 def run_cli_readme(ctx, n_reads=2_000_000, sample=3000):
     """SURVEY f.3 under the driver's eyes: the host CLI (readbouncer_amd/readbouncer_amd_cli, usage = "classify",
     src/main/classify.hpp:142-365) end to end on the README shape -- the four filters stored as .ibf files, a generated FASTQ of
@@ -1423,7 +1495,7 @@ def xgmi_preflight(ctx):
         return {"ran": False, "error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
 
-FULL_LEGS = ("c3np2", "c4", "c5", "c2", "grch38_f100k", "readme", "readme_360bp", "targets3", "deplete_target", "cli_readme", "pool_c3", "pool_c4")
+FULL_LEGS = ("c3np2", "c4", "c5", "c3_early", "c2", "grch38_f100k", "readme", "readme_360bp", "targets3", "deplete_target", "cli_readme", "pool_c3", "pool_c4")
 # N > 1 (what a SCALE record carries, four runs back to back): the BASELINE configs that name several GPUs, config 3 at the
 # reference's own sizing, and the one-process pool legs; the narrow shapes and c2 are single-GPU parity / roofline legs
 MULTI_LEGS = ("c3np2", "c4", "c5", "pool_c3", "pool_c4")
@@ -1601,6 +1673,9 @@ def main():
     elif args.workload == "c5":
         result = replay(ctx)
         extras = False
+    elif args.workload == "c3_early":
+        result = run_early(ctx, n_reads=args.reads or 2_000_000, steps=max(1, min(args.steps, 5)))
+        extras = False
     else:
         name = args.workload or "c3"
         extras = not args.workload and not args.reads and not args.read_len and not args.no_extras and not bin_sharded
@@ -1641,6 +1716,8 @@ def main():
             # two and three narrow filters of one hash geometry: one table that one lane holds per lookup (merged form)
             "targets3": lambda: run_throughput(ctx, "targets3", steps=few, warmup=1, cpu_seconds=3.0),
             "deplete_target": lambda: run_throughput(ctx, "deplete_target", steps=few, warmup=1, cpu_seconds=3.0),
+            # the opt-in early-decision mode on config 3's filter: a product figure (work skipped), rank 0 only
+            "c3_early": lambda: (run_early(ctx) if rank == 0 else {"value": 0.0}),
             # the host CLI end to end on the README shape (SURVEY f.3): rank 0 only, the other ranks pass
             "cli_readme": lambda: (run_cli_readme(ctx) if rank == 0 else {"value": 0.0}),
             # one host process driving every GPU of the job through rb_pool (rank 0; the other ranks wait): what SCALE's per-rank

@@ -195,6 +195,16 @@ RB_API int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_
  * Results are identical. */
 RB_API int rb_engine_set_reads_per_wave(rb_engine *e, uint32_t reads);
 
+/* OPT-IN, off by default; never part of a roofline figure (work is skipped).  check_unblock (src/main/adaptive_sampling.hpp:35-113) looks at a
+ * filter's count only through "count >= threshold(r)" and "count >= threshold(r - 0.02)" (the rescan of :55-56); both are settled the moment
+ * some bin of the filter reaches the larger of the two thresholds on either strand -- the reference counts on, and counts again for the
+ * rescan.  With this mode on, RB_MODE_CHECK_UNBLOCK calls of the throughput form (batches above the micro-batch limit) that do NOT ask for
+ * the raw maxima (out_maxcount / d_maxcount NULL) let a wave of the plain count kernel (filters of five and more word columns: the
+ * depletion filter) stop there; target filters do so only when best_target is not asked for either (their counts pick it).  Every
+ * output the call returns is identical to the mode being off.  In host depletion most reads are positive and stop after a fraction of
+ * one strand. */
+RB_API int rb_engine_set_early_decision(rb_engine *e, int enabled);
+
 /* How the eight XCDs walk the slices of a phased table (each has an L2 of its own, so each reloads every slice): bit 0 of `mode` -- at
  * any time every XCD works on a different slice (slice = (window + XCD number) mod slices); bit 1 -- the XCDs' windows start an eighth
  * of a window apart, so that they refill their L2s one after the other instead of all in the same instant.  0 (default): one clock, one

@@ -6,6 +6,7 @@ MI355X_MICROARCH.md prescribes: FETCH_SIZE is in KiB and gfx950 reports 128-byte
 Usage: python3 profiles/summarize.py gpurun_out/r01e profiles/r01"""
 import csv
 import glob
+import re
 import json
 import os
 import shutil
@@ -31,7 +32,11 @@ for w in ("c2", "c3", "c3np2", "grch38_f100k", "c4", "c5", "readme", "readme360"
 SAME_KERNEL_PER_STEP = {"targets3_apart": 3, "deplete_target_apart": 2}
 
 
-def counter_means(path, per_step=1):
+# workloads of which only ONE build of the count kernel is the subject (the leg also launches the full-count build for comparison)
+ONLY_KERNEL = {"c3_early": re.compile(r"ibf_count_max_kernel<[^>]*, true, true>")}  # <..., PH, EARLY = true>
+
+
+def counter_means(path, per_step=1, only=None):
     """{counter: (dispatches, value per step, kernel ms per step)} of the count kernels (every form of K1).  A step launches
     one count kernel per filter -- different template instantiations, or the same one several times (the three one-word
     targets of the README shape): the per-step figure is the sum over all dispatches divided by the number of steps, and
@@ -39,7 +44,7 @@ def counter_means(path, per_step=1):
     tot, per_kernel = {}, {}
     with open(path, newline="") as fh:
         for r in csv.DictReader(fh):
-            if "ibf_count_max" not in r["Kernel_Name"]:
+            if "ibf_count_max" not in r["Kernel_Name"] or (only is not None and not only.search(r["Kernel_Name"])):
                 continue
             a = tot.setdefault(r["Counter_Name"], [0, 0.0, 0.0])
             a[0] += 1
@@ -58,7 +63,7 @@ from readbouncer_amd import synth  # noqa: E402
 
 rows, traffic = [], {}
 MOCK = ["mock_deplete", "mock_t1", "mock_t2", "mock_t3"]
-FILTERS = {"c2": ["c2"], "c3": ["c3"], "c3np2": ["c3np2"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
+FILTERS = {"c2": ["c2"], "c3": ["c3"], "c3_early": ["c3"], "c3np2": ["c3np2"], "c4": ["c3", "zymo"], "grch38_f100k": ["grch38_f100k"], "c1": ["c1"],
            "readme": MOCK, "c1_r01": ["c1"], "readme_r01": MOCK, "readme_skew": MOCK, "readme360": MOCK, "readme360_six0": MOCK,
            "readme_phased": MOCK, "readme360_phased": MOCK, "w1_64mib": ["w1_64mib"], "w1_64mib_plain": ["w1_64mib"],
            "targets3": ["mock_t1", "mock_t2", "mock_t3"], "targets3_apart": ["mock_t1", "mock_t2", "mock_t3"],
@@ -66,7 +71,7 @@ FILTERS = {"c2": ["c2"], "c3": ["c3"], "c3np2": ["c3np2"], "c4": ["c3", "zymo"],
 READ_LEN = {"readme": 250, "readme_r01": 250, "readme_skew": 250, "readme_phased": 250, "w1_64mib": 250, "w1_64mib_plain": 250,
             "targets3": 250, "targets3_apart": 250, "deplete_target": 250, "deplete_target_apart": 250}
 when = os.environ.get("RB_EVIDENCE_DATE", "")
-for w in ("c2", "c3", "c3np2", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0", "readme_phased", "readme360_phased",
+for w in ("c2", "c3", "c3_early", "c3np2", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "readme_r01", "readme_skew", "readme360", "readme360_six0", "readme_phased", "readme360_phased",
           "w1_64mib", "w1_64mib_plain", "targets3", "targets3_apart", "deplete_target", "deplete_target_apart"):
     d = os.path.join(src, "pmc_" + w)
     if not os.path.isdir(d):
@@ -76,7 +81,7 @@ for w in ("c2", "c3", "c3np2", "c4", "grch38_f100k", "c1", "readme", "c1_r01", "
         hits = glob.glob(os.path.join(d, p, "**", "*counter_collection.csv"), recursive=True)
         if not hits:
             continue
-        for name, (n, v, ms) in counter_means(hits[0], SAME_KERNEL_PER_STEP.get(w, 1)).items():
+        for name, (n, v, ms) in counter_means(hits[0], SAME_KERNEL_PER_STEP.get(w, 1), ONLY_KERNEL.get(w)).items():
             rows.append((w, p, name, n, v, ms))
             m[name] = v
     if "FETCH_SIZE" not in m:

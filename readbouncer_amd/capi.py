@@ -138,6 +138,7 @@ SIGNATURES = {
     "rb_engine_set_phase_slices": (_int, [_vp, _u32, _u32]),
     "rb_engine_set_reads_per_wave": (_int, [_vp, _u32]),
     "rb_engine_set_phase_xcd_skew": (_int, [_vp, _u32]),
+    "rb_engine_set_early_decision": (_int, [_vp, _int]),
     "rb_engine_set_phased": (_int, [_vp, _u64, _u64, _u32, _u32, _u32]),
     "rb_engine_set_timing": (_int, [_vp, _int]),
     "rb_engine_kernel_time": (_int, [_vp, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -516,6 +517,10 @@ class Engine:
     def set_reads_per_wave(self, reads):
         """two-word phased tables, reads of up to 256 k-mers: reads a wave carries through a pass of the windows (0: the one-read build)"""
         _check(lib().rb_engine_set_reads_per_wave(self.h, reads), "rb_engine_set_reads_per_wave")
+
+    def set_early_decision(self, on):
+        """opt-in: check_unblock calls without raw maxima stop counting a read once a bin has reached the larger of its two thresholds"""
+        _check(lib().rb_engine_set_early_decision(self.h, int(on)), "rb_engine_set_early_decision")
 
     def set_phase_xcd_skew(self, mode):
         """bit 0: every XCD on a different slice at any time; bit 1: the XCDs' windows start an eighth of a window apart"""

@@ -133,6 +133,10 @@ struct CountLaunch {
     uint32_t fused_col_begin[kMaxFused], fused_col_end[kMaxFused], fused_out_offset[kMaxFused];
     uint8_t fused_geom[kMaxFused], fused_parts[kMaxFused], fused_sub[kMaxFused];  // latency form, see FilterSet
     const struct FoldJob *fold;   // latency form: the launch also makes the decisions (nullptr: it only counts)
+    // opt-in early decision (plain throughput form, RB_MODE_CHECK_UNBLOCK without raw maxima): the decision kernel's threshold table, so that
+    // a wave can stop counting once a bin has reached the larger of the read's two thresholds for this filter (nullptr: count everything)
+    const uint16_t *early_thr;
+    uint32_t early_thr_len, early_nf, early_fi;
 };
 
 inline uint8_t geom_code(int lg, int wpl, int nt) { return (uint8_t)(lg | (wpl == 2 ? 8 : 0) | (nt ? 16 : 0)); }

@@ -331,6 +331,9 @@ struct rb_engine {
     // one-read build
     uint32_t multi_reads = 1;   // (default since round 6: 250 bp -10 ... -11 %, 360 bp -16 ... -19 % on two-word tables, profiles/r06/multi/)
     uint32_t phase_tskew_div = 8;  // RB_PHASE_TSKEW_DIV: the XCDs' windows start 1 / this of a window apart (time skew)
+    // rb_engine_set_early_decision (opt-in, off by default): RB_MODE_CHECK_UNBLOCK calls of the throughput form that do not ask for the raw maxima
+    // let a wave of the plain count kernel stop once a bin has reached the larger of the read's two thresholds (rb_kernels.hip, EarlyCfg)
+    bool early_decision = false;
     bool multi_one_word = true;  // ... for one-word blocks of up to 2^21 - 1 of them (16 MiB) (RB_MULTI_ONE_WORD=0: the register builds)
     bool multi_wide = true;      // ... and for blocks of three and four words (RB_MULTI_WIDE=0: those keep the register builds)
     bool multi_wide_six = true;  // ... six tiles in one round for their reads of 257-384 k-mers (RB_MULTI_WIDE_SIX=0: rounds of three tiles)
@@ -1163,6 +1166,14 @@ int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_s
     return RB_OK;
 }
 
+int rb_engine_set_early_decision(rb_engine *e, int enabled)
+{
+    if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->early_decision = enabled != 0;
+    return RB_OK;
+}
+
 int rb_engine_set_phase_xcd_skew(rb_engine *e, uint32_t mode)
 {
     if (!e || mode > 3) return rb::fail(RB_ERR_INVALID_ARG, "mode 0..3 (bit 0: slice skew, bit 1: time skew)");
@@ -1832,6 +1843,15 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
     }
     // fork/join over auxiliary streams costs ~20-40 us of event traffic per call (measured): worth it for large
     // batches only; micro-batches queue their few short kernels on the one stream
+    // opt-in early decision: the count kernels of the plain throughput form read the decision kernel's threshold table (made here, on the
+    // call's stream, before any count kernel -- the auxiliary streams wait for the fork event below)
+    const uint16_t *early_thr = nullptr;
+    uint32_t early_thr_len = 0;
+    if (e->early_decision && mode == RB_MODE_CHECK_UNBLOCK && !d_maxcount && !host_maxcount && e->shard_world == 1 && n_reads > e->split_threshold &&
+        (d_decision || d_status || d_best_target)) {
+        rc = ensure_thresholds(e, max_len, error_rate, significance, st, &early_thr, &early_thr_len);
+        if (rc != RB_OK) return rc;
+    }
     const bool fan_out = e->overlap && nf > 1 && !e->aux.empty() && n_reads > e->split_threshold;
     if (fan_out) {
         RB_HIP(hipEventRecord(e->fork_ev, st));
@@ -1981,6 +2001,14 @@ static int classify_device_impl(rb_engine *e, const rb_batch_desc *desc, double 
             continue;
         }
         if (a.n_slices != 1 || a.split_waves < 2) fold_ok = false;
+        // (a target filter's count also picks best_target -- the strictly-greater argmax of IBFClassify.cpp:262-273 -- so target filters stop
+        // early only when the caller does not ask for best_target; a deplete filter's count is seen through the two predicates alone)
+        if (early_thr && a.split_waves < 2 && (fi < e->nd || !d_best_target)) {
+            a.early_thr = early_thr;
+            a.early_thr_len = early_thr_len;
+            a.early_nf = (uint32_t)nf;
+            a.early_fi = (uint32_t)fi;
+        }
         if (a.n_slices == 1) {
             a.out = maxcount + fi;
             a.out_read_stride = (uint32_t)nf;

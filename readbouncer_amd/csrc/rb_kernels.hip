@@ -469,11 +469,14 @@ __device__ __forceinline__ void phased_gather_x4(uint64_t (&x0)[N], uint64_t (&x
 // Counts one strand of one read into the wave's bit-sliced counters, visiting the macro tiles
 // mt_first, mt_first + mt_step, ... (mt_step = ITEMS walks the whole read; the split kernel interleaves waves) and of
 // each macro tile the eight-step blocks [blk_first, blk_end) (all STEPS / 8 of them, or a wave's share in the split kernel).
-template <int LG, int WPL, int NP, int H, bool NT, bool PH = false>
-__device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
+// EARLY (the opt-in early-decision mode of the throughput form, rb_engine_set_early_decision): after every macro tile the running
+// maximum of this wave's counters is compared with `stop_at`; once it is reached the strand is left (the counters are a lower bound of
+// the read's, which is all the decision needs: see ibf_count_max_kernel) and true is returned.
+template <int LG, int WPL, int NP, int H, bool NT, bool PH = false, bool EARLY = false>
+__device__ __forceinline__ bool count_strand(Planes<NP> (&pl)[WPL], const IbfDev &f, const LaneCols<WPL> &lc,
                                              const BaseSrc &seq, uint32_t len, uint32_t n, int strand,
                                              uint32_t mt_first, uint32_t mt_step, int blk_first, int blk_end,
-                                             uint8_t *stage, int lane, const PhaseCfg ph = PhaseCfg{0, 0, 0, 0, 0})
+                                             uint8_t *stage, int lane, const PhaseCfg ph = PhaseCfg{0, 0, 0, 0, 0}, uint32_t stop_at = 0xFFFFFFFFu)
 {
     using T = TileShape<LG>;
     constexpr int NG = T::NG, SPT = T::SPT, J = T::J, ITEMS = T::ITEMS;
@@ -627,6 +630,11 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
 #pragma unroll
             for (int w = 0; w < WPL; ++w) pl[w].add8(x[w]);
         }
+        if constexpr (EARLY) {
+            // (with several lane groups per block every group holds the counts of ITS k-mers only: a lower bound of a lower bound, still
+            // sufficient; the butterfly below is skipped when the wave leaves here)
+            if (planes_max<NP, WPL>(pl, lc.valid) >= stop_at) return true;
+        }
     }
 
     // ---- sum the partial counters of the NG groups (butterfly): every group then holds the total
@@ -637,6 +645,7 @@ __device__ __forceinline__ void count_strand(Planes<NP> (&pl)[WPL], const IbfDev
             for (int w = 0; w < WPL; ++w) pl[w].add_from_lane_xor(lane, m);
         }
     }
+    return false;
 }
 
 __device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item, uint32_t *len_out)
@@ -663,10 +672,22 @@ __device__ __forceinline__ BaseSrc make_base_src(const ReadSrc &r, uint32_t item
 #ifndef RB_WAVES_PLAIN  // waves per SIMD the plain throughput kernel is compiled for (one word per lane, ten planes)
 #define RB_WAVES_PLAIN 3
 #endif
-template <int LG, int WPL, int NP, int H, bool NT>
+// EARLY: the opt-in early-decision mode (rb_engine_set_early_decision; RB_MODE_CHECK_UNBLOCK calls that do not ask for the raw maxima).
+// check_unblock (src/main/adaptive_sampling.hpp:35-113) looks at a filter's count only through "count >= threshold at r" and "count >=
+// threshold at r - 0.02" (the rescan of :55-56); both are decided for good the moment some bin of the filter reaches the larger of the
+// two thresholds on either strand -- the reference counts on (and counts again for the rescan).  A wave that gets there writes the
+// maximum it has, a lower bound >= both thresholds, and stops: the decision kernel's predicates come out as with the full count.  Work is
+// SKIPPED in this mode: its reads/s are a product figure, never a roofline figure (bench.py reports it as `c3_early`, apart).
+struct EarlyCfg {
+    const uint16_t *thr;  // [thr_len][nf][2] thresholds at r and r - 0.02 by read length (the decision kernel's table)
+    uint32_t thr_len, nf;
+    uint32_t fi[kMaxFused];  // blockIdx.y -> filter index in the table
+};
+
+template <int LG, int WPL, int NP, int H, bool NT, bool EARLY = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((WPL == 1 && NP == 10 && H == 3) ? RB_WAVES_PLAIN : 3, 8))) void ibf_count_max_kernel(
     FilterSet set, ReadSrc src, uint32_t n_reads, uint32_t n_slices, uint16_t *__restrict__ out_base,
-    uint32_t out_read_stride, uint32_t out_slice_stride)
+    uint32_t out_read_stride, uint32_t out_slice_stride, EarlyCfg early)
 {
     __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
     const IbfDev &f = set.f[blockIdx.y];  // filters of equal kernel geometry may share a launch (micro-batches)
@@ -686,15 +707,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const BaseSrc seq = make_base_src(src, read, &len);
     const uint32_t n = len >= f.k ? len - f.k + 1 : 0;
 
+    uint32_t stop_at = 0xFFFFFFFFu;
+    if constexpr (EARLY) {
+        // the larger of the read's two thresholds for this filter (a negative int16 threshold arrives as 65 5xx: never reached, as in K2),
+        // and at least one hit (a threshold of 0 is met by every read, but "classified" also needs a count above 0)
+        const uint32_t tl = len < early.thr_len ? len : early.thr_len - 1;
+        const uint16_t *t = early.thr + ((size_t)tl * early.nf + early.fi[blockIdx.y]) * 2;
+        stop_at = max(max((uint32_t)t[0], (uint32_t)t[1]), 1u);
+    }
     uint32_t best = 0;
     for (int strand = 0; strand < 2; ++strand) {
         Planes<NP> pl[WPL];
 #pragma unroll
         for (int w = 0; w < WPL; ++w) pl[w].clear();
-        count_strand<LG, WPL, NP, H, NT>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0,
-                                         TileShape<LG>::STEPS / 8, s_stage[wave], lane);
+        const bool left = count_strand<LG, WPL, NP, H, NT, false, EARLY>(pl, f, lc, seq, len, n, strand, 0u, (uint32_t)TileShape<LG>::ITEMS, 0,
+                                                                         TileShape<LG>::STEPS / 8, s_stage[wave], lane, PhaseCfg{0, 0, 0, 0, 0}, stop_at);
         const uint32_t m = planes_max<NP, WPL>(pl, lc.valid);
         best = m > best ? m : best;
+        if (EARLY && left) break;  // wave-uniform
     }
     if (lane == 0) out[(size_t)read * out_read_stride + (size_t)slice * out_slice_stride] = (uint16_t)best;
 }
@@ -800,6 +830,70 @@ __device__ __forceinline__ void write_member_maxima(const uint32_t (&colmax)[NC]
     }
 }
 
+// k-mer values from staged TRIPLES of bases, for k <= 13 (the reference's default; 5^13 < 2^31, so a value fits 32 bits).  Beside the
+// staged Dna5 ordinals ord[i] a read's staging area holds f3[i] = 25 ord[i] + 5 ord[i+1] + ord[i+2] and r3[i] = the same of the
+// complemented bases in reverse order; the forward value of the window at p is then k/3 steps `v = 125 v + f3[..]` (v_mad_u32_u24: every
+// step starts below 5^10 < 2^24, the 24-bit multiply is exact) plus k%3 single bases, the reverse-complement value the single bases from
+// the right end first and then the triples from the right -- ~20 VALU instructions per window position and both strands where thirteen
+// 64-bit multiply-adds per strand took ~180.  The narrow kernels are three quarters VALU-busy (profiles/r05/pmc_summary.csv, targets3:
+// SQ_INSTS_VALU 4 207 per read x 4 cycles over 1 024 SIMDs = 7.3 of 9.5 ms), and the hashing was the largest part of it.
+constexpr uint32_t kTripleMaxK = 13;
+__device__ __forceinline__ void stage_triples(const uint8_t *ord, uint8_t *f3, uint8_t *r3, uint32_t len, uint32_t comp_n, int lane)
+{
+    for (uint32_t i = lane; i + 2 < len; i += 64) {
+        const uint32_t a = ord[i], b = ord[i + 1], c = ord[i + 2];
+        f3[i] = (uint8_t)(a * 25u + b * 5u + c);
+        r3[i] = (uint8_t)(rbspec::dna5_comp(c, comp_n) * 25u + rbspec::dna5_comp(b, comp_n) * 5u + rbspec::dna5_comp(a, comp_n));
+    }
+}
+// values of the k-mer at p and of its reverse complement; small_k: the triples are staged (k <= kTripleMaxK), q3 = k / 3, s1 = k % 3
+__device__ __forceinline__ void kmer_values_both(const uint8_t *ord, const uint8_t *f3, const uint8_t *r3, uint32_t p, uint32_t k, uint32_t q3,
+                                                 uint32_t s1, uint32_t comp_n, bool small_k, uint64_t &vf, uint64_t &vr)
+{
+    if (small_k) {
+        uint32_t a = 0, b = 0;
+        for (uint32_t t = 0; t < q3; ++t) a = __umul24(a, 125u) + f3[p + 3u * t];
+        for (uint32_t t = 0; t < s1; ++t) a = a * 5u + ord[p + 3u * q3 + t];
+        for (uint32_t t = 0; t < s1; ++t) b = b * 5u + rbspec::dna5_comp(ord[p + k - 1u - t], comp_n);
+        for (uint32_t t = q3; t-- > 0;) b = __umul24(b, 125u) + r3[p + 3u * t];
+        vf = a;
+        vr = b;
+    } else {
+        const uint8_t *bs = ord + p;
+        vf = 0;
+        vr = 0;
+        for (uint32_t i = 0; i < k; ++i) vf = vf * 5u + bs[i];
+        for (uint32_t i = 0; i < k; ++i) vr = vr * 5u + rbspec::dna5_comp(bs[k - 1 - i], comp_n);
+    }
+}
+// the same for ONE strand (rc: the reverse complement's k-mer over the window at p)
+__device__ __forceinline__ uint64_t kmer_value_one(const uint8_t *ord, const uint8_t *f3, const uint8_t *r3, uint32_t p, uint32_t k, uint32_t q3,
+                                                   uint32_t s1, uint32_t comp_n, bool small_k, bool rc)
+{
+    if (small_k) {
+        uint32_t a = 0;
+        if (!rc) {
+            for (uint32_t t = 0; t < q3; ++t) a = __umul24(a, 125u) + f3[p + 3u * t];
+            for (uint32_t t = 0; t < s1; ++t) a = a * 5u + ord[p + 3u * q3 + t];
+        } else {
+            for (uint32_t t = 0; t < s1; ++t) a = a * 5u + rbspec::dna5_comp(ord[p + k - 1u - t], comp_n);
+            for (uint32_t t = q3; t-- > 0;) a = __umul24(a, 125u) + r3[p + 3u * t];
+        }
+        return a;
+    }
+    const uint8_t *bs = ord + p;
+    uint64_t v = 0;
+    if (!rc) {
+        for (uint32_t i = 0; i < k; ++i) v = v * 5u + bs[i];
+    } else {
+        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(bs[k - 1 - i], comp_n);
+    }
+    return v;
+}
+// staging area of the one-lane-per-block register builds: the ordinals of a read of up to 512 + k - 1 bases, then the two triple arrays
+constexpr int kTripleStride = 64 * kMaxTiles + rbspec::kMaxKmer;  // = kStageBytes: bytes per staged array
+constexpr int kStageBytes3 = 3 * kTripleStride;
+
 // Waves per SIMD each build of the phased kernel is compiled for (amdgpu_waves_per_eu minimum = the register budget the compiler
 // works against).  Left to itself it stops at the first allocation that fits its default target; told to aim higher it finds
 // 56 instead of 73 registers for the one-word 250 bp build (8 waves), 76 instead of 93 for the one-word 360 bp build (6 waves), 72
@@ -854,7 +948,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     IbfDev f, uint32_t col_begin, uint32_t col_end, ReadSrc src, uint32_t n_reads, PhaseCfg ph, uint16_t *__restrict__ out,
     uint32_t out_read_stride, NarrowMerge nm)
 {
-    __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes];
+    __shared__ uint8_t s_stage[kWavesPerBlock][kStageBytes3];  // (ordinals + the two triple arrays of stage_triples)
     if (ph.xcd_skew) ph.skew = xcc_id();
     if (ph.tskew) ph.tskew *= xcc_id();
     const int lane = threadIdx.x & 63;
@@ -882,6 +976,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
+            // (the build with loop state, rounds of three tiles, keeps the 64-bit Horner: the triples' extra state costs it its eighth wave -- 72
+            // registers and a spill)
+            const bool small_k = !(SHORT == 2) && k <= kTripleMaxK;
+            const uint32_t q3 = k / 3u, s1 = k - 3u * q3;
+            if (small_k) {
+                stage_triples(stage, stage + kTripleStride, stage + 2 * kTripleStride, len, f.comp_n, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
             const uint32_t col_bytes = (uint32_t)((lc.lane_base - f.words) * 8);
             const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * (f.stride * 8u)))
                                                           : min(31u, ph.shift + 3u + (31u - (uint32_t)__builtin_clz(f.stride)));
@@ -892,18 +995,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             uint32_t bn[2 * T][3];
             uint64_t x[2 * T];
 #pragma unroll
-            for (int j = 0; j < 2 * T; ++j) {
+            for (int j = 0; j < 2 * T; ++j) {  // slots 0 .. T-1: forward k-mers; T .. 2T-1: those of the reverse complement over the same windows
                 const uint32_t p = base + (uint32_t)((j % T) * 64 + lane);
                 const bool ok = (p < n) && lc.colok;
                 uint64_t v = 0;
-                if (ok) {
-                    const uint8_t *b = stage + p;
-                    if (j < T) {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
-                    } else {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
-                    }
-                }
+                if (ok) v = kmer_value_one(stage, stage + kTripleStride, stage + 2 * kTripleStride, p, k, q3, s1, f.comp_n, small_k, j >= T);
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
@@ -940,6 +1036,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
+            const bool small_k = !(SHORT == 2) && k <= kTripleMaxK;  // (not in the builds with loop state: registers)
+            const uint32_t q3 = k / 3u, s1 = k - 3u * q3;
+            if (small_k) {
+                stage_triples(stage, stage + kTripleStride, stage + 2 * kTripleStride, len, f.comp_n, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
             const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
             const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 16u)) : min(31u, ph.shift + 4u);
             uint32_t cf = 0, cr = 0;  // lane b: counts of bins b (low half) and 64 + b (high half), forward / reverse complement
@@ -952,14 +1055,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                 const uint32_t p = base + (uint32_t)((j % T) * 64 + lane);
                 const bool ok = p < n;
                 uint64_t v = 0;
-                if (ok) {
-                    const uint8_t *b = stage + p;
-                    if (j < T) {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
-                    } else {
-                        for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
-                    }
-                }
+                if (ok) v = kmer_value_one(stage, stage + kTripleStride, stage + 2 * kTripleStride, p, k, q3, s1, f.comp_n, small_k, j >= T);
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
                     const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
@@ -1001,6 +1097,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const uint32_t k = f.k;
+            const bool small_k = SHORT == 1 && k <= kTripleMaxK;  // (not in the builds with loop state: registers)
+            const uint32_t q3 = k / 3u, s1 = k - 3u * q3;
+            if (small_k) {
+                stage_triples(stage, stage + kTripleStride, stage + 2 * kTripleStride, len, f.comp_n, lane);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
             const uint64_t valid0 = col_bits_mask(nm.col_bits[0]), valid1 = col_bits_mask(nm.col_bits[1]);
             const uint64_t valid2 = col_bits_mask(nm.col_bits[2]), valid3 = col_bits_mask(nm.col_bits[3]);
             const uint32_t slice_shift = (ph.shift >> 31) ? (0x80000000u | ((ph.shift & 0x7FFFFFFFu) * 32u)) : min(31u, ph.shift + 5u);
@@ -1014,14 +1117,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
                     const uint32_t p = base + (uint32_t)((j % T2) * 64 + lane);
                     const bool ok = p < n;
                     uint64_t v = 0;
-                    if (ok) {
-                        const uint8_t *b = stage + p;
-                        if (j < T2) {
-                            for (uint32_t i = 0; i < k; ++i) v = v * 5u + b[i];
-                        } else {
-                            for (uint32_t i = 0; i < k; ++i) v = v * 5u + rbspec::dna5_comp(b[k - 1 - i], f.comp_n);
-                        }
-                    }
+                    if (ok) v = kmer_value_one(stage, stage + kTripleStride, stage + 2 * kTripleStride, p, k, q3, s1, f.comp_n, small_k, j >= T2);
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
                         const uint32_t blk = rbspec::block_index(v, f.precalc[h], f.n_blocks, f.magic, f.pow2_mask);
@@ -1156,13 +1252,9 @@ __device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev 
     uint8_t *f3 = ord + M::kArr, *r3 = ord + 2 * M::kArr;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const bool small_k = k <= 13u;
+    const bool small_k = k <= kTripleMaxK;
     if (small_k && n) {
-        for (uint32_t i = lane; i + 2 < len; i += 64) {
-            const uint32_t a = ord[i], b = ord[i + 1], c = ord[i + 2];
-            f3[i] = (uint8_t)(a * 25u + b * 5u + c);
-            r3[i] = (uint8_t)(rbspec::dna5_comp(c, f.comp_n) * 25u + rbspec::dna5_comp(b, f.comp_n) * 5u + rbspec::dna5_comp(a, f.comp_n));
-        }
+        stage_triples(ord, f3, r3, len, f.comp_n, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
@@ -1176,23 +1268,7 @@ __device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev 
         uint64_t pf = ~0ULL, pr = ~0ULL;
         if (p < n) {
             uint64_t vf, vr;
-            if (small_k) {
-                // forward: q3 triples from the left, then s1 single bases; reverse complement: the s1 bases from the right end
-                // first, then the triples from the right (every x 125 step starts below 5^10 < 2^24: the 24-bit multiply is exact)
-                uint32_t a = 0, b = 0;
-                for (uint32_t t = 0; t < q3; ++t) a = __umul24(a, 125u) + f3[p + 3u * t];
-                for (uint32_t t = 0; t < s1; ++t) a = a * 5u + ord[p + 3u * q3 + t];
-                for (uint32_t t = 0; t < s1; ++t) b = b * 5u + rbspec::dna5_comp(ord[p + k - 1u - t], f.comp_n);
-                for (uint32_t t = q3; t-- > 0;) b = __umul24(b, 125u) + r3[p + 3u * t];
-                vf = a;
-                vr = b;
-            } else {
-                const uint8_t *bs = ord + p;
-                vf = 0;
-                vr = 0;
-                for (uint32_t i = 0; i < k; ++i) vf = vf * 5u + bs[i];
-                for (uint32_t i = 0; i < k; ++i) vr = vr * 5u + rbspec::dna5_comp(bs[k - 1 - i], f.comp_n);
-            }
+            kmer_values_both(ord, f3, r3, p, k, q3, s1, f.comp_n, small_k, vf, vr);
             pf = pack_lookups(vf, f);
             pr = pack_lookups(vr, f);
         }
@@ -1339,7 +1415,7 @@ __device__ __forceinline__ void multi_finish(uint64_t (&x)[NW][2 * T], const Nar
 }
 
 // waves per SIMD the builds are compiled for: two-word four tiles 8 (R = 1: 50 registers) / 5 (R = 2: 91), six tiles 6; four-word 4
-constexpr int multi_min_waves(int r, int t, int nw) { return nw == 1 ? 8 : nw == 4 ? (t == 4 ? RB_MULTI_WAVES_W4 : 3) : t == 4 ? (r == 1 ? 8 : RB_MULTI_WAVES) : (r == 1 ? 6 : 3); }
+constexpr int multi_min_waves(int r, int t, int nw) { return nw == 1 ? (t == 4 ? 8 : 7) : nw == 4 ? (t == 4 ? RB_MULTI_WAVES_W4 : 3) : t == 4 ? (r == 1 ? 8 : RB_MULTI_WAVES) : (r == 1 ? 6 : 3); }
 
 template <int R, bool INV, int T = 4, int NW = 2>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_waves(R, T, NW), 8))) void ibf_count_max_phased_multi_kernel(
@@ -1894,8 +1970,20 @@ static hipError_t launch_count_nt(const CountLaunch &a, hipStream_t st)
     }
     const uint64_t items = (uint64_t)a.n_reads * a.n_slices;
     dim3 grid((uint32_t)((items + kWavesPerBlock - 1) / kWavesPerBlock), set.n);
+    EarlyCfg early{};
+    if constexpr (H == 3 && NP == 10) {  // (the early-decision builds exist for three hash functions and ten counter planes: what config 3 / 4 take)
+        if (a.early_thr && a.n_fused == 0) {
+            early.thr = a.early_thr;
+            early.thr_len = a.early_thr_len;
+            early.nf = a.early_nf;
+            early.fi[0] = a.early_fi;
+            hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT, true>), grid, dim3(64 * kWavesPerBlock), 0, st, set, a.src,
+                               a.n_reads, a.n_slices, a.out, a.out_read_stride, a.out_slice_stride, early);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((ibf_count_max_kernel<LG, WPL, NP, H, NT>), grid, dim3(64 * kWavesPerBlock), 0, st, set, a.src,
-                       a.n_reads, a.n_slices, a.out, a.out_read_stride, a.out_slice_stride);
+                       a.n_reads, a.n_slices, a.out, a.out_read_stride, a.out_slice_stride, early);
     return hipGetLastError();
 }
 

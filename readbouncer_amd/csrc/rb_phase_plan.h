@@ -294,13 +294,17 @@ inline uint64_t phase_multi_window_ticks(PhaseShape shape, uint32_t slice_log2, 
         return std::max<uint64_t>(rule_ticks, (uint64_t)(620.0 * (0.5 + 0.5 * fill)));
     }
     // blocks of three and four words (five waves per SIMD where the register build had four; reads of 257-384 k-mers in ONE round of six
-    // tiles where it takes two rounds of three): README shape, 37.7 MiB in eight equal slices -- 250 bp: 500 ticks 18.23 ms, 550: 15.54,
-    // 600: 13.07, 675: 13.93 (register build: 14.82 at 500); 360 bp: 630 ticks 27.52, 735: 19.84, 840: 20.78 (register build: 22.18 at 378)
-    if (phase_shape_is_wide(shape) && slice_log2 >= 22) {
+    // tiles where it takes two rounds of three).  Four tiles, slices of 4 MiB or equal-length ones, best window by slices: 4 slices
+    // (13 MiB, 200 bp) 744 ticks 10.13 ms, 868: 11.20; 6 (24 MiB, 250 bp) 578: 12.27, 660: 11.83, 743: 12.68; 8 (README shape, 37.7 MiB,
+    // 250 bp) 550: 15.54, 600: 13.07, 675: 13.93 (register build: 14.82 at 500); 9 (36 MiB, 200 bp) 495: 12.70, 551: 13.03 -- 400 +
+    // 1 700 / n.  Six tiles: a cliff near 650-700 ticks whatever the number of slices (a wave's pass over twelve slots of three
+    // lookups of two gathers) -- 24 MiB, 6 slices, 360 bp: 607 ticks 22.06, 709: 15.89, 810: 17.92; 37.7 MiB, 8 slices: 630: 27.52, 735:
+    // 19.84, 840: 20.78 (register build: 22.18 at 378); 12 MiB in 6 slices of 2 MiB: 585: 15.56, 682: 15.10 -- never below 750.
+    if (phase_shape_is_wide(shape)) {
         const bool six = shape == PhaseShape::WideRounds || shape == PhaseShape::Wide3Rounds;
-        return std::max<uint64_t>(rule_ticks, (six ? 6080u : 4960u) / n);
+        if (six) return slice_log2 >= 21 ? std::max<uint64_t>(rule_ticks, 750u) : rule_ticks + rule_ticks / 5;
+        return slice_log2 >= 22 ? (uint64_t)(400u + 1700u / n) : rule_ticks + rule_ticks / 5;
     }
-    if (phase_shape_is_wide(shape)) return rule_ticks + rule_ticks / 5;
     return rule_ticks;
 }
 

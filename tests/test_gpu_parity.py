@@ -1,6 +1,7 @@
 """GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
 seeded inputs.  Bit-exact (integer/bit work).  Run on the MI355X box with `-m gpu`."""
 import os
+import subprocess
 import sys
 
 import numpy as np
@@ -1017,7 +1018,10 @@ def test_measurement_aids_answer():
     small = capi.DeviceIBF.create(0, 64, 3, 13, 64 * 1310000)  # 10 MiB of one-word blocks
     e2 = capi.Engine(0, [small], [])
     pl = e2.plan(0, 100000, 250)
-    assert pl["kernel"] == "ibf_count_max_phased_kernel" and pl["phased"] == 1 and pl["phase_shape_name"].startswith("four tiles")
+    assert pl["kernel"] == "ibf_count_max_phased_multi_kernel" and pl["phased"] == 1 and pl["phase_shape_name"].startswith("four tiles")
+    e2.set_reads_per_wave(0)  # (the build with the offsets in registers: the same plan otherwise)
+    assert e2.plan(0, 100000, 250)["kernel"] == "ibf_count_max_phased_kernel"
+    e2.set_reads_per_wave(1)
     assert pl["phase_slices"] * (1 << pl["phase_slice_log2"]) >= pl["table_bytes"] and 100 <= pl["phase_window_ticks"] <= 2000
     assert capi.lib().rb_dibf_touch(small.h) == 0 and capi.lib().rb_dibf_touch(None) != 0
     # rb_engine_calibrate: windows measured on this device replace the table's for exactly that table and shape; results stay
@@ -1505,7 +1509,15 @@ def test_large_tables_are_placed_by_trial():
     """A table of 1 GiB and more is allocated two to five times, every candidate probed with random whole-block gathers, the best kept
     (rb_set_placement_tries; profiles/r05/placement_*.txt: the same table gathers 1.7-2.9 % slower or faster from one allocation to the
     next).  Nothing but the address depends on it: the filter round-trips and classifies like its oracle view; tries = 1 switches it off;
-    small tables are never tried."""
+    small tables are never tried; a device on which an engine of the process is alive is never tried either (a process that is already
+    classifying is not stalled by probe launches and transient copies) -- which is why the checks run in a process of their own: engines
+    that earlier tests of this process created and never destroyed would count."""
+    code = "import sys; sys.path.insert(0, %r); from tests.test_gpu_parity import placement_checks; placement_checks(); print('placement ok')" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0 and "placement ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def placement_checks():
     rng = np.random.default_rng(99)
     ref = H.random_dna(rng, 30000)
     n_blocks = (1200 << 20) // 1024  # 8192 bins: 1 KiB blocks, 1.17 GiB
@@ -1867,3 +1879,61 @@ def test_device_thresholds_match_the_reference_compiled_table():
                 assert len(bad) == 0, [(int(lens[lo + i]), int(mc[i, 0]), int(thr_of[lo + i])) for i in bad[:5]]
                 assert (expect != want_dec[lo:hi]).sum() <= 3  # ... and nearly every read sits where it was put: one each side of t(L)
         eng.destroy()
+
+
+@pytest.mark.parametrize("nd,nt", [(1, 0), (1, 1), (2, 2), (0, 2)])
+def test_early_decision_mode_changes_no_output(nd, nt):
+    """The opt-in early-decision mode (rb_engine_set_early_decision): RB_MODE_CHECK_UNBLOCK calls of the throughput form that do not ask
+    for the raw maxima let a wave of the plain count kernel stop once a bin has reached the larger of the read's two thresholds
+    (adaptive_sampling.hpp:47-86 looks at a count only through "count >= threshold(r)" and "count >= threshold(r - 0.02)").  Every output
+    the call returns -- decision, status, best_target -- equals the mode being off and the oracle's check_unblock: wide filters (one wave
+    per block, and several lane groups per block, whose counters are partial when a wave leaves), several column slices, three error
+    rates, reads that match on either strand, reads right at their thresholds, short and empty reads."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(7 + 10 * nd + nt)
+    ref = H.random_dna(rng, 60000)
+    geos = [(8192, 13), (600, 13), (1024, 15), (8300, 13)]  # W = 128 (16-byte lanes), 10 (16 lanes per block), 16, 130 (two column slices)
+    filters, views, keep = [], [], []
+    for i in range(nd + nt):
+        n_bins, k = geos[i % len(geos)]
+        W = (n_bins + 63) // 64
+        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 1531)
+        lo = (i * 9000) % 40000
+        d.add_sequence(ref[lo:lo + 16000], 2000)
+        o, kp = oracle_view(d)
+        filters.append(d); views.append(o); keep.append(kp)
+    # > 2 048 reads: the throughput form.  Error rates from clean to hopeless put many reads near their thresholds.
+    reads = []
+    for e_ in (0.0, 0.05, 0.1, 0.14, 0.18, 0.25):
+        reads += make_reads(rng, ref, 450, lo=10, hi=700, err=e_)
+    reads += ["", "ACGT", "A" * 13, ref[500:860], ref[20000:20360]]
+    buf, offs, lens = H.pack_reads(reads)
+    n = len(lens)
+    assert n > 2048
+    up = lambda a, dt: torch.from_numpy(a.view(dt)).to(dev)
+    t_buf, t_offs, t_lens = up(np.ascontiguousarray(buf), np.uint8), up(np.ascontiguousarray(offs, dtype=np.uint64), np.int64), up(np.ascontiguousarray(lens, dtype=np.uint32), np.int32)
+    eng = capi.Engine(0, filters[:nd], filters[nd:])
+    for r in (0.1, 0.05, 0.15):
+        exp_dec, exp_st = po.batch_check_unblock(views[:nd], views[nd:], buf, offs, lens, r=r, n_threads=8)
+        got = {}
+        for early in (0, 1):
+            eng.set_early_decision(early)
+            for with_best in (True, False):
+                t_dec = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                t_st = torch.full((n,), 9, dtype=torch.uint8, device=dev)
+                t_best = torch.full((n,), -9, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                eng.classify_device(t_buf.data_ptr(), t_offs.data_ptr(), t_lens.data_ptr(), n, int(lens.max()), error_rate=r,
+                                    d_best=t_best.data_ptr() if with_best else None, d_decision=t_dec.data_ptr(), d_status=t_st.data_ptr())
+                torch.cuda.synchronize()
+                got[(early, with_best)] = (t_dec.cpu().numpy(), t_st.cpu().numpy(), t_best.cpu().numpy())
+                assert np.array_equal(got[(early, with_best)][0], exp_dec), (r, early, with_best)
+                assert np.array_equal(got[(early, with_best)][1], exp_st), (r, early, with_best)
+        assert np.array_equal(got[(1, True)][2], got[(0, True)][2])  # best_target as without the mode
+        assert len(set(exp_dec.tolist())) >= 2
+    # the mode never touches a call that asks for the raw maxima
+    eng.set_early_decision(1)
+    mc = eng.classify(buf, offs, lens)[0]
+    assert np.array_equal(mc, np.stack([po.batch_raw_max(v, buf, offs, lens, 8) for v in views], axis=1))
+    eng.set_early_decision(0)

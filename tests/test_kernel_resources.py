@@ -15,8 +15,9 @@ CSRC = os.path.join(ROOT, "readbouncer_amd", "csrc")
 
 # kernel<template arguments> -> least waves per SIMD
 EXPECT = {
-    "ibf_count_max_kernel<6,2,10,3,1>": 3,        # config 3 / 4: 16-byte lanes, 12 KiB of gathers in flight per wave
-    "ibf_count_max_kernel<4,1,10,3,0>": 4,        # config 2
+    "ibf_count_max_kernel<6,2,10,3,1,0>": 3,      # config 3 / 4: 16-byte lanes, 12 KiB of gathers in flight per wave
+    "ibf_count_max_kernel<6,2,10,3,1,1>": 3,      # ... its opt-in early-decision twin (last argument; round 6)
+    "ibf_count_max_kernel<4,1,10,3,0,0>": 4,      # config 2
     "ibf_count_max_phased_kernel<0,10,1,4>": 8,   # one-word blocks, <= 256 k-mers
     "ibf_count_max_phased_kernel<0,10,3,4>": 6,   # one-word blocks, six tiles (360 bp)
     "ibf_count_max_phased_kernel<0,10,2,4>": 8,   # one-word blocks, rounds of three tiles
