@@ -392,6 +392,19 @@ class Engine:
                                        _ptr(maxcount), _ptr(best), _ptr(decision), _ptr(status)), "rb_classify_batch")
         return maxcount, best, decision, status
 
+    def decide(self, seqs, offsets, lens, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
+        """host buffers in, (decision[n], status[n]) out; the raw maxima and best_target are NOT asked for (NULL out pointers) -- the form
+        of call the opt-in early-decision mode applies to (set_early_decision)"""
+        n = len(lens)
+        decision = np.zeros(n, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.uint8)
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        _check(lib().rb_classify_batch(self.h, _ptr(seqs), _ptr(offsets), _ptr(lens), n, error_rate, significance, mode,
+                                       None, None, _ptr(decision), _ptr(status)), "rb_classify_batch")
+        return decision, status
+
     def classify_reads(self, reads, error_rate=0.1, significance=0.95, mode=RB_MODE_CHECK_UNBLOCK):
         """list of bytes objects (one buffer per read) through rb_classify_batch_ptrs"""
         n = len(reads)

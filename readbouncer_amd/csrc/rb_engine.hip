@@ -1399,7 +1399,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
                 uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes)
                                 : one_word_rule ? phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) : 0;  // (one-word tables from 50 MiB on)
                 if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
-                if (want >= 1 && want <= e->phase_max_slices && want < n_sl) {
+                if (want >= 1 && want <= e->phase_max_slices && (want < n_sl || e->phase_n_slices)) {  // (an explicit count may also be MORE slices than the 4 MiB cut)
                     // the kernels carry blocks-per-slice in 31 bits and the slice's span in BYTES in 31 bits as well (bit 31 is the
                     // flag of this form): a slice of 2 GiB or more keeps the power-of-two cut, whose span is a shift (ADVICE r4 --
                     // a truncated span would read lookups beyond it as "no lookup" and the counts would be silently short)

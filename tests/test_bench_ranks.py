@@ -66,7 +66,8 @@ def _check_line(d, n_gpus):
     assert isinstance(c["config"]["workload"], str) and "model" not in c["config"]
     for leg, row in (c.get("other_configs") or {}).items():
         assert set(row) <= {"value", "ms_per_step", "frac", "frac_of_read_peak", "Glines_per_s", "request_bound_frac", "p99_ms", "live_p99_ms", "cpu_reads_per_s",
-                            "parity_ok", "checked_reads", "error"}, (leg, row)
+                            "parity_ok", "checked_reads", "error", "work_skipped"}, (leg, row)
+        assert ("work_skipped" in row) == (leg == "c3_early") and not (row.get("work_skipped") and "frac" in row)  # skipped work never carries a roofline fraction
         assert len(json.dumps(row)) < 300
     return c
 

@@ -70,6 +70,12 @@ def _random_geometry(seed, n_rule):
         mc, _, dec, st = eng.classify(buf, offs, lens, error_rate=r_err)
         assert np.array_equal(mc[:, 0], exp_max), (n_bins, k, h, n_blocks, split)
         assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, split)
+    # the opt-in early-decision mode on the throughput form (a call that asks for decisions only): same decisions, whatever the geometry
+    # (builds without an early twin -- h != 3 -- count on as before)
+    eng.set_early_decision(1)
+    dec, st = eng.decide(buf, offs, lens, error_rate=r_err)
+    eng.set_early_decision(0)
+    assert np.array_equal(dec, exp_dec) and np.array_equal(st, exp_st), (n_bins, k, h, n_blocks, "early")
     # throughput form with clock-phased gathers (forced; serves blocks of one and two words with three hash functions)
     eng.set_phased(0, 1 << 40, int(rng.choice([0, 100, 1500])), int(rng.choice([1, 30])), 1)
     eng.set_phase_slices(1, int(rng.choice([2, 5, 8, 32])))  # as many slices as that, however small the table

@@ -253,6 +253,13 @@ def test_decisions_match_oracle(nd, nt):
         exp_dec, exp_st = po.batch_check_unblock(odep, otgt, buf, offs, lens, r=r, n_threads=4)
         assert np.array_equal(decision, exp_dec), "check_unblock decisions differ at r=%g" % r
         assert np.array_equal(status, exp_st)
+        # the same through the throughput form with the opt-in early-decision mode (decisions only: no raw maxima asked for)
+        eng.set_split_threshold(0)
+        eng.set_early_decision(1)
+        dec_e, st_e = eng.decide(buf, offs, lens, error_rate=r)
+        eng.set_early_decision(0)
+        eng.set_split_threshold(2048)
+        assert np.array_equal(dec_e, exp_dec) and np.array_equal(st_e, exp_st), "early-decision mode differs at r=%g" % r
     assert len(set(exp_dec.tolist())) >= 2
     # offline chunk semantics (classify.hpp): classified flag, credited target, failed status
     _, best, classified, status = eng.classify(buf, offs, lens, mode=capi.RB_MODE_CLASSIFY_CHUNK)
@@ -1898,7 +1905,7 @@ def test_early_decision_mode_changes_no_output(nd, nt):
     for i in range(nd + nt):
         n_bins, k = geos[i % len(geos)]
         W = (n_bins + 63) // 64
-        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 1531)
+        d = capi.DeviceIBF.create(0, n_bins, 3, k, W * 64 * 24001)  # (2 000-base bins: a fifth of a bin's bits set)
         lo = (i * 9000) % 40000
         d.add_sequence(ref[lo:lo + 16000], 2000)
         o, kp = oracle_view(d)
