@@ -185,6 +185,11 @@ RB_API int rb_engine_calibrate(rb_engine *e, size_t n_reads, uint32_t read_len, 
  * by table size and block width; 1-5 = as small as max_slices allows, which puts test-sized tables through many slices), and
  * never more than max_slices (1-32, default 32; a table that would need more gets larger slices).  Results are identical. */
 RB_API int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_slices);
+/* ... or into n_slices slices of EQUAL length, any number of blocks each (1-32; 0 = back to the built-in rule, which itself cuts the
+ * four-word tables, the two-word tables of the LDS-offset builds and one-word tables from 50 MiB on this way: slices shorter than an
+ * L2 leave the lines of the window before in place while the next slice arrives).  Ignored while rb_engine_set_phase_slices names a
+ * slice size.  Results are identical. */
+RB_API int rb_engine_set_phase_equal_slices(rb_engine *e, uint32_t n_slices);
 
 /* Two-word tables (65-128 bins, or two to three small targets merged) of up to 2^21 - 1 blocks (32 MiB), reads of up to 256 k-mers, phased
  * form: `reads` = 2 or 3 takes the build that carries that many reads per wave through one pass of the windows -- AND accumulators in

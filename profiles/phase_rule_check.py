@@ -48,6 +48,11 @@ def k1_ms(eng, seqs, offs, lens, n, L, mc, ref, warm=1):
     return ms / calls * 1e6 / n
 
 
+def cut_name(key):
+    """sweep keys: log2 of the slice size, or minus the number of equal-length slices"""
+    return "%d equal slices" % -key if key < 0 else "slices of %4d KiB" % (1 << (key - 10))
+
+
 bad = []
 reads_cache = {}
 print("K1 ms per 1 M reads; tolerance %.0f %%" % (args.tol * 100))
@@ -90,6 +95,24 @@ for point in args.points.split(","):
             if not eng.plan(0, N, L)["phased"]:
                 continue  # (a block width the phased form does not serve)
             sweep[(lg2, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+    # slices of equal length (rb_engine_set_phase_equal_slices), two-word tables the rule cuts that way (round 6): the rule's count and its
+    # neighbours, windows around the rule's -- so that the yardstick knows the cut the rule uses (keys: minus the slice count)
+    if plan["phased"] and plan["phase_slice_bytes"] and plan["phase_slice_bytes"] != (1 << plan["phase_slice_log2"]) and W == 2:
+        n_rule = plan["phase_slices"]
+        eng.set_phase_slices(0, 32)
+        for n_eq in (n_rule - 1, n_rule, n_rule + 1):
+            if n_eq < 2:
+                continue
+            eng.set_phase_equal_slices(n_eq)
+            for fct in FACTORS:
+                ticks = int(min(2000, max(100, plan["phase_window_ticks"] * n_rule / n_eq * fct)))
+                if (-n_eq, ticks) in sweep:
+                    continue
+                eng.set_phased(1 << 18, 1 << 32, ticks, 0, 1)
+                if eng.plan(0, N, L)["phase_slices"] != n_eq:
+                    continue
+                sweep[(-n_eq, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
+        eng.set_phase_equal_slices(0)
     # the rule once more at the end (a 5 ms kernel measured first read up to 10 % high against the same setting inside the sweep)
     eng.set_phase_slices(0, 32)
     eng.set_phased()
@@ -112,18 +135,18 @@ for point in args.points.split(","):
     robust_key = min(smooth, key=smooth.get) if smooth else None
     t_best = min([t_plain] + ([smooth[robust_key]] if robust_key else []))
     off = t_rule / t_best - 1.0
-    chose = ("phased %s, %d slices of %d KiB, %d ticks" % (plan["phase_shape_name"], plan["phase_slices"], 1 << (plan["phase_slice_log2"] - 10),
+    chose = ("phased %s, %d slices of %d KiB, %d ticks" % (plan["phase_shape_name"], plan["phase_slices"], (plan["phase_slice_bytes"] or (1 << plan["phase_slice_log2"])) >> 10,
                                                            plan["phase_window_ticks"])) if plan["phased"] else plan["kernel"] + " (no clock)"
     verdict = "ok" if off <= args.tol else "RULE OFF"
     if off > args.tol:
         bad.append(point)
     print("%d-word %3d bp %5.1f MiB: rule %6.2f (%s) | plain %6.2f | best phased %s, smoothed %s | rule vs best %+5.1f %%  %s"
           % (W, L, mib, t_rule, chose, t_plain,
-             ("%6.2f at %d KiB x %d ticks" % (sweep[best_key], 1 << (best_key[0] - 10), best_key[1])) if best_key else "   n/a",
-             ("%6.2f at %d KiB x %d ticks" % (smooth[robust_key], 1 << (robust_key[0] - 10), robust_key[1])) if robust_key else "n/a",
+             ("%6.2f at %s x %d ticks" % (sweep[best_key], cut_name(best_key[0]), best_key[1])) if best_key else "   n/a",
+             ("%6.2f at %s x %d ticks" % (smooth[robust_key], cut_name(robust_key[0]), robust_key[1])) if robust_key else "n/a",
              off * 100, verdict), flush=True)
     if sweep:
         for lg2 in sorted({k[0] for k in sweep}):
-            print("      slices of %4d KiB: " % (1 << (lg2 - 10)) + "  ".join("%d:%.2f" % (t, sweep[(lg2, t)]) for (l, t) in sorted(sweep) if l == lg2), flush=True)
+            print("      %s: " % cut_name(lg2) + "  ".join("%d:%.2f" % (t, sweep[(lg2, t)]) for (l, t) in sorted(sweep) if l == lg2), flush=True)
 print("points outside the tolerance: %s" % (", ".join(bad) if bad else "none"))
 sys.exit(1 if bad else 0)

@@ -136,6 +136,7 @@ SIGNATURES = {
     "rb_engine_set_host_slice_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_serial_table_bytes": (_int, [_vp, _u64]),
     "rb_engine_set_phase_slices": (_int, [_vp, _u32, _u32]),
+    "rb_engine_set_phase_equal_slices": (_int, [_vp, _u32]),
     "rb_engine_set_reads_per_wave": (_int, [_vp, _u32]),
     "rb_engine_set_phase_xcd_skew": (_int, [_vp, _u32]),
     "rb_engine_set_early_decision": (_int, [_vp, _int]),
@@ -526,6 +527,10 @@ class Engine:
     def set_phase_slices(self, slice_log2=0, max_slices=32):
         """slices of 2^slice_log2 bytes (0: built-in rule; 1-5: as small as max_slices allows), at most max_slices"""
         _check(lib().rb_engine_set_phase_slices(self.h, slice_log2, max_slices), "rb_engine_set_phase_slices")
+
+    def set_phase_equal_slices(self, n_slices=0):
+        """n equal-length slices for the phased form (0 = the built-in rule); ignored while set_phase_slices names a slice size"""
+        _check(lib().rb_engine_set_phase_equal_slices(self.h, n_slices), "rb_engine_set_phase_equal_slices")
 
     def set_reads_per_wave(self, reads):
         """two-word phased tables, reads of up to 256 k-mers: reads a wave carries through a pass of the windows (0: the one-read build)"""

@@ -1166,6 +1166,15 @@ int rb_engine_set_phase_slices(rb_engine *e, uint32_t slice_log2, uint32_t max_s
     return RB_OK;
 }
 
+int rb_engine_set_phase_equal_slices(rb_engine *e, uint32_t n_slices)
+{
+    if (!e || n_slices > 32) return rb::fail(RB_ERR_INVALID_ARG, "0 (the rule) or 1..32 equal-length slices");
+    std::lock_guard<std::mutex> lock(e->mu);
+    e->phase_n_slices = n_slices;
+    e->phase_overrides.clear();
+    return RB_OK;
+}
+
 int rb_engine_set_early_decision(rb_engine *e, int enabled)
 {
     if (!e) return rb::fail(RB_ERR_INVALID_ARG, "null engine");
@@ -1392,14 +1401,25 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             while (slice_log2 >= 6 && (f->stride * 8) << (sh + 1) <= (1ull << slice_log2)) ++sh;  // (< 6: as small as max_slices allows)
             while (((f->geo.n_blocks + (1ull << sh) - 1) >> sh) > e->phase_max_slices) ++sh;
             uint32_t n_sl = (uint32_t)((f->geo.n_blocks + (1ull << sh) - 1) >> sh);
+            // the builds that keep the offsets in LDS (two-word blocks of up to 2^21 - 1 blocks, reads of up to 384 k-mers): planned here because the
+            // window belongs to the build (rb_phase_plan.h, phase_multi_window_ticks)
+            // (lg 1: short_only 1 / 3 = at most 256 / 384 k-mers; lg 2, blocks of three and four words: short_only 5 = at most 256, 4 = at most 512 --
+            // up to 384 of them fit one round of six tiles)
+            const int multi_tiles = a.lg <= 1 ? (a.short_only == 1 ? 4 : a.short_only == 3 ? 6 : 0)
+                                    : (a.lg == 2 && wide_short) ? (a.short_only == 5 ? 4 : (a.short_only == 4 && kmers <= 384 && e->multi_wide_six) ? 6 : 0) : 0;
+            const bool multi_build = e->multi_reads && multi_tiles && a.planes <= 10 && a.col_begin == 0 && f->geo.n_blocks < (1ull << 21) - 1 &&
+                                     ((a.lg == 1 && a.col_end == 2 && f->stride == 2) || (a.lg == 2 && e->multi_wide && f->stride == 4) ||
+                                      (a.lg == 0 && e->multi_one_word && a.col_end == 1 && f->stride == 1 && W == 1));
             // the four-word one-lane builds: slices of equal length, fewer than the 4 MiB ones (rb_phase_plan.h, phase_equal_slices)
             uint64_t blocks_per_slice = 0;
             const bool one_word_rule = f->stride == 1 && a.lg == 0 && phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) != 0;
-            if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || one_word_rule || e->phase_n_slices)) {
+            // ... and the two-word LDS-offset builds where their rule asks for 4 MiB slices: equal ones SHORTER than an L2 (phase_multi_equal_slices)
+            const uint32_t multi_equal = (multi_build && a.lg == 1 && !e->phase_n_slices) ? phase_multi_equal_slices(shape, a.lg, slice_log2, table_bytes, kmers) : 0;
+            if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || one_word_rule || multi_equal || e->phase_n_slices)) {
                 uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes)
-                                : one_word_rule ? phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) : 0;  // (one-word tables from 50 MiB on)
+                                : one_word_rule ? phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) : multi_equal;  // (one-word tables from 50 MiB on)
                 if (e->phase_n_slices) want = e->phase_n_slices;  // (RB_PHASE_N_SLICES, measurements: profiles/r04/slice_count_sweep.txt)
-                if (want >= 1 && want <= e->phase_max_slices && (want < n_sl || e->phase_n_slices)) {  // (an explicit count may also be MORE slices than the 4 MiB cut)
+                if (want >= 1 && want <= e->phase_max_slices && (want < n_sl || e->phase_n_slices || multi_equal)) {  // (an explicit count and the two-word rule may also ask for MORE slices than the 4 MiB cut)
                     // the kernels carry blocks-per-slice in 31 bits and the slice's span in BYTES in 31 bits as well (bit 31 is the
                     // flag of this form): a slice of 2 GiB or more keeps the power-of-two cut, whose span is a shift (ADVICE r4 --
                     // a truncated span would read lookups beyond it as "no lookup" and the counts would be silently short)
@@ -1411,6 +1431,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
                 }
             }
             uint64_t ticks = e->phase_explicit ? e->phase_base_ticks + (table_bytes >> 20) * e->phase_ticks_per_mib
+                             : (blocks_per_slice && multi_equal) ? phase_multi_equal_ticks(shape, n_sl, table_bytes, kmers)
                              : (blocks_per_slice && one_word_rule && !e->phase_n_slices) ? phase_equal_slices_one_word_ticks(shape, n_sl, table_bytes, kmers)
                              : blocks_per_slice ? phase_equal_slices_ticks(shape, a.lg, n_sl, kmers)
                                                 : phase_window_ticks(shape, a.lg, slice_log2, n_sl, kmers);
@@ -1418,16 +1439,7 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             if (!e->phase_explicit)  // a window measured on this device for exactly this table, shape and slice size (rb_engine_calibrate)
                 for (const rb_engine::PhaseOverride &o : e->phase_overrides)
                     if (o.table_bytes == table_bytes && o.stride == f->stride && o.shape == (int)shape && o.lg == a.lg && o.slice_log2 == slice_log2) ticks = o.ticks;
-            // the builds that keep the offsets in LDS (two-word blocks of up to 2^21 - 1 blocks, reads of up to 384 k-mers): planned here because the
-            // window belongs to the build (rb_phase_plan.h, phase_multi_window_ticks)
-            // (lg 1: short_only 1 / 3 = at most 256 / 384 k-mers; lg 2, blocks of three and four words: short_only 5 = at most 256, 4 = at most 512 --
-            // up to 384 of them fit one round of six tiles)
-            const int multi_tiles = a.lg <= 1 ? (a.short_only == 1 ? 4 : a.short_only == 3 ? 6 : 0)
-                                    : (a.lg == 2 && wide_short) ? (a.short_only == 5 ? 4 : (a.short_only == 4 && kmers <= 384 && e->multi_wide_six) ? 6 : 0) : 0;
-            const bool multi_build = e->multi_reads && multi_tiles && a.planes <= 10 && a.col_begin == 0 && f->geo.n_blocks < (1ull << 21) - 1 &&
-                                     ((a.lg == 1 && a.col_end == 2 && f->stride == 2) || (a.lg == 2 && e->multi_wide && f->stride == 4) ||
-                                      (a.lg == 0 && e->multi_one_word && a.col_end == 1 && f->stride == 1 && W == 1));
-            if (multi_build && !e->phase_explicit) {
+            if (multi_build && !e->phase_explicit && !(blocks_per_slice && multi_equal)) {  // (the equal cut's window is the build's own already)
                 const uint64_t scaled = phase_multi_window_ticks(shape, slice_log2, n_sl, kmers, a.phase_rule_ticks);
                 if (ticks == a.phase_rule_ticks) ticks = scaled;  // (a window measured by rb_engine_calibrate for this table stays)
                 a.phase_rule_ticks = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(scaled, 100), 2000);

@@ -308,6 +308,39 @@ inline uint64_t phase_multi_window_ticks(PhaseShape shape, uint32_t slice_log2, 
     return rule_ticks;
 }
 
+// Round 6, after the LDS-offset builds: where the two-word rule asks for 4 MiB slices, slices of EQUAL length SHORTER than an L2 (2.4-3.2 MiB)
+// serve the LDS-offset builds better.  A 4 MiB slice is a whole L2: the lines of the window before are evicted as the next slice arrives,
+// waves that are a little late miss, and the table's last, shorter slice runs under the same window as the others.  With ~2.5 MiB slices
+// the window shrinks to what a slice's lookups need (about 500 ticks whatever the table) and the cycle with it.  K1 ms per 1 M reads, single
+// 128-bin filters (AND form), rule of 4 MiB slices -> equal slices at the best window (profiles/r06/multi/equal_slices_fit_two_word.txt):
+//   four tiles, 250 bp: 18.9 MiB 8.41 -> 7.66 (8 slices, 500 ticks); 22: 9.06 -> 7.97 (9, 511); 26: 9.86 -> 8.47 (9, 511); 31: 10.21 -> 8.90 (10, 540);
+//               200 bp: 16 MiB 6.85 -> 6.25 (6-7); 18.9: 7.54 -> 6.64 (7, 485); 22: 8.03 -> 6.92 (7-8); 26: 8.45 -> 7.38 (9, 477); 31: 9.83 -> 8.10 (10, 460);
+//   six tiles,  360 bp: 18.9 MiB 12.90 -> 10.95 (7 slices, 687 ticks); 22: 13.33 -> 11.53 (8, 650); 26: 14.14 -> 12.24 (9, 621); 31: 13.53 -> 13.11 (10, 598);
+//               300 bp: 16 MiB 11.10 -> 9.16 (5, 806); 18.9: 11.96 -> 9.71 (6, 736) / 9.93 (7, 631); 22: 12.51 -> 10.40 (7, 687); 26: 12.70 -> 11.11 (8, 650);
+//   the merged OR form (bench legs deplete_target / targets3, 18.9 MiB): 250 bp 8.22 -> 7.58 (8 slices, 507 ticks); 360 bp 12.7 -> 10.93 (7, 727).
+// Every curve has a cliff on the short side (a window shorter than about 1.4 x the slice's refill, or -- six tiles -- than a wave's pass
+// over its twelve slots): four tiles near 165 ticks per MiB of slice, 5-15 % up; six tiles 30-40 % up within 8 % of the optimum
+// (18.9 MiB, 360 bp, 7 slices: 631 ticks 12.57, 687: 10.95; the merged form: 669: 12.15, 727: 10.93) -- the rule stays 5-8 % above it.
+// Tables the rule cuts into 2 MiB slices (up to 13-16 MiB) are within 2-4 % of the best equal cut and keep it.
+inline uint32_t phase_multi_equal_slices(PhaseShape shape, int lg, uint32_t slice_log2, uint64_t table_bytes, uint32_t kmers)
+{
+    if (lg != 1 || slice_log2 != 22) return 0;
+    const double mib = (double)table_bytes / 1048576.0, fill = phase_fill(shape, kmers);
+    double slice_mib;
+    if (shape == PhaseShape::FourTiles) slice_mib = (1.45 + 0.048 * mib) * (1.5 - 0.5 * fill);  // (shorter reads: fewer, longer slices)
+    else if (shape == PhaseShape::SixTiles) slice_mib = 2.5 + 0.02 * mib;
+    else return 0;
+    const uint32_t n = (uint32_t)(mib / slice_mib + 0.5);
+    return n >= 2 && n <= 32 ? n : 0;
+}
+inline uint64_t phase_multi_equal_ticks(PhaseShape shape, uint32_t n_slices, uint64_t table_bytes, uint32_t kmers)
+{
+    const double mib = (double)table_bytes / 1048576.0, fill = phase_fill(shape, kmers);
+    const uint32_t n = std::max(n_slices, 1u);
+    if (shape == PhaseShape::SixTiles) return (uint64_t)((2350.0 + 130.0 * mib) * 1.08 * (0.75 + 0.25 * fill) / n);  // (a cycle, over the slices)
+    return (uint64_t)(1.05 * std::max(480.0, 168.0 * mib / n) * (0.85 + 0.15 * fill));
+}
+
 // from which table size on the phased form pays ...
 inline uint64_t phase_shape_min_bytes(PhaseShape shape, int lg, double fill)
 {

@@ -1818,6 +1818,21 @@ def test_several_reads_per_wave_match_oracle(widths, n_blocks):
                 if base is None:
                     base = got
                 assert all(np.array_equal(a, b) for a, b in zip(got, base)), (reads_per_wave, base_ticks, max_slices)
+            # slices of equal length, any number of blocks each (rb_engine_set_phase_equal_slices; what the planner's rule cuts real tables
+            # into): 3, 7 and 31 of them -- the last one shorter, ending with the table
+            eng.set_phase_slices(0, 32)
+            for base_ticks, n_equal in ((200, 3), (1, 7), (500, 31)):
+                eng.set_phased(0, 1 << 40, base_ticks, 0, 1)
+                eng.set_phase_equal_slices(n_equal)
+                pl = eng.plan(0, len(lens), int(lens.max()))
+                assert pl["phased"] and pl["phase_slices"] == -(-n_blocks // -(-n_blocks // n_equal)) and pl["phase_slice_bytes"] % 8 == 0, pl
+                assert pl["phase_slice_bytes"] == -(-n_blocks // n_equal) * 8 * pl["stride_words"], pl
+                got = eng.classify(buf, offs, lens)
+                assert np.array_equal(got[0], exp), (reads_per_wave, base_ticks, n_equal, "equal slices")
+                assert all(np.array_equal(a, b) for a, b in zip(got, base)), (reads_per_wave, base_ticks, n_equal, "equal slices")
+            eng.set_phase_equal_slices(0)
+            eng.set_phased(0, 1 << 40, 150, 0, 1)
+            eng.set_phase_slices(1, 1)
             # sub-batches: every remainder of the batch size modulo the reads per wave
             for n_sub in (2049, 2050, 2051):
                 got = eng.classify(buf, offs[:n_sub], lens[:n_sub])

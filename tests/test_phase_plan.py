@@ -92,6 +92,50 @@ int main() {
     assert 660 <= rows[80][5] <= 800 and 700 <= rows[127][5] <= 800  # (the measured optima: 769-807 ticks at 80 MiB / 13 slices, 750 at 127 MiB / 16)
 
 
+def test_equal_length_slices_of_the_two_word_lds_offset_builds(tmp_path):
+    """phase_multi_equal_slices / phase_multi_equal_ticks (rb_phase_plan.h, round 6): only two-word blocks whose rule asks for 4 MiB slices;
+    slices of 2.3-3.3 MiB; four tiles: a window of about 500 ticks whatever the table, never below 1.05 x 168 ticks per MiB of slice; six
+    tiles: a cycle of 2 350 + 130 per MiB ticks (+ 8 %); slice counts and windows at the measured points of
+    profiles/r06/multi/equal_slices_fit_two_word.txt"""
+    src = tmp_path / "mw.cpp"
+    src.write_text('''
+#include <cstdint>
+#include <cstdio>
+#include "%s"
+using namespace rbplan;
+int main() {
+    const double mib[] = {13, 16, 18.9, 22, 26, 31};
+    const uint32_t kmers[] = {188, 238, 288, 348};
+    for (double m : mib)
+        for (uint32_t km : kmers) {
+            const uint64_t b = (uint64_t)(m * 1048576.0);
+            const PhaseShape sh = km <= 256 ? PhaseShape::FourTiles : PhaseShape::SixTiles;
+            const uint32_t n = phase_multi_equal_slices(sh, 1, 22, b, km);
+            std::printf("%%.1f %%u %%u %%llu %%u %%u %%u\\n", m, km, n, (unsigned long long)phase_multi_equal_ticks(sh, n ? n : 1, b, km),
+                        phase_multi_equal_slices(sh, 1, 21, b, km), phase_multi_equal_slices(sh, 0, 22, b, km), phase_multi_equal_slices(PhaseShape::WideFourTiles, 2, 22, b, km));
+        }
+}
+''' % os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h"))
+    exe = str(tmp_path / "mw")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", str(src), "-o", exe])
+    rows = {(float(r[0]), int(r[1])): [int(x) for x in r[2:]] for r in (l.split() for l in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines())}
+    for (m, km), (n, ticks, n21, n_one_word, n_wide) in rows.items():
+        assert n21 == n_one_word == n_wide == 0  # 4 MiB rule only, two-word blocks only, not the wide shapes
+        assert 2.1 <= m / n <= 3.4, (m, km, n)
+        if km <= 256:
+            assert 1.05 * 168 * (m / n) * 0.95 <= ticks <= 600 and ticks >= 460, (m, km, n, ticks)
+        else:
+            assert 0.9 * (2350 + 130 * m) <= ticks * n <= 1.09 * (2350 + 130 * m), (m, km, n, ticks)
+    # the measured optima (slices, window): the rule's cut is the best or second-best one measured, its window 0-10 % above the optimum
+    assert rows[(18.9, 238)][0] == 8 and 500 <= rows[(18.9, 238)][1] <= 540      # 7.66 ms at 8 x 500 ticks (4 MiB slices: 8.41)
+    assert rows[(22.0, 238)][0] == 9 and 500 <= rows[(22.0, 238)][1] <= 550      # 7.97 at 9 x 511
+    assert rows[(31.0, 238)][0] in (10, 11) and 490 <= rows[(31.0, 238)][1] <= 580
+    assert rows[(18.9, 188)][0] == 7 and 470 <= rows[(18.9, 188)][1] <= 520      # 6.64 at 7 x 485
+    assert rows[(18.9, 348)][0] == 7 and 700 <= rows[(18.9, 348)][1] <= 760      # 10.95 at 7 x 687; the merged form's cliff ends at ~700
+    assert rows[(26.0, 348)][0] == 9 and 621 <= rows[(26.0, 348)][1] <= 690      # 12.24 at 9 x 621
+    assert rows[(18.9, 288)][0] == 7 and 640 <= rows[(18.9, 288)][1] <= 730      # 9.93 at 7 x 631, 10.28 at 687
+
+
 def test_every_shape_has_a_named_row():
     hdr = open(os.path.join(ROOT, "readbouncer_amd", "csrc", "rb_phase_plan.h")).read()
     for name in ("General", "FourTiles", "Rounds", "SixTiles", "WideRounds", "WideFourTiles", "Wide3FourTiles", "Wide3Rounds"):
