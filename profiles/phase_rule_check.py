@@ -95,9 +95,9 @@ for point in args.points.split(","):
             if not eng.plan(0, N, L)["phased"]:
                 continue  # (a block width the phased form does not serve)
             sweep[(lg2, ticks)] = k1_ms(eng, seqs, offs, lens, N, L, mc, ref)
-    # slices of equal length (rb_engine_set_phase_equal_slices), two-word tables the rule cuts that way (round 6): the rule's count and its
+    # slices of equal length (rb_engine_set_phase_equal_slices), one- and two-word tables the rule cuts that way (round 6): the rule's count and its
     # neighbours, windows around the rule's -- so that the yardstick knows the cut the rule uses (keys: minus the slice count)
-    if plan["phased"] and plan["phase_slice_bytes"] and plan["phase_slice_bytes"] != (1 << plan["phase_slice_log2"]) and W == 2:
+    if plan["phased"] and plan["phase_slice_bytes"] and plan["phase_slice_bytes"] != (1 << plan["phase_slice_log2"]) and W <= 2 and mib < 50:
         n_rule = plan["phase_slices"]
         eng.set_phase_slices(0, 32)
         for n_eq in (n_rule - 1, n_rule, n_rule + 1):

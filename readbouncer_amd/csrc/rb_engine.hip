@@ -1407,14 +1407,15 @@ static bool plan_geometry(const rb_engine *e, const rb_dibf *f, size_t n_reads, 
             // up to 384 of them fit one round of six tiles)
             const int multi_tiles = a.lg <= 1 ? (a.short_only == 1 ? 4 : a.short_only == 3 ? 6 : 0)
                                     : (a.lg == 2 && wide_short) ? (a.short_only == 5 ? 4 : (a.short_only == 4 && kmers <= 384 && e->multi_wide_six) ? 6 : 0) : 0;
-            const bool multi_build = e->multi_reads && multi_tiles && a.planes <= 10 && a.col_begin == 0 && f->geo.n_blocks < (1ull << 21) - 1 &&
+            const bool multi_build = e->multi_reads && multi_tiles && a.planes <= 10 && a.col_begin == 0 &&
+                                     f->geo.n_blocks < (1ull << (a.lg == 0 ? 22 : 21)) - 1 &&  // (block numbers of 21 bits; one-word blocks: 22, rb_kernels.hip kPackBits1)
                                      ((a.lg == 1 && a.col_end == 2 && f->stride == 2) || (a.lg == 2 && e->multi_wide && f->stride == 4) ||
                                       (a.lg == 0 && e->multi_one_word && a.col_end == 1 && f->stride == 1 && W == 1));
             // the four-word one-lane builds: slices of equal length, fewer than the 4 MiB ones (rb_phase_plan.h, phase_equal_slices)
             uint64_t blocks_per_slice = 0;
             const bool one_word_rule = f->stride == 1 && a.lg == 0 && phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) != 0;
-            // ... and the two-word LDS-offset builds where their rule asks for 4 MiB slices: equal ones SHORTER than an L2 (phase_multi_equal_slices)
-            const uint32_t multi_equal = (multi_build && a.lg == 1 && !e->phase_n_slices) ? phase_multi_equal_slices(shape, a.lg, slice_log2, table_bytes, kmers) : 0;
+            // ... and the one- and two-word LDS-offset builds where their rule asks for 4 MiB slices: equal ones SHORTER than an L2 (phase_multi_equal_slices)
+            const uint32_t multi_equal = (multi_build && a.lg <= 1 && !e->phase_n_slices) ? phase_multi_equal_slices(shape, a.lg, slice_log2, table_bytes, kmers) : 0;
             if (!e->phase_slice_log2 && ((f->stride == 4 && a.lg == 2) || one_word_rule || multi_equal || e->phase_n_slices)) {
                 uint32_t want = (f->stride == 4 && a.lg == 2) ? phase_equal_slices(shape, slice_log2, table_bytes)
                                 : one_word_rule ? phase_equal_slices_one_word(shape, a.lg, slice_log2, table_bytes) : multi_equal;  // (one-word tables from 50 MiB on)

@@ -1184,6 +1184,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 // are identical by construction (the same AND of the same words).
 constexpr uint32_t kPackBits = 21;
 constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
+// One-word blocks (8 bytes each: a table of 2^21 of them is only 16 MiB) pack 22-bit block numbers: the first two whole, the low 20 bits
+// of the third, and its top two bits in a per-lane SPILL word held in a register (two bits per slot, at most twelve slots) -- tables of
+// up to 2^22 - 2 blocks (32 MiB), which takes in the 64-bin filter of the reference's own test data (2.47 M blocks).  Two VALU operations
+// more per slot and window; 0x3FFFFF = no lookup.
+constexpr uint32_t kPackBits1 = 22;
+constexpr uint32_t kPackMask1 = (1u << kPackBits1) - 1u;
 #ifndef RB_MULTI_WAVES
 #define RB_MULTI_WAVES 5
 #endif
@@ -1191,13 +1197,15 @@ constexpr uint32_t kPackMask = (1u << kPackBits) - 1u;
 #define RB_MULTI_WAVES_W4 5
 #endif
 
-// three packed block numbers of one k-mer (kPackBits each)
-__device__ __forceinline__ uint64_t pack_lookups(uint64_t v, const IbfDev &f)
+// three packed block numbers of one k-mer (PB = kPackBits each, or kPackBits1 with the third one's top two bits returned in hi2)
+template <int PB>
+__device__ __forceinline__ uint64_t pack_lookups(uint64_t v, const IbfDev &f, uint32_t &hi2)
 {
     const uint64_t b0 = rbspec::block_index(v, f.precalc[0], f.n_blocks, f.magic, f.pow2_mask);
     const uint64_t b1 = rbspec::block_index(v, f.precalc[1], f.n_blocks, f.magic, f.pow2_mask);
     const uint64_t b2 = rbspec::block_index(v, f.precalc[2], f.n_blocks, f.magic, f.pow2_mask);
-    return b0 | (b1 << kPackBits) | (b2 << (2 * kPackBits));
+    hi2 = PB == (int)kPackBits ? 0u : (uint32_t)(b2 >> 20);
+    return b0 | (b1 << PB) | (b2 << (2 * PB));  // (22 bits: the shift drops the third number's top two bits)
 }
 
 // Phase A of the multi-read build for ONE read: its k-mers' packed block numbers go to slots[j * 64 + lane], j = 0..3 the forward
@@ -1222,10 +1230,10 @@ struct MultiShape {
     static_assert(3 * kArr <= NST * 512u, "the staged arrays fit the slot regions they borrow");
 };
 
-template <int T>
-__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane);
-template <int T>
-__device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDev &f, const ReadSrc &src, uint32_t rid, uint32_t n_reads, int lane)
+template <int T, int PB>
+__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane, uint32_t &spill);
+template <int T, int PB = (int)kPackBits>
+__device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDev &f, const ReadSrc &src, uint32_t rid, uint32_t n_reads, int lane, uint32_t &spill)
 {
     using M = MultiShape<T>;
     const uint32_t k = f.k;
@@ -1238,13 +1246,14 @@ __device__ __forceinline__ uint32_t multi_hash_read(uint64_t *slots, const IbfDe
         if (n)
             for (uint32_t i = lane; i < len; i += 64) ord[i] = (uint8_t)seq.ord(i);
     }
-    multi_hash_staged<T>(slots, f, len, n, lane);
+    multi_hash_staged<T, PB>(slots, f, len, n, lane, spill);
     return n;
 }
 
 // the second half: the read's Dna5 ordinals are staged at the start of the staging area (by this wave; no fence taken yet)
-template <int T>
-__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane)
+// (spill: PB = 22 only -- bits 2 u, 2 u + 1 = the top two bits of slot u's third block number; all ones where a slot has no k-mer)
+template <int T, int PB>
+__device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev &f, uint32_t len, uint32_t n, int lane, uint32_t &spill)
 {
     using M = MultiShape<T>;
     const uint32_t k = f.k;
@@ -1268,9 +1277,12 @@ __device__ __forceinline__ void multi_hash_staged(uint64_t *slots, const IbfDev 
         uint64_t pf = ~0ULL, pr = ~0ULL;
         if (p < n) {
             uint64_t vf, vr;
+            uint32_t hf, hr;
             kmer_values_both(ord, f3, r3, p, k, q3, s1, f.comp_n, small_k, vf, vr);
-            pf = pack_lookups(vf, f);
-            pr = pack_lookups(vr, f);
+            pf = pack_lookups<PB>(vf, f, hf);
+            pr = pack_lookups<PB>(vr, f, hr);
+            if constexpr (PB != (int)kPackBits)
+                spill = (spill & ~((3u << (2 * j)) | (3u << (2 * (j + T))))) | (hf << (2 * j)) | (hr << (2 * (j + T)));
         }
         slots[j * 64 + lane] = pf;
         if (j < T - M::NST) slots[(j + T) * 64 + lane] = pr;
@@ -1309,7 +1321,8 @@ __device__ __forceinline__ void multi_init(uint64_t (&x)[NW][2 * T], uint32_t n_
 // gathers).  (Measured and left out, profiles/r06/negative_results.md: cache-policy bits on the gathers -- sc0 / sc1 change nothing, nt
 // keeps the lines out of the L2 and costs a factor of 2.4 --, two slots per batch of gathers.)
 template <int R, bool INV, int T, int NW>
-__device__ __forceinline__ void multi_windows(uint64_t (&x)[R][NW][2 * T], const uint64_t (*s_off)[2 * T][64], const IbfDev &f, const PhaseCfg &ph, int lane)
+__device__ __forceinline__ void multi_windows(uint64_t (&x)[R][NW][2 * T], const uint64_t (*s_off)[2 * T][64], const IbfDev &f, const PhaseCfg &ph, int lane,
+                                              const uint32_t (&spill)[R])
 {
     static_assert(NW == 1 || NW == 2 || NW == 4, "one- and two-word blocks, or the stride-4 layout of three- and four-word blocks");
     constexpr int S = 2 * T;
@@ -1347,9 +1360,15 @@ __device__ __forceinline__ void multi_windows(uint64_t (&x)[R][NW][2 * T], const
                     const uint64_t pk = s_off[r0 + rr][u][lane];
                     const uint32_t lo = (uint32_t)pk, hi = (uint32_t)(pk >> 32);
                     // (field extract + shift-and-add of the negated slice start: seven VALU operations per k-mer)
-                    rel[rr][0] = ((lo & kPackMask) << kBlockShift) + nstart;
-                    rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << kBlockShift) + nstart;
-                    rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << kBlockShift) + nstart;
+                    if constexpr (NW == 1) {  // 22-bit numbers, the third one's top two bits from the spill word
+                        rel[rr][0] = ((lo & kPackMask1) << kBlockShift) + nstart;
+                        rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits1) & kPackMask1) << kBlockShift) + nstart;
+                        rel[rr][2] = (((hi >> (2 * kPackBits1 - 32)) | (__builtin_amdgcn_ubfe(spill[r0 + rr], 2 * u, 2) << 20)) << kBlockShift) + nstart;
+                    } else {
+                        rel[rr][0] = ((lo & kPackMask) << kBlockShift) + nstart;
+                        rel[rr][1] = ((__builtin_amdgcn_alignbit(hi, lo, kPackBits) & kPackMask) << kBlockShift) + nstart;
+                        rel[rr][2] = (__builtin_amdgcn_ubfe(hi, 2 * kPackBits - 32, kPackBits) << kBlockShift) + nstart;
+                    }
 #pragma unroll
                     for (int h = 0; h < 3; ++h) {
 #pragma unroll
@@ -1428,16 +1447,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_wa
     const int lane = threadIdx.x;
     const uint32_t read0 = blockIdx.x * (uint32_t)R;
     uint32_t nk[R];  // k-mers of each read (0: no such read, or a read longer than promised -- it writes 0 like the one-read build)
+    uint32_t spill[R];  // one-word blocks: the top two bits of every slot's third block number
+    constexpr int PB = NW == 1 ? (int)kPackBits1 : (int)kPackBits;
+    static_assert(NW != 1 || R == 1, "the 22-bit packing is built for one read per wave");
 
     // ---- phase A: hash every k-mer of every read once; the block numbers go to LDS
 #pragma unroll
-    for (int r = 0; r < R; ++r) nk[r] = 0;
+    for (int r = 0; r < R; ++r) nk[r] = 0, spill[r] = ~0u;
 #pragma unroll 1
     for (int r = 0; r < R; ++r) {
-        const uint32_t n = multi_hash_read<T>(&s_off[r][0][0], f, src, read0 + (uint32_t)r, n_reads, lane);
+        uint32_t sp = ~0u;
+        const uint32_t n = multi_hash_read<T, PB>(&s_off[r][0][0], f, src, read0 + (uint32_t)r, n_reads, lane, sp);
 #pragma unroll
         for (int q = 0; q < R; ++q)
-            if (q == r) nk[q] = n;
+            if (q == r) nk[q] = n, spill[q] = sp;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1446,7 +1469,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(multi_min_wa
     uint64_t x[R][NW][S];
 #pragma unroll
     for (int r = 0; r < R; ++r) multi_init<INV, T, NW>(x[r], nk[r], nm, lane);
-    multi_windows<R, INV, T, NW>(x, s_off, f, ph, lane);
+    multi_windows<R, INV, T, NW>(x, s_off, f, ph, lane, spill);
 
     // ---- per-bin sums across the wave, maxima per member
 #pragma unroll
@@ -2192,7 +2215,7 @@ static hipError_t launch_phased(const CountLaunch &a, hipStream_t st)
     // one-word blocks the same way (a filter of up to 64 bins on its own: the AND form)
     if constexpr (LG == 0 && NP == 10) {
         if (a.multi_reads && a.multi_tiles && a.col_begin == 0 && a.col_end == 1 && a.f.stride == 1) {
-            if (a.f.n_blocks > kPackMask) return hipErrorInvalidValue;
+            if (a.f.n_blocks >= kPackMask1) return hipErrorInvalidValue;  // (0x3FFFFF itself is "no lookup")
             dim3 g1(a.n_reads);
             if (a.multi_tiles == 6)
                 hipLaunchKernelGGL((ibf_count_max_phased_multi_kernel<1, false, 6, 1>), g1, dim3(64), 0, st, a.f, a.src, a.n_reads, a.phase, a.out, a.out_read_stride, a.narrow);

@@ -67,7 +67,7 @@ def _check_line(d, n_gpus):
     for leg, row in (c.get("other_configs") or {}).items():
         assert set(row) <= {"value", "ms_per_step", "frac", "frac_of_read_peak", "Glines_per_s", "request_bound_frac", "p99_ms", "live_p99_ms", "cpu_reads_per_s",
                             "parity_ok", "checked_reads", "error", "work_skipped"}, (leg, row)
-        assert ("work_skipped" in row) == (leg == "c3_early") and not (row.get("work_skipped") and "frac" in row)  # skipped work never carries a roofline fraction
+        assert ("work_skipped" not in row or leg == "c3_early") and not (row.get("work_skipped") and "frac" in row)  # skipped work never carries a roofline fraction
         assert len(json.dumps(row)) < 300
     return c
 
@@ -315,6 +315,9 @@ def test_gpus2_default_line_decisions_equal_one_rank_on_c3_and_c4():
             assert d["other_configs"][leg]["roofline"]["frac"] > 0 and d["_compact"]["other_configs"][leg]["frac"] > 0
         _check_line(d, d["n_gpus"])
         if d is d1:
+            early = d["other_configs"]["c3_early"]  # the opt-in mode's leg: labelled as skipped work in the detail AND in the line, never a roofline
+            assert early["work_skipped"] is True and early["roofline"] is None and d["_compact"]["other_configs"]["c3_early"]["work_skipped"] is True
+            assert early["parity"]["oracle_mismatches"] == 0 and early["parity"]["decision_mismatches"] == 0
             g = d["other_configs"]["grch38_f100k"]  # the reference-default human filter: W = 485, non-power-of-two block count
             assert g["config"]["filters"][0]["n_bins"] == 31000 and g["parity"]["near_threshold_reads"] > 0
         assert "generic modulus" in d["other_configs"]["c3np2"]["config"]["workload"]

@@ -1769,8 +1769,9 @@ def test_pool_replicas_of_a_large_filter_started_side_by_side():
                                              # blocks of three and four words (stride 4): filters on their own, the README shape's packed table, a triple
                                              ((130,), 2053), ((256,), 4096), ((200,), 30011), ((122, 43, 29, 49), 30011), ((100, 60, 30), 30011),
                                              ((64, 64, 64, 64), 8192),
-                                             # one-word blocks (a filter of up to 64 bins on its own)
-                                             ((40,), 4099), ((64,), 4096)])
+                                             # one-word blocks (a filter of up to 64 bins on its own); the last two: more than 2^21 blocks -- 22-bit
+                                             # block numbers whose third one keeps its top two bits in the spill word (Barrett and mask modulus)
+                                             ((40,), 4099), ((64,), 4096), ((64,), 2470013), ((33,), 1 << 21), ((64,), (1 << 22) - 2)])
 def test_several_reads_per_wave_match_oracle(widths, n_blocks):
     """Round 6: the builds of the phased kernel that keep a read's block numbers packed in LDS and carry one or two reads per wave
     through a pass of the windows (rb_engine_set_reads_per_wave; ibf_count_max_phased_multi_kernel) -- blocks of two, three and four words, reads of up to
