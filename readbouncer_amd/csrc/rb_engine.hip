@@ -334,7 +334,7 @@ struct rb_engine {
     // rb_engine_set_early_decision (opt-in, off by default): RB_MODE_CHECK_UNBLOCK calls of the throughput form that do not ask for the raw maxima
     // let a wave of the plain count kernel stop once a bin has reached the larger of the read's two thresholds (rb_kernels.hip, EarlyCfg)
     bool early_decision = false;
-    bool multi_one_word = true;  // ... for one-word blocks of up to 2^21 - 1 of them (16 MiB) (RB_MULTI_ONE_WORD=0: the register builds)
+    bool multi_one_word = true;  // ... for one-word blocks of up to 2^22 - 2 of them (32 MiB) (RB_MULTI_ONE_WORD=0: the register builds)
     bool multi_wide = true;      // ... and for blocks of three and four words (RB_MULTI_WIDE=0: those keep the register builds)
     bool multi_wide_six = true;  // ... six tiles in one round for their reads of 257-384 k-mers (RB_MULTI_WIDE_SIX=0: rounds of three tiles)
     bool multi_no_inv = false;  // (bit 4 of rb_engine_set_reads_per_wave's argument: the AND form on merged copies too; measurements)

@@ -322,9 +322,10 @@ inline uint64_t phase_multi_window_ticks(PhaseShape shape, uint32_t slice_log2, 
 // over its twelve slots): four tiles near 165 ticks per MiB of slice, 5-15 % up; six tiles 30-40 % up within 8 % of the optimum
 // (18.9 MiB, 360 bp, 7 slices: 631 ticks 12.57, 687: 10.95; the merged form: 669: 12.15, 727: 10.93) -- the rule stays 5-8 % above it.
 // Tables the rule cuts into 2 MiB slices (up to 13-16 MiB) are within 2-4 % of the best equal cut and keep it.
-// The one-word LDS-offset builds (tables of up to 16 MiB) follow the same curves where their rule asks for 4 MiB slices (equal_slices_fit_one_word.txt:
-// 13 MiB, 250 bp: 8.02 -> 7.3 in six slices; 16 MiB: 8.27 -> 7.5 in seven, 300 bp: 10.59 -> 9.3-9.7 in six) and take the same cut; the one-word
-// REGISTER builds (tables beyond 2^21 - 1 blocks) gain 0-6 % at their best cut and keep the 4 MiB slices.
+// The one-word LDS-offset builds (tables of up to 32 MiB: 22-bit block numbers) follow the same curves where their rule asks for 4 MiB slices
+// (equal_slices_fit_one_word.txt: 13 MiB, 250 bp: 8.02 -> 7.3 in six slices; 16 MiB: 8.27 -> 7.5 in seven, 300 bp: 10.59 -> 9.3-9.7 in six; the
+// 19.8 MB filter of the reference's test data: 8.42 -> 7.78 in eight, 360 bp 12.40 -> 10.69 in seven; guard_one_word_22bit.txt: seven points of 19.8-31 MiB
+// within tolerance) and take the same cut; the one-word REGISTER builds (larger tables) gain 0-6 % at their best cut and keep the 4 MiB slices.
 inline uint32_t phase_multi_equal_slices(PhaseShape shape, int lg, uint32_t slice_log2, uint64_t table_bytes, uint32_t kmers)
 {
     if (lg > 1 || slice_log2 != 22) return 0;
