@@ -381,7 +381,8 @@ def test_narrow_filters_kernel_forms_agree_at_full_size(narrow):
         assert np.array_equal(base[2][:n], exp_dec) and np.array_equal(base[3][:n], exp_st)
 
 
-@pytest.mark.parametrize("bins,mib", [(64, 8.0), (64, 100.0), (128, 60.0), (100, 30.0), (64, 2.0), (128, 5.0), (90, 1.0), (256, 24.0), (150, 40.0), (200, 3.0)])
+@pytest.mark.parametrize("bins,mib", [(64, 8.0), (64, 100.0), (128, 60.0), (100, 30.0), (64, 2.0), (128, 5.0), (90, 1.0), (256, 24.0), (150, 40.0), (200, 3.0),
+                                      (64, 20.0), (50, 31.9), (128, 19.0)])  # (round 6: one-word tables of 16-32 MiB -- 22-bit block numbers -- and the equal cut)
 def test_phased_form_over_its_whole_range_agrees_with_the_plain_kernel(bins, mib):
     """The phased form serves one- and two-word tables of 1.25-128 MiB in slices of 0.5-4 MiB, up to 32 of them (rb_engine.hip,
     phase_slice_log2 / phase_window_ticks): same maxima as the plain kernel on 10^5 reads of 250, 360, 450 and 600 bp across that
