@@ -58,6 +58,7 @@ for mib in [float(x) for x in args.sizes.split(",")]:
             torch.cuda.synchronize()
         seqs, offs, lens = reads_cache[L]
         mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()  # (torch zeroes on its stream; the engine launches on its own)
         ref = [None]
         counts = [0] + sorted({max(1, int(round(mib / float(t)))) for t in args.targets.split(",")})
         scale = 1.0 if L <= 268 else 1.3

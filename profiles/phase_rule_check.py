@@ -65,6 +65,7 @@ for point in args.points.split(","):
         torch.cuda.synchronize()  # torch filled these on ITS stream; the engine launches on its own (non-blocking) stream
     seqs, offs, lens = reads_cache[L]
     mc = torch.zeros((N, 1), dtype=torch.int16, device=dev)
+    torch.cuda.synchronize()  # (torch zeroes on its stream; the engine launches on its own)
     stride = 1 if W == 1 else 2 if W == 2 else 4
     n_blocks = int(mib * (1 << 20) / (8 * stride)) - 3
     d = capi.DeviceIBF.create(0, 64 * W, 3, 13, W * 64 * n_blocks)
